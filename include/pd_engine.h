@@ -1,0 +1,194 @@
+/*
+ * pd_engine.h -- C-ABI of the MI355X-native PoseDiffusion sampling engine (libpd_engine.so).
+ *
+ * This is the drop-in boundary for ONE hot path of facebookresearch/PoseDiffusion: the DDPM
+ * reverse loop over camera-pose tokens and the Geometry-Guided-Sampling (GGS) Sampson step.
+ * The reference is pure Python (no FFI of its own), so each entry point below names the
+ * reference Python function it replaces (paths relative to /root/reference/pose_diffusion/);
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no torch / C++ types.
+ *   - every `float*` / `const float*` documented as DEVICE is a HIP device pointer to
+ *     contiguous row-major fp32 owned by the caller; the engine borrows it for the call.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the HIP default stream).  All calls
+ *     are asynchronous on that stream unless stated; the engine has no host threads.
+ *   - return value: 0 = PD_OK, negative = error; pd_last_error() gives the message
+ *     (thread-local).  The "insufficient valid matches" early exit of GGS is not an error
+ *     (geometry_guided_sampling.py:104-108).
+ *   - one engine per device; not re-entrant per instance.
+ */
+#ifndef PD_ENGINE_H
+#define PD_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PD_OK 0
+#define PD_ERR_INVALID_ARG (-1)   /* NULL pointer, non-positive size, t out of range ...          */
+#define PD_ERR_UNSUPPORTED (-2)   /* shape family the kernels are not built for                  */
+#define PD_ERR_HIP (-3)           /* a HIP runtime call failed (message carries hipGetErrorString)*/
+#define PD_ERR_STATE (-4)         /* e.g. GGS requested for a sequence with no matches uploaded  */
+
+#define PD_MAX_LAYERS 16
+#define PD_POSE_DIM 9             /* absT(3) | quaR wxyz(4) | logFL(2), camera_transform.py:80-97 */
+
+typedef struct pd_engine pd_engine;
+
+/* One nn.TransformerEncoderLayer (models/denoiser.py:88-97, cfgs/default.yaml:27-35).
+ * PyTorch layouts: Linear weight [out, in] row-major.  DEVICE pointers. */
+typedef struct pd_layer_weights {
+    const float *norm1_w, *norm1_b;         /* [d]                                   */
+    const float *in_proj_w, *in_proj_b;     /* [3d, d], [3d]   (q | k | v rows)      */
+    const float *out_proj_w, *out_proj_b;   /* [d, d], [d]                           */
+    const float *norm2_w, *norm2_b;         /* [d]                                   */
+    const float *linear1_w, *linear1_b;     /* [ff, d], [ff]                         */
+    const float *linear2_w, *linear2_b;     /* [d, ff], [d]                          */
+} pd_layer_weights;
+
+/* Everything `Denoiser` + `GaussianDiffusion` hold that the sampler reads
+ * (models/denoiser.py:23-51, util/embedding.py:13-37, models/gaussian_diffuser.py:157-182).
+ * All pointers DEVICE fp32; the engine repacks/copies them at create time and keeps no
+ * reference to the caller's storage afterwards. */
+typedef struct pd_weights {
+    int32_t d_model;        /* 512  */
+    int32_t nhead;          /* 4    */
+    int32_t dim_ff;         /* 1024 */
+    int32_t num_layers;     /* 8    */
+    int32_t z_dim;          /* 384  */
+    int32_t n_harmonic;     /* 10   (PoseEmbedding, embedding.py:41)                     */
+    int32_t t_emb_dim;      /* 256  (TimeStepEmbedding.dim; output is dim/2 = 128)       */
+    int32_t mlp_hidden;     /* 128  (Denoiser.mlp_hidden_dim)                            */
+    int32_t timesteps;      /* 100                                                       */
+    int32_t reserved;
+    const float *time_w0, *time_b0;     /* time_embed.linear.0  [128,256],[128]          */
+    const float *time_w2, *time_b2;     /* time_embed.linear.2  [128,128],[128]          */
+    const float *first_w, *first_b;     /* _first  [d, 189+128+z_dim+1 = 702], [d]       */
+    pd_layer_weights layers[PD_MAX_LAYERS];
+    const float *last0_w, *last0_b;     /* _last.0 [128, d], [128]                       */
+    const float *last_ln_w, *last_ln_b; /* _last.1 LayerNorm [128]                       */
+    const float *last3_w, *last3_b;     /* _last.3 [9,128], [9]                          */
+    /* schedule tables, each [timesteps] (gaussian_diffuser.py:167-182) */
+    const float *sqrt_recip_alphas_cumprod;
+    const float *sqrt_recipm1_alphas_cumprod;
+    const float *posterior_mean_coef1;
+    const float *posterior_mean_coef2;
+    const float *posterior_log_variance_clipped;
+} pd_weights;
+
+/* GGS knobs: cfgs/default.yaml:6-13 as passed through **GGS_cfg to GGS_optimize
+ * (geometry_guided_sampling.py:67-81). */
+typedef struct pd_ggs_cfg {
+    float alpha;            /* 1e-4  */
+    float learning_rate;    /* 1e-2  */
+    int32_t iter_num;       /* 100 (doubled when R, T and FL are all updated, :86-87) */
+    float sampson_max;      /* 10    */
+    int32_t min_matches;    /* 10    */
+    float momentum;         /* 0.9 (torch.optim.SGD at :89) */
+    int32_t wgs_per_seq;    /* 0 = engine picks; >0 = workgroups cooperating on one sequence */
+    int32_t reserved;
+} pd_ggs_cfg;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+
+/* Build an engine on the current HIP device.  Replaces the module construction +
+ * load_state_dict of demo.py:46,56-57 for the sampling path.  Synchronous.
+ * max_B sequences x max_N frames bound every later call (workspaces are sized once). */
+int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_engine **out);
+void pd_engine_destroy(pd_engine *eng);
+const char *pd_last_error(void);
+/* ABI/version string, e.g. "pd_engine 0.1 gfx950". */
+const char *pd_version(void);
+
+/* ---- denoiser + DDPM (GaussianDiffusion.p_sample pieces) --------------------------------- */
+
+/* eps_out[B,N,9] = Denoiser.forward(x[B,N,9], t (same for all B), z[B,N,z_dim])
+ * (models/denoiser.py:53-76).  x, z, eps_out DEVICE. */
+int pd_denoise_step(pd_engine *eng, const float *x, const float *z, int t, int B, int N,
+                    float *eps_out, void *stream);
+
+/* model_mean of p_mean_variance (gaussian_diffuser.py:231-246): runs the denoiser and
+ * x0 = c_recip[t] x - c_recipm1[t] eps ; mean = coef1[t] x0 + coef2[t] x.
+ * mean_out[B,N,9]; x0_out may be NULL.  DEVICE pointers. */
+int pd_p_mean(pd_engine *eng, const float *x, const float *z, int t, int B, int N,
+              float *mean_out, float *x0_out, void *stream);
+
+/* pred = mean + exp(0.5 * posterior_log_variance_clipped[t]) * noise  (gaussian_diffuser.py:280);
+ * noise == NULL means noise = 0 (guided steps and t == 0, :276-278).  DEVICE pointers. */
+int pd_p_finish(pd_engine *eng, const float *mean, const float *noise, int t, int B, int N,
+                float *x_out, void *stream);
+
+/* ---- Geometry-Guided Sampling ------------------------------------------------------------ */
+
+/* Upload the matches of sequence slot `seq` (0 <= seq < max_B).  Replaces the per-call host
+ * prep of geometry_guided_sampling.py:16-45: HOST pointers exactly as demo.py:82-84 holds them
+ * (kp1/kp2 float64 [M,2] pixel coords in the cropped+resized image, i12 int64 [M,2] frame
+ * indices); the fp64->fp32 cast of :167, the pair index of :26-27 and the homogeneous pad of
+ * :29-33 happen inside.  n_frames/height/width = img_shape[0], [2], [3] (:16).
+ * Synchronous (allocates).  M == 0 clears the slot. */
+int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, const double *kp2,
+                       const int64_t *i12, int64_t M, int n_frames, int height, int width);
+
+/* model_mean[B,N,9] (DEVICE, in/out) <- geometry_guided_sampling(model_mean, t, ...) for every
+ * sequence b using match slot b: the five GGS_optimize calls (all, FL, R, T, all) of
+ * geometry_guided_sampling.py:48-63.  stats_out (DEVICE, may be NULL) receives [B,5,4] floats:
+ * per optimisation {sampson_to_print (:169), iterations stepped, last n_valid, last loss}. */
+int pd_ggs_guide(pd_engine *eng, float *model_mean, int B, int N, int t, const pd_ggs_cfg *cfg,
+                 float *stats_out, void *stream);
+
+/* One GGS_optimize call (geometry_guided_sampling.py:67-126) with explicit update flags;
+ * used by the parity tests.  trace_out (DEVICE, may be NULL): [B, iters, N*9 + 3] per-iteration
+ * {x after the step, loss, n_valid, grad-norm} for iterations actually stepped. */
+int pd_ggs_optimize(pd_engine *eng, float *model_mean, int B, int N, int update_R, int update_T,
+                    int update_FL, const pd_ggs_cfg *cfg, float *stats_out, float *trace_out,
+                    void *stream);
+
+/* Sampson loss + analytic gradient at x (no update): loss_out[B,4] = {mean valid sampson,
+ * n_valid, mean(clamp(s, max)), 0}; grad_out[B,N,9].  Parity-test entry for
+ * compute_sampson_distance + backward (geometry_guided_sampling.py:129-172, :110-112). */
+int pd_ggs_loss_grad(pd_engine *eng, const float *x, int B, int N, int update_R, int update_T,
+                     int update_FL, const pd_ggs_cfg *cfg, float *loss_out, float *grad_out,
+                     void *stream);
+
+/* ---- whole sampler ------------------------------------------------------------------------ */
+
+/* GaussianDiffusion.sample / p_sample_loop (gaussian_diffuser.py:284-306).
+ *   z      [B,N,z_dim]                      DEVICE
+ *   noise  [T+1,B,N,9]                      DEVICE  noise[0] = the randn(shape) of :289;
+ *          noise[1+k] = the randn_like of step t = T-1-k (:278); slots the reference never
+ *          draws (t == 0, guided steps) are ignored.
+ *   cond_start_step / ggs: if ggs != NULL, steps with t < cond_start_step run pd_ggs_guide on
+ *          the model mean with noise = 0 (:270-276); ggs == NULL = unguided.
+ *   pose_out    [B,N,9]       DEVICE
+ *   process_out [T+1,B,N,9]   DEVICE, may be NULL
+ *   stats_out   [cond_start_step,B,5,4] DEVICE, may be NULL (see pd_ggs_guide), ordered by
+ *          guided step t = cond_start_step-1 .. 0
+ * use_graph != 0 replays a cached hipGraph of the whole loop (captured on first use). */
+int pd_sample(pd_engine *eng, const float *z, const float *noise, int B, int N, int cond_start_step,
+              const pd_ggs_cfg *ggs, float *pose_out, float *process_out, float *stats_out,
+              int use_graph, void *stream);
+
+/* Final decode pose_encoding_to_camera (camera_transform.py:64-105): enc[B*N,9] ->
+ * R[B*N,9] row-major 3x3, T[B*N,3], focal[B*N,2] (PyTorch3D NDC).  DEVICE pointers. */
+int pd_pose_to_camera(pd_engine *eng, const float *enc, int n_cameras, float *R_out, float *T_out,
+                      float *focal_out, void *stream);
+
+/* ---- measurement helpers ------------------------------------------------------------------ */
+
+/* Times `reps` launches of the dominant kernels with hipEvents on `stream` (the stream the
+ * kernels run on) and returns average milliseconds per launch.  what: 0 = one full denoiser
+ * step (pd_p_mean) at (B,N); 1 = one pd_ggs_guide at (B,N).  Used by bench.py's roofline leg. */
+int pd_time_kernel(pd_engine *eng, int what, int B, int N, const pd_ggs_cfg *cfg, int reps,
+                   float *ms_out, void *stream);
+
+/* Synchronises the device and reports (PD_ERR_STATE) if a bounded spin of the GGS
+ * cross-workgroup exchange gave up since the last check.  PD_OK otherwise. */
+int pd_check_async_error(pd_engine *eng);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PD_ENGINE_H */

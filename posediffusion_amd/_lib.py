@@ -1,0 +1,110 @@
+"""ctypes binding of libpd_engine.so (the C-ABI declared in include/pd_engine.h).
+
+The product path has NO fallback: if the shared library is missing or cannot be loaded this
+module raises, and every engine entry point raises with it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpd_engine.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "include", "pd_engine.h"))
+
+PD_MAX_LAYERS = 16
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class pd_layer_weights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "norm1_w", "norm1_b", "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b",
+        "norm2_w", "norm2_b", "linear1_w", "linear1_b", "linear2_w", "linear2_b")]
+
+
+class pd_weights(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ("d_model", "nhead", "dim_ff", "num_layers", "z_dim", "n_harmonic",
+                                  "t_emb_dim", "mlp_hidden", "timesteps", "reserved")]
+        + [(n, C.c_void_p) for n in ("time_w0", "time_b0", "time_w2", "time_b2", "first_w", "first_b")]
+        + [("layers", pd_layer_weights * PD_MAX_LAYERS)]
+        + [(n, C.c_void_p) for n in ("last0_w", "last0_b", "last_ln_w", "last_ln_b", "last3_w", "last3_b",
+                                     "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                                     "posterior_mean_coef1", "posterior_mean_coef2",
+                                     "posterior_log_variance_clipped")]
+    )
+
+
+class pd_ggs_cfg(C.Structure):
+    _fields_ = [("alpha", C.c_float), ("learning_rate", C.c_float), ("iter_num", C.c_int32),
+                ("sampson_max", C.c_float), ("min_matches", C.c_int32), ("momentum", C.c_float),
+                ("wgs_per_seq", C.c_int32), ("reserved", C.c_int32)]
+
+
+# name -> (restype, argtypes); kept in one table so the "exports every declared symbol" test and
+# the binding cannot drift apart.
+_vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
+SIGNATURES = {
+    "pd_engine_create": (_i, [C.POINTER(pd_weights), _i, _i, C.POINTER(_vp)]),
+    "pd_engine_destroy": (None, [_vp]),
+    "pd_last_error": (C.c_char_p, []),
+    "pd_version": (C.c_char_p, []),
+    "pd_denoise_step": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "pd_p_mean": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "pd_p_finish": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "pd_ggs_set_matches": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i]),
+    "pd_ggs_guide": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp]),
+    "pd_ggs_optimize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp]),
+    "pd_ggs_loss_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp]),
+    "pd_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp, _i, _vp]),
+    "pd_pose_to_camera": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "pd_time_kernel": (_i, [_vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _i, C.POINTER(C.c_float), _vp]),
+    "pd_check_async_error": (_i, [_vp]),
+}
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libpd_engine.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j4"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0 or not os.path.isfile(LIB_PATH):
+        raise RuntimeError("building libpd_engine.so failed:\n" + res.stdout[-4000:])
+    return LIB_PATH
+
+
+def load():
+    """dlopen the engine.  torch is imported first so that libamdhip64.so.7 resolves to the copy
+    PyTorch-ROCm already loaded (one HIP runtime per process: device pointers and streams are
+    shared with torch)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"posediffusion_amd: HIP engine library not found at {LIB_PATH}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C posediffusion_amd/csrc`). "
+            "There is no CPU fallback.")
+    import torch  # noqa: F401  (loads the HIP runtime first)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = library does not match the header
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load().pd_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "pd_engine"):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")

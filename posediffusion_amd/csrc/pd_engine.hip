@@ -1,0 +1,394 @@
+// pd_engine.hip -- C-ABI entry points (include/pd_engine.h), lifecycle, the sampling loop and its
+// hipGraph capture.  The kernels live in pd_denoiser.hip and pd_ggs.hip.
+//
+// Replaces (paths relative to /root/reference/pose_diffusion/):
+//   models/gaussian_diffuser.py:248-306   p_sample / p_sample_loop / sample
+//   util/camera_transform.py:64-105      pose_encoding_to_camera (final decode)
+#include "pd_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local char g_err[1024] = "";
+
+void pd_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *pd_last_error(void) { return g_err; }
+extern "C" const char *pd_version(void) { return "pd_engine 0.1 gfx950"; }
+
+// ---- small kernels ------------------------------------------------------------------------------
+__global__ void pd_finish_kernel(const float *__restrict__ mean, const float *__restrict__ noise, float sigma, int n,
+                                 float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = noise ? mean[i] + sigma * noise[i] : mean[i];   // gaussian_diffuser.py:280
+}
+
+__global__ void pd_camera_kernel(const float *__restrict__ enc, int n, float *__restrict__ R, float *__restrict__ T,
+                                 float *__restrict__ F) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const float *x = enc + (size_t)c * 9;
+    const float r = x[3], i = x[4], j = x[5], k = x[6];
+    const float two_s = 2.0f / (r * r + i * i + j * j + k * k);   // pytorch3d quaternion_to_matrix
+    float *o = R + (size_t)c * 9;
+    o[0] = 1.0f - two_s * (j * j + k * k);
+    o[1] = two_s * (i * j - k * r);
+    o[2] = two_s * (i * k + j * r);
+    o[3] = two_s * (i * j + k * r);
+    o[4] = 1.0f - two_s * (i * i + k * k);
+    o[5] = two_s * (j * k - i * r);
+    o[6] = two_s * (i * k - j * r);
+    o[7] = two_s * (j * k + i * r);
+    o[8] = 1.0f - two_s * (i * i + j * j);
+    T[c * 3 + 0] = x[0];
+    T[c * 3 + 1] = x[1];
+    T[c * 3 + 2] = x[2];
+    F[c * 2 + 0] = fminf(fmaxf(expf(x[7] + 1.8f), 0.1f), 20.0f);   // camera_transform.py:89-97
+    F[c * 2 + 1] = fminf(fmaxf(expf(x[8] + 1.8f), 0.1f), 20.0f);
+}
+
+// ---- lifecycle ----------------------------------------------------------------------------------
+static int fetch_table(std::vector<float> &dst, const float *dev, int n) {
+    if (!dev) {
+        pd_set_error("pd_engine_create: a schedule table pointer is NULL");
+        return PD_ERR_INVALID_ARG;
+    }
+    dst.resize(n);
+    PD_HIP_CHECK(hipMemcpy(dst.data(), dev, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return PD_OK;
+}
+
+extern "C" void pd_engine_destroy(pd_engine *eng) {
+    if (!eng) return;
+    (void)hipSetDevice(eng->device);
+    (void)hipDeviceSynchronize();
+    for (auto &g : eng->graphs) (void)hipGraphExecDestroy(g.second);
+    for (auto &s : eng->seqs) pd_ggs_free_seq(s);
+    pd_denoiser_destroy(eng);
+    void *ptrs[] = {eng->d_seqs, eng->d_xchg, eng->d_err, eng->d_z, eng->d_noise, eng->d_process, eng->d_mean, eng->d_stats};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete eng;
+}
+
+extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_engine **out) {
+    if (!w || !out || max_B <= 0 || max_N <= 0 || max_N > PD_MAX_FRAMES || w->timesteps <= 0 || w->timesteps > 4096) {
+        pd_set_error("pd_engine_create: invalid arguments (max_B=%d, max_N=%d must be in [1,%d])", max_B, max_N, PD_MAX_FRAMES);
+        return PD_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    pd_engine *eng = new pd_engine();
+    int rc = PD_OK;
+    do {
+        if (hipGetDevice(&eng->device) != hipSuccess) {
+            pd_set_error("pd_engine_create: no HIP device");
+            rc = PD_ERR_HIP;
+            break;
+        }
+        eng->max_B = max_B;
+        eng->max_N = max_N;
+        eng->d_model = w->d_model;
+        eng->nhead = w->nhead;
+        eng->dim_ff = w->dim_ff;
+        eng->num_layers = w->num_layers;
+        eng->z_dim = w->z_dim;
+        eng->timesteps = w->timesteps;
+        if ((rc = fetch_table(eng->c_recip, w->sqrt_recip_alphas_cumprod, w->timesteps))) break;
+        if ((rc = fetch_table(eng->c_recipm1, w->sqrt_recipm1_alphas_cumprod, w->timesteps))) break;
+        if ((rc = fetch_table(eng->coef1, w->posterior_mean_coef1, w->timesteps))) break;
+        if ((rc = fetch_table(eng->coef2, w->posterior_mean_coef2, w->timesteps))) break;
+        if ((rc = fetch_table(eng->logvar, w->posterior_log_variance_clipped, w->timesteps))) break;
+        if ((rc = pd_denoiser_create(eng, w))) break;
+        if ((rc = pd_ggs_init())) break;
+        eng->seqs.resize(max_B);
+        const int T = w->timesteps;
+        const size_t bn9 = (size_t)max_B * max_N * 9;
+        // all-pairs upper bound on work items for the exchange buffer: N*(N-1) ordered pairs, 1 item each,
+        // plus slack for pairs split into several items
+        eng->xchg_granules = (size_t)(max_N * max_N + 256) * PD_ITEM_VALS;
+#define PD_ALLOC(ptr, bytes)                                             \
+    if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) {             \
+        pd_set_error("pd_engine_create: hipMalloc of %zu B failed", (size_t)(bytes)); \
+        rc = PD_ERR_HIP;                                                 \
+        break;                                                           \
+    }
+        PD_ALLOC(eng->d_seqs, sizeof(PdSeqDesc) * max_B);
+        PD_ALLOC(eng->d_xchg, sizeof(unsigned long long) * 2 * eng->xchg_granules * max_B);
+        PD_ALLOC(eng->d_err, 64);
+        PD_ALLOC(eng->d_z, sizeof(float) * max_B * max_N * w->z_dim);
+        PD_ALLOC(eng->d_noise, sizeof(float) * (T + 1) * bn9);
+        PD_ALLOC(eng->d_process, sizeof(float) * (T + 1) * bn9);
+        PD_ALLOC(eng->d_mean, sizeof(float) * bn9);
+        PD_ALLOC(eng->d_stats, sizeof(float) * (size_t)T * max_B * 5 * 4);
+#undef PD_ALLOC
+        if (hipMemset(eng->d_seqs, 0, sizeof(PdSeqDesc) * max_B) != hipSuccess ||
+            hipMemset(eng->d_err, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            pd_set_error("pd_engine_create: hipMemset failed");
+            rc = PD_ERR_HIP;
+            break;
+        }
+    } while (0);
+    if (rc) {
+        pd_engine_destroy(eng);
+        return rc;
+    }
+    *out = eng;
+    return PD_OK;
+}
+
+// ---- step-level API -----------------------------------------------------------------------------
+extern "C" int pd_denoise_step(pd_engine *eng, const float *x, const float *z, int t, int B, int N, float *eps_out,
+                               void *stream) {
+    if (!eng || !eps_out) {
+        pd_set_error("pd_denoise_step: NULL argument");
+        return PD_ERR_INVALID_ARG;
+    }
+    return pd_denoiser_launch(eng, x, z, t, B, N, eps_out, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int pd_p_mean(pd_engine *eng, const float *x, const float *z, int t, int B, int N, float *mean_out,
+                         float *x0_out, void *stream) {
+    if (!eng || !mean_out) {
+        pd_set_error("pd_p_mean: NULL argument");
+        return PD_ERR_INVALID_ARG;
+    }
+    return pd_denoiser_launch(eng, x, z, t, B, N, nullptr, mean_out, x0_out, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int pd_p_finish(pd_engine *eng, const float *mean, const float *noise, int t, int B, int N, float *x_out,
+                           void *stream) {
+    if (!eng || !mean || !x_out || B <= 0 || N <= 0 || t < 0 || t >= eng->timesteps) {
+        pd_set_error("pd_p_finish: invalid arguments");
+        return PD_ERR_INVALID_ARG;
+    }
+    const int n = B * N * 9;
+    hipLaunchKernelGGL(pd_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, noise,
+                       expf(0.5f * eng->logvar[t]), n, x_out);
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}
+
+extern "C" int pd_pose_to_camera(pd_engine *eng, const float *enc, int n_cameras, float *R_out, float *T_out,
+                                 float *focal_out, void *stream) {
+    if (!eng || !enc || !R_out || !T_out || !focal_out || n_cameras <= 0) {
+        pd_set_error("pd_pose_to_camera: invalid arguments");
+        return PD_ERR_INVALID_ARG;
+    }
+    hipLaunchKernelGGL(pd_camera_kernel, dim3((n_cameras + 63) / 64), dim3(64), 0, (hipStream_t)stream, enc, n_cameras,
+                       R_out, T_out, focal_out);
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}
+
+// ---- GGS API ------------------------------------------------------------------------------------
+static void guide_stages(const pd_ggs_cfg *cfg, PdGgsStage *st) {
+    // geometry_guided_sampling.py:48-63: all (2x iters, :86-87), FL, R, T, all
+    const int it = cfg->iter_num;
+    st[0] = {1, 1, 1, 2 * it};
+    st[1] = {0, 0, 1, it};
+    st[2] = {1, 0, 0, it};
+    st[3] = {0, 1, 0, it};
+    st[4] = {1, 1, 1, 2 * it};
+}
+
+static int check_cfg(const pd_ggs_cfg *cfg, const char *who) {
+    if (!cfg || cfg->iter_num < 0 || !(cfg->learning_rate > 0.0f)) {
+        pd_set_error("%s: invalid pd_ggs_cfg", who);
+        return PD_ERR_INVALID_ARG;
+    }
+    return PD_OK;
+}
+
+extern "C" int pd_ggs_guide(pd_engine *eng, float *model_mean, int B, int N, int t, const pd_ggs_cfg *cfg,
+                            float *stats_out, void *stream) {
+    (void)t;   // only printed by the reference (:124)
+    int rc = check_cfg(cfg, "pd_ggs_guide");
+    if (rc) return rc;
+    PdGgsStage st[5];
+    guide_stages(cfg, st);
+    return pd_ggs_launch(eng, model_mean, B, N, st, 5, cfg, 0, stats_out, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int pd_ggs_optimize(pd_engine *eng, float *model_mean, int B, int N, int update_R, int update_T, int update_FL,
+                               const pd_ggs_cfg *cfg, float *stats_out, float *trace_out, void *stream) {
+    int rc = check_cfg(cfg, "pd_ggs_optimize");
+    if (rc) return rc;
+    PdGgsStage st = {update_R ? 1 : 0, update_T ? 1 : 0, update_FL ? 1 : 0, cfg->iter_num};
+    if (update_R && update_T && update_FL) st.iters *= 2;   // :86-87
+    return pd_ggs_launch(eng, model_mean, B, N, &st, 1, cfg, 0, stats_out, trace_out, st.iters, nullptr, nullptr,
+                         (hipStream_t)stream);
+}
+
+extern "C" int pd_ggs_loss_grad(pd_engine *eng, const float *x, int B, int N, int update_R, int update_T, int update_FL,
+                                const pd_ggs_cfg *cfg, float *loss_out, float *grad_out, void *stream) {
+    int rc = check_cfg(cfg, "pd_ggs_loss_grad");
+    if (rc) return rc;
+    if (!loss_out || !grad_out) {
+        pd_set_error("pd_ggs_loss_grad: NULL output");
+        return PD_ERR_INVALID_ARG;
+    }
+    PdGgsStage st = {update_R ? 1 : 0, update_T ? 1 : 0, update_FL ? 1 : 0, 1};
+    return pd_ggs_launch(eng, const_cast<float *>(x), B, N, &st, 1, cfg, 1, nullptr, nullptr, 0, loss_out, grad_out,
+                         (hipStream_t)stream);
+}
+
+// ---- whole sampler ------------------------------------------------------------------------------
+// Issues every launch of p_sample_loop on `s`, reading/writing only engine-owned buffers (so the
+// same code can be captured into a graph and replayed).
+static int issue_loop(pd_engine *eng, int B, int N, int cond_start, const pd_ggs_cfg *ggs, bool want_stats, hipStream_t s) {
+    const int T = eng->timesteps;
+    const size_t bn9 = (size_t)B * N * 9;
+    float *proc = eng->d_process;
+    for (int step = 0; step < T; ++step) {
+        const int t = T - 1 - step;                               // reversed(range(T))  :296
+        const float *x = proc + (size_t)step * bn9;
+        float *xn = proc + (size_t)(step + 1) * bn9;
+        const bool guided = ggs && t < cond_start;                // :270
+        int rc;
+        if (guided) {
+            // mean -> next slot, GGS refines it in place, noise = 0  (:272-276)
+            rc = pd_denoiser_launch(eng, x, eng->d_z, t, B, N, nullptr, nullptr, nullptr, nullptr, xn, s);
+            if (rc) return rc;
+            float *st = want_stats ? eng->d_stats + (size_t)(cond_start - 1 - t) * B * 5 * 4 : nullptr;
+            rc = pd_ggs_guide(eng, xn, B, N, t, ggs, st, s);
+        } else {
+            const float *nz = (t > 0) ? eng->d_noise + (size_t)(step + 1) * bn9 : nullptr;   // :278
+            rc = pd_denoiser_launch(eng, x, eng->d_z, t, B, N, nullptr, nullptr, nullptr, nz, xn, s);
+        }
+        if (rc) return rc;
+    }
+    return PD_OK;
+}
+
+static bool same_cfg(const pd_ggs_cfg &a, const pd_ggs_cfg &b) { return memcmp(&a, &b, sizeof(a)) == 0; }
+
+extern "C" int pd_sample(pd_engine *eng, const float *z, const float *noise, int B, int N, int cond_start_step,
+                         const pd_ggs_cfg *ggs, float *pose_out, float *process_out, float *stats_out, int use_graph,
+                         void *stream) {
+    if (!eng || !z || !noise || !pose_out || B <= 0 || B > eng->max_B || N <= 0 || N > eng->max_N ||
+        cond_start_step < 0 || cond_start_step > eng->timesteps) {
+        pd_set_error("pd_sample: invalid arguments (B=%d N=%d cond_start_step=%d)", B, N, cond_start_step);
+        return PD_ERR_INVALID_ARG;
+    }
+    if (ggs) {
+        int rc = check_cfg(ggs, "pd_sample");
+        if (rc) return rc;
+        if (cond_start_step > 0) {
+            for (int b = 0; b < B; ++b)
+                if (!eng->seqs[b].blob) {
+                    pd_set_error("pd_sample: GGS requested but sequence slot %d has no matches", b);
+                    return PD_ERR_STATE;
+                }
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int T = eng->timesteps;
+    const size_t bn9 = (size_t)B * N * 9;
+    const bool has_ggs = ggs && cond_start_step > 0;
+    const bool want_stats = has_ggs && stats_out;
+    PD_HIP_CHECK(hipMemcpyAsync(eng->d_z, z, sizeof(float) * B * N * eng->z_dim, hipMemcpyDeviceToDevice, s));
+    PD_HIP_CHECK(hipMemcpyAsync(eng->d_noise, noise, sizeof(float) * (T + 1) * bn9, hipMemcpyDeviceToDevice, s));
+    PD_HIP_CHECK(hipMemcpyAsync(eng->d_process, noise, sizeof(float) * bn9, hipMemcpyDeviceToDevice, s));   // :289
+    if (!use_graph) {
+        int rc = issue_loop(eng, B, N, cond_start_step, has_ggs ? ggs : nullptr, true, s);
+        if (rc) return rc;
+    } else {
+        pd_engine::GraphKey key;
+        memset(&key, 0, sizeof(key));
+        key.B = B;
+        key.N = N;
+        key.cond_start = has_ggs ? cond_start_step : 0;
+        key.has_ggs = has_ggs;
+        if (has_ggs) key.cfg = *ggs;
+        hipGraphExec_t exec = nullptr;
+        for (auto &g : eng->graphs)
+            if (g.first.B == B && g.first.N == N && g.first.cond_start == key.cond_start && g.first.has_ggs == key.has_ggs &&
+                same_cfg(g.first.cfg, key.cfg))
+                exec = g.second;
+        if (!exec) {
+            // capture on a private stream so the caller's stream state is untouched
+            if (!eng->own_stream) PD_HIP_CHECK(hipStreamCreateWithFlags(&eng->own_stream, hipStreamNonBlocking));
+            hipGraph_t graph = nullptr;
+            PD_HIP_CHECK(hipStreamBeginCapture(eng->own_stream, hipStreamCaptureModeThreadLocal));
+            int rc = issue_loop(eng, B, N, cond_start_step, has_ggs ? ggs : nullptr, true, eng->own_stream);
+            hipError_t ce = hipStreamEndCapture(eng->own_stream, &graph);
+            if (rc) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return rc;
+            }
+            PD_HIP_CHECK(ce);
+            PD_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            PD_HIP_CHECK(hipGraphDestroy(graph));
+            eng->graphs.push_back({key, exec});
+        }
+        PD_HIP_CHECK(hipGraphLaunch(exec, s));
+    }
+    PD_HIP_CHECK(hipMemcpyAsync(pose_out, eng->d_process + (size_t)T * bn9, sizeof(float) * bn9, hipMemcpyDeviceToDevice, s));
+    if (process_out)
+        PD_HIP_CHECK(hipMemcpyAsync(process_out, eng->d_process, sizeof(float) * (T + 1) * bn9, hipMemcpyDeviceToDevice, s));
+    if (want_stats)
+        PD_HIP_CHECK(hipMemcpyAsync(stats_out, eng->d_stats, sizeof(float) * (size_t)cond_start_step * B * 5 * 4,
+                                    hipMemcpyDeviceToDevice, s));
+    return PD_OK;
+}
+
+// ---- measurement helper -------------------------------------------------------------------------
+extern "C" int pd_time_kernel(pd_engine *eng, int what, int B, int N, const pd_ggs_cfg *cfg, int reps, float *ms_out,
+                              void *stream) {
+    if (!eng || !ms_out || reps <= 0 || B <= 0 || B > eng->max_B || N <= 0 || N > eng->max_N) {
+        pd_set_error("pd_time_kernel: invalid arguments");
+        return PD_ERR_INVALID_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    PD_HIP_CHECK(hipEventCreate(&e0));
+    PD_HIP_CHECK(hipEventCreate(&e1));
+    const size_t bn9 = (size_t)B * N * 9;
+    int rc = PD_OK;
+    // inputs: whatever the sampler buffers currently hold (process slot 0 = a pose sample, d_z)
+    if (what == 0) {
+        rc = pd_denoiser_launch(eng, eng->d_process, eng->d_z, 50, B, N, nullptr, eng->d_mean, nullptr, nullptr, nullptr, s);
+        PD_HIP_CHECK(hipEventRecord(e0, s));
+        for (int i = 0; i < reps && !rc; ++i)
+            rc = pd_denoiser_launch(eng, eng->d_process, eng->d_z, 50, B, N, nullptr, eng->d_mean, nullptr, nullptr, nullptr, s);
+        PD_HIP_CHECK(hipEventRecord(e1, s));
+    } else {
+        if ((rc = check_cfg(cfg, "pd_time_kernel"))) return rc;
+        // GGS on a scratch copy of the final pose of the last pd_sample (slot T), so timing does not drift
+        PD_HIP_CHECK(hipEventRecord(e0, s));
+        for (int i = 0; i < reps && !rc; ++i) {
+            PD_HIP_CHECK(hipMemcpyAsync(eng->d_mean, eng->d_process + (size_t)eng->timesteps * bn9, sizeof(float) * bn9,
+                                        hipMemcpyDeviceToDevice, s));
+            rc = pd_ggs_guide(eng, eng->d_mean, B, N, 0, cfg, nullptr, s);
+        }
+        PD_HIP_CHECK(hipEventRecord(e1, s));
+    }
+    if (rc) return rc;
+    PD_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    PD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / (float)reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return PD_OK;
+}
+
+// async error word of the GGS exchange (nonzero = a bounded spin gave up); synchronises the device
+extern "C" int pd_check_async_error(pd_engine *eng) {
+    if (!eng) return PD_ERR_INVALID_ARG;
+    unsigned int v = 0;
+    PD_HIP_CHECK(hipDeviceSynchronize());
+    PD_HIP_CHECK(hipMemcpy(&v, eng->d_err, sizeof(v), hipMemcpyDeviceToHost));
+    if (v) {
+        pd_set_error("GGS cross-workgroup exchange timed out (flag=%u)", v);
+        (void)hipMemset(eng->d_err, 0, sizeof(v));
+        return PD_ERR_STATE;
+    }
+    return PD_OK;
+}

@@ -1,0 +1,817 @@
+// pd_ggs.hip -- Geometry-Guided Sampling as ONE persistent kernel per guided diffusion step.
+//
+// Replaces (paths relative to /root/reference/pose_diffusion/):
+//   util/geometry_guided_sampling.py:14-64   geometry_guided_sampling  (5 optimisations)
+//   util/geometry_guided_sampling.py:67-126  GGS_optimize  (clipped momentum SGD, early exit)
+//   util/geometry_guided_sampling.py:129-172 compute_sampson_distance
+//   util/get_fundamental_matrix.py:14-51     F for the frame pairs that own matches
+//   util/camera_transform.py:80-97           pose decode (quat -> R, clamp(exp(logFL + 1.8)))
+// plus torch autograd's backward of all of the above, derived by hand (DESIGN.md "GGS backward";
+// the same derivation in fp64 numpy is oracle/pd_oracle.py:sampson_loss_grad_analytic).
+//
+// Mapping to CDNA4.  The reference launches ~1850 ATen kernels per iteration and 700 iterations
+// per guided step; the chain is strictly sequential, so the design goal is launch-free, sync-cheap
+// iterations:
+//   * one launch runs every iteration of every stage; pose parameters, momentum and all per-frame
+//     state live in registers/LDS of the owning workgroup(s);
+//   * matches are pair-sorted at upload; a wavefront owns one (pair, <=512 matches) work item, the
+//     pair's F is wave-uniform, the per-match Sampson residual + dL/dF is accumulated per lane and
+//     reduced with a 64-lane butterfly (fixed order -> bitwise reproducible);
+//   * k workgroups may cooperate on one sequence (k = ceil(items / 8) when CUs are free): each
+//     publishes its 12 per-item sums as tagged 8-byte granules (write-through, data-is-the-flag,
+//     guide section 6 G16 R2) and every workgroup gathers all of them, then redundantly runs the
+//     tiny per-frame backward + SGD update, so there is exactly ONE cross-workgroup hop per
+//     iteration and no broadcast of the new parameters.  All arithmetic orders are fixed, so the
+//     replicas stay bitwise identical (and k = 1 and k > 1 give identical bits).
+//   * blockIdx -> (sequence, workgroup) is XCD-aware: with B % 8 == 0 all workgroups of a sequence
+//     sit on one XCD (dispatcher places block b on XCD b % 8) so the exchange stays in one L2.
+//     That is a speed choice only; correctness uses agent-scope granules and bounded spins.
+#include "pd_internal.h"
+
+#include <algorithm>
+#include <math.h>
+#include <string.h>
+
+typedef unsigned long long u64;
+
+// --------------------------------------------------------------------------------------------
+// device helpers
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_allsum(float v) {
+    // xor-butterfly: every lane ends with bitwise the same sum (fp add is commutative).
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct Cam {   // shared intrinsics of the step: A = K^-1 = [[a0,0,c0],[0,a1,c1],[0,0,1]]
+    float a0, a1, c0, c1;
+};
+
+// forward of get_essential_matrix for one ordered pair (camera 1 = i, camera 2 = j)
+// (get_fundamental_matrix.py:45-51), keeping the intermediates the backward needs.
+struct PairFwd {
+    float R12[9], t12[3], Et[3], E[9];
+};
+
+__device__ __forceinline__ void pair_forward(const float *Ri, const float *ti, const float *Rj, const float *tj,
+                                             PairFwd &o) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            o.R12[a * 3 + c] = Rj[a * 3 + 0] * Ri[c * 3 + 0] + Rj[a * 3 + 1] * Ri[c * 3 + 1] + Rj[a * 3 + 2] * Ri[c * 3 + 2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        o.t12[a] = tj[a] - (o.R12[a * 3 + 0] * ti[0] + o.R12[a * 3 + 1] * ti[1] + o.R12[a * 3 + 2] * ti[2]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        o.Et[a] = -(o.R12[0 * 3 + a] * o.t12[0] + o.R12[1 * 3 + a] * o.t12[1] + o.R12[2 * 3 + a] * o.t12[2]);
+    const float ex = o.Et[0], ey = o.Et[1], ez = o.Et[2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {   // E = R12 * hat(Et), hat = [[0,-z,y],[z,0,-x],[-y,x,0]]
+        o.E[a * 3 + 0] = o.R12[a * 3 + 1] * ez - o.R12[a * 3 + 2] * ey;
+        o.E[a * 3 + 1] = o.R12[a * 3 + 2] * ex - o.R12[a * 3 + 0] * ez;
+        o.E[a * 3 + 2] = o.R12[a * 3 + 0] * ey - o.R12[a * 3 + 1] * ex;
+    }
+}
+
+// F as used by _sampson_distance after the permute of geometry_guided_sampling.py:155:
+// F = (K2^-T E K1^-1)^T = (A^T E A)^T   (get_fundamental_matrix.py:41; K1 = K2, focal is the mean)
+__device__ __forceinline__ void fundamental_from_E(const float *E, const Cam &c, float *F) {
+    float Mx[9];   // A^T E
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        Mx[0 * 3 + q] = c.a0 * E[0 * 3 + q];
+        Mx[1 * 3 + q] = c.a1 * E[1 * 3 + q];
+        Mx[2 * 3 + q] = c.c0 * E[0 * 3 + q] + c.c1 * E[1 * 3 + q] + E[2 * 3 + q];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {   // Fo = Mx A ; F[c][r] = Fo[r][c]
+        F[0 * 3 + r] = Mx[r * 3 + 0] * c.a0;
+        F[1 * 3 + r] = Mx[r * 3 + 1] * c.a1;
+        F[2 * 3 + r] = Mx[r * 3 + 0] * c.c0 + Mx[r * 3 + 1] * c.c1 + Mx[r * 3 + 2];
+    }
+}
+
+// LDS carve (floats).  Everything lives in the one dynamic region (guide G17).
+#define PD_GGS_LDS_FIXED (64 * 9 + 64 * 3 + 64 * 2 + 64 * 2 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8)
+struct Lds {
+    float *Rc;     // [64*9]  R_cv per frame  (opencv_from_cameras_projection)
+    float *tc;     // [64*3]
+    float *fl;     // [64*2]  clamped focal per frame
+    float *flp;    // [64*2]  clamp pass-through mask (1/0)
+    float *cam;    // [8]     a0,a1,c0,c1,fbar_x,fbar_y
+    float *gT;     // [64*3]  per-frame dL/dT  (un-normalised: not yet divided by n_valid)
+    float *gR;     // [64*9]  per-frame dL/dR  (PyTorch3D R, un-normalised)
+    float *gA;     // [64*4]  per-frame partial dL/dA {00,02,11,12}
+    float *ctl;    // [8]     ctl[0] = stage done flag, ctl[1] = abort
+    int4 *itab;    // [n_slots] (first match, count, i, j) of the local items
+    float *F;      // [n_slots*9]
+    float *item;   // [n_items*12]
+};
+
+__device__ __forceinline__ Lds carve(float *base, int n_slots) {
+    Lds L;
+    L.Rc = base;
+    L.tc = L.Rc + 64 * 9;
+    L.fl = L.tc + 64 * 3;
+    L.flp = L.fl + 64 * 2;
+    L.cam = L.flp + 64 * 2;
+    L.gT = L.cam + 8;
+    L.gR = L.gT + 64 * 3;
+    L.gA = L.gR + 64 * 9;
+    L.ctl = L.gA + 64 * 4;
+    L.itab = (int4 *)(L.ctl + 8);
+    L.F = (float *)(L.itab + n_slots);
+    L.item = L.F + n_slots * 9 + ((4 - ((n_slots * 9) & 3)) & 3);
+    return L;
+}
+static size_t ggs_lds_bytes(int n_slots, int n_items) {
+    size_t f9 = (size_t)n_slots * 9;
+    f9 += (4 - (f9 & 3)) & 3;
+    return ((size_t)PD_GGS_LDS_FIXED + f9 + (size_t)n_items * PD_ITEM_VALS) * 4 + (size_t)n_slots * 16;
+}
+
+// decode one frame's 9-vector into R_cv, t_cv, focal (camera_transform.py:80-97 + pytorch3d
+// quaternion_to_matrix + opencv_from_cameras_projection); executed by lane n of wave 0.
+__device__ __forceinline__ void decode_frame(const float *x, float *Rc, float *tc, float &flx, float &fly,
+                                             float &px, float &py) {
+    const float r = x[3], i = x[4], j = x[5], k = x[6];
+    const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+    float R[9];
+    R[0] = 1.0f - two_s * (j * j + k * k);
+    R[1] = two_s * (i * j - k * r);
+    R[2] = two_s * (i * k + j * r);
+    R[3] = two_s * (i * j + k * r);
+    R[4] = 1.0f - two_s * (i * i + k * k);
+    R[5] = two_s * (j * k - i * r);
+    R[6] = two_s * (i * k - j * r);
+    R[7] = two_s * (j * k + i * r);
+    R[8] = 1.0f - two_s * (i * i + j * j);
+    // Rc[a][b] = D[a] * R[b][a], D = diag(-1,-1,1); tc = D * T
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Rc[a * 3 + c] = (a < 2 ? -1.0f : 1.0f) * R[c * 3 + a];
+    tc[0] = -x[0];
+    tc[1] = -x[1];
+    tc[2] = x[2];
+    const float fx = expf(x[7] + 1.8f), fy = expf(x[8] + 1.8f);
+    px = (fx >= 0.1f && fx <= 20.0f) ? 1.0f : 0.0f;   // torch.clamp backward passes min <= v <= max
+    py = (fy >= 0.1f && fy <= 20.0f) ? 1.0f : 0.0f;
+    flx = fminf(fmaxf(fx, 0.1f), 20.0f);
+    fly = fminf(fmaxf(fy, 0.1f), 20.0f);
+}
+
+// wave 0: publish the decoded cameras of the current parameters to LDS
+__device__ __forceinline__ void decode_all(const Lds &L, const float *xr, int lane, int N, const PdSeqDesc &D) {
+    float flx = 0.f, fly = 0.f, px = 0.f, py = 0.f;
+    if (lane < N) {
+        decode_frame(xr, &L.Rc[lane * 9], &L.tc[lane * 3], flx, fly, px, py);
+        L.fl[lane * 2] = flx;
+        L.fl[lane * 2 + 1] = fly;
+        L.flp[lane * 2] = px;
+        L.flp[lane * 2 + 1] = py;
+    }
+    // focal_length.mean(dim=0) over all cameras (geometry_guided_sampling.py:142)
+    const float fbx = wave_allsum(flx) / (float)N, fby = wave_allsum(fly) / (float)N;
+    if (lane == 0) {
+        const float a0 = 1.0f / (fbx * D.sc), a1 = 1.0f / (fby * D.sc);
+        L.cam[0] = a0;
+        L.cam[1] = a1;
+        L.cam[2] = -D.cx * a0;
+        L.cam[3] = -D.cy * a1;
+        L.cam[4] = fbx;
+        L.cam[5] = fby;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// the kernel
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, int B, int n_slots) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x % B, wg = blockIdx.x / B;   // XCD-aware: see header comment
+    const PdSeqDesc D = P.seqs[b];
+    const int N = P.N, k = P.k;
+    const int nW = k * PD_GGS_WAVES;
+    const int n_items = D.n_items;
+    const Lds L = carve(smem, n_slots);
+    float *xg = P.x + (size_t)b * N * PD_POSE_DIM;
+    u64 *xchg = P.xchg ? P.xchg + (size_t)b * 2 * P.xchg_stride : nullptr;
+
+    // wave 0, lane n owns frame n: parameters + momentum in registers for the whole launch
+    float xr[9], mom[9];
+    const bool own = (wave == 0 && lane < N);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        xr[c] = own ? xg[lane * 9 + c] : 0.0f;
+        mom[c] = 0.0f;
+    }
+    // local item table -> LDS (slot = wave + 8 * round <-> item = wg*8 + wave + round * nW)
+    for (int s = tid; s < n_slots; s += PD_GGS_THREADS) {
+        const int item = wg * PD_GGS_WAVES + (s & 7) + (s >> 3) * nW;
+        int4 e = make_int4(0, 0, 0, 0);
+        if (item < n_items) {
+            const int4 it = D.items[item];
+            const int2 ij = D.pair_ij[it.x];
+            e = make_int4(it.y, it.z, ij.x, ij.y);
+        }
+        L.itab[s] = e;
+    }
+    if (tid == 0) {
+        L.ctl[0] = 0.0f;
+        L.ctl[1] = 0.0f;
+    }
+    if (wave == 0) decode_all(L, xr, lane, N, D);
+    __syncthreads();
+
+    unsigned epoch = 0;
+    int trace_row = 0;
+    const float inv_M = 1.0f / (float)D.M;
+    for (int st = 0; st < P.n_stages; ++st) {
+        const PdGgsStage S = P.stages[st];
+        int stepped = 0;
+        float last_print = __int_as_float(0x7fc00000), last_cnt = 0.0f, last_loss = __int_as_float(0x7fc00000);
+        for (int it = 0; it < S.iters; ++it) {
+            // ---- P1: F for the pairs of this workgroup's items -------------------------------
+            const Cam cam = {L.cam[0], L.cam[1], L.cam[2], L.cam[3]};
+            for (int s = tid; s < n_slots; s += PD_GGS_THREADS) {
+                const int4 e = L.itab[s];
+                if (e.y > 0) {
+                    float Ri[9], Rj[9], ti[3], tj[3];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) {
+                        Ri[c] = L.Rc[e.z * 9 + c];
+                        Rj[c] = L.Rc[e.w * 9 + c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        ti[c] = L.tc[e.z * 3 + c];
+                        tj[c] = L.tc[e.w * 3 + c];
+                    }
+                    PairFwd f;
+                    pair_forward(Ri, ti, Rj, tj, f);
+                    float F[9];
+                    fundamental_from_E(f.E, cam, F);
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) L.F[s * 9 + c] = F[c];
+                }
+            }
+            __syncthreads();
+
+            // ---- P2: per-match Sampson residual + dL/dF, one (pair, chunk) item per wave ------
+            ++epoch;
+            for (int r = 0;; ++r) {
+                const int item = wg * PD_GGS_WAVES + wave + r * nW;
+                if (item >= n_items) break;
+                const int s = wave + 8 * r;
+                const int4 e = L.itab[s];
+                const float F00 = L.F[s * 9 + 0], F01 = L.F[s * 9 + 1], F02 = L.F[s * 9 + 2];
+                const float F10 = L.F[s * 9 + 3], F11 = L.F[s * 9 + 4], F12 = L.F[s * 9 + 5];
+                const float F20 = L.F[s * 9 + 6], F21 = L.F[s * 9 + 7], F22 = L.F[s * 9 + 8];
+                float acc[PD_ITEM_VALS];
+#pragma unroll
+                for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = 0.0f;
+                const float4 *pts = D.pts + e.x;
+                for (int m = lane; m < e.y; m += 64) {
+                    const float4 pt = pts[m];
+                    const float u1 = pt.x, v1 = pt.y, u2 = pt.z, v2 = pt.w;
+                    // left = x1^T F, right = F x2   (geometry_guided_sampling.py:158-159)
+                    const float l0 = fmaf(u1, F00, fmaf(v1, F10, F20));
+                    const float l1 = fmaf(u1, F01, fmaf(v1, F11, F21));
+                    const float l2 = fmaf(u1, F02, fmaf(v1, F12, F22));
+                    const float r0 = fmaf(F00, u2, fmaf(F01, v2, F02));
+                    const float r1 = fmaf(F10, u2, fmaf(F11, v2, F12));
+                    const float ee = fmaf(l0, u2, fmaf(l1, v2, l2));
+                    const float bottom = l0 * l0 + l1 * l1 + r0 * r0 + r1 * r1;   // :161
+                    const float sam = (ee * ee) / bottom;                             // :162-164
+                    acc[11] += fminf(sam, P.sampson_max);                             // :169
+                    const bool valid = sam < P.sampson_max;                           // :170
+                    const float inv = 1.0f / bottom;
+                    const float ca = valid ? 2.0f * ee * inv : 0.0f;
+                    const float cb = valid ? 2.0f * sam * inv : 0.0f;
+                    acc[9] += valid ? sam : 0.0f;
+                    acc[10] += valid ? 1.0f : 0.0f;
+                    // d sam / dF[r][c] = ca x1[r] x2[c] - cb (l_c x1[r] [c<2] + r_r x2[c] [r<2])
+                    acc[0] += ca * u1 * u2 - cb * (l0 * u1 + r0 * u2);
+                    acc[1] += ca * u1 * v2 - cb * (l1 * u1 + r0 * v2);
+                    acc[2] += ca * u1 - cb * r0;
+                    acc[3] += ca * v1 * u2 - cb * (l0 * v1 + r1 * u2);
+                    acc[4] += ca * v1 * v2 - cb * (l1 * v1 + r1 * v2);
+                    acc[5] += ca * v1 - cb * r1;
+                    acc[6] += ca * u2 - cb * l0;
+                    acc[7] += ca * v2 - cb * l1;
+                    acc[8] += ca;
+                }
+#pragma unroll
+                for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = wave_allsum(acc[c]);
+                if (k == 1) {
+                    if (lane == 0) {
+#pragma unroll
+                        for (int c = 0; c < PD_ITEM_VALS; ++c) L.item[item * PD_ITEM_VALS + c] = acc[c];
+                    }
+                } else {
+                    float v = acc[0];
+#pragma unroll
+                    for (int c = 1; c < PD_ITEM_VALS; ++c) v = (lane == c) ? acc[c] : v;
+                    if (lane < PD_ITEM_VALS) {
+                        u64 *g = xchg + (size_t)(epoch & 1) * P.xchg_stride + (size_t)item * PD_ITEM_VALS + lane;
+                        __hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            if (k > 1) {
+                // all-gather of every item's 12 sums: the data IS the flag (tag == epoch)
+                const u64 *slot = xchg + (size_t)(epoch & 1) * P.xchg_stride;
+                bool fail = false;
+                for (int g = tid; g < n_items * PD_ITEM_VALS; g += PD_GGS_THREADS) {
+                    u64 v;
+                    unsigned spins = 0;
+                    for (;;) {
+                        v = __hip_atomic_load(slot + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(v >> 32) == epoch) break;
+                        if (++spins > (1u << 22) ||
+                            ((spins & 1023u) == 0 &&
+                             __hip_atomic_load(P.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            fail = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    L.item[g] = __uint_as_float((unsigned)v);
+                }
+                if (fail) {
+                    atomicOr(P.err_flag, 1u);
+                    L.ctl[1] = 1.0f;
+                }
+            }
+            __syncthreads();
+            if (L.ctl[1] != 0.0f) return;   // a bounded spin gave up: abort the whole workgroup
+
+            // ---- P3: per-frame backward, one frame per wave, one incident pair per lane ------
+            for (int n = wave; n < N; n += PD_GGS_WAVES) {
+                const int e0 = D.inc_off[n], deg = D.inc_off[n + 1] - e0;
+                float oR[9], ot[3], oA[4];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) oR[c] = 0.0f;
+                ot[0] = ot[1] = ot[2] = 0.0f;
+                oA[0] = oA[1] = oA[2] = oA[3] = 0.0f;
+                for (int q = lane; q < deg; q += 64) {
+                    const int4 ie = D.inc[e0 + q];   // (i, j, first item, n_items | side << 16)
+                    const int pi = ie.x, pj = ie.y, side = ie.w >> 16, nit = ie.w & 0xffff;
+                    float G[9];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) G[c] = 0.0f;
+                    for (int u = 0; u < nit; ++u)
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) G[c] += L.item[(ie.z + u) * PD_ITEM_VALS + c];
+                    float Ri[9], Rj[9], ti[3], tj[3];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) {
+                        Ri[c] = L.Rc[pi * 9 + c];
+                        Rj[c] = L.Rc[pj * 9 + c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        ti[c] = L.tc[pi * 3 + c];
+                        tj[c] = L.tc[pj * 3 + c];
+                    }
+                    PairFwd f;
+                    pair_forward(Ri, ti, Rj, tj, f);
+                    // Gf = dL/dFo = G^T ; gE = A Gf A^T  (A = [[a0,0,c0],[0,a1,c1],[0,0,1]])
+                    float AG[9], gE[9];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {   // AG = A Gf, Gf[r][c] = G[c][r]
+                        const float g0 = G[c * 3 + 0], g1 = G[c * 3 + 1], g2 = G[c * 3 + 2];
+                        AG[0 * 3 + c] = cam.a0 * g0 + cam.c0 * g2;
+                        AG[1 * 3 + c] = cam.a1 * g1 + cam.c1 * g2;
+                        AG[2 * 3 + c] = g2;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {   // gE = AG A^T : gE[r][c] = sum_q AG[r][q] A[c][q]
+                        gE[r * 3 + 0] = AG[r * 3 + 0] * cam.a0 + AG[r * 3 + 2] * cam.c0;
+                        gE[r * 3 + 1] = AG[r * 3 + 1] * cam.a1 + AG[r * 3 + 2] * cam.c1;
+                        gE[r * 3 + 2] = AG[r * 3 + 2];
+                    }
+                    if (side == 0) {
+                        // dL/dA = E A Gf^T + E^T A Gf, entries (0,0),(0,2),(1,1),(1,2); each pair once
+                        float AGt[9];   // A Gf^T, Gf^T = G
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float g0 = G[0 * 3 + c], g1 = G[1 * 3 + c], g2 = G[2 * 3 + c];
+                            AGt[0 * 3 + c] = cam.a0 * g0 + cam.c0 * g2;
+                            AGt[1 * 3 + c] = cam.a1 * g1 + cam.c1 * g2;
+                            AGt[2 * 3 + c] = g2;
+                        }
+#define PD_DA(r, c)                                                                                      \
+    (f.E[(r)*3 + 0] * AGt[0 * 3 + (c)] + f.E[(r)*3 + 1] * AGt[1 * 3 + (c)] + f.E[(r)*3 + 2] * AGt[2 * 3 + (c)] + \
+     f.E[0 * 3 + (r)] * AG[0 * 3 + (c)] + f.E[1 * 3 + (r)] * AG[1 * 3 + (c)] + f.E[2 * 3 + (r)] * AG[2 * 3 + (c)])
+                        oA[0] += PD_DA(0, 0);
+                        oA[1] += PD_DA(0, 2);
+                        oA[2] += PD_DA(1, 1);
+                        oA[3] += PD_DA(1, 2);
+#undef PD_DA
+                    }
+                    // E = R12 H : gR12 = gE H^T ; gH = R12^T gE
+                    const float ex = f.Et[0], ey = f.Et[1], ez = f.Et[2];
+                    float gR12[9], gH[9];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {   // (gE H^T)[r][c] = sum_q gE[r][q] H[c][q]
+                        const float g0 = gE[r * 3 + 0], g1 = gE[r * 3 + 1], g2 = gE[r * 3 + 2];
+                        gR12[r * 3 + 0] = -g1 * ez + g2 * ey;
+                        gR12[r * 3 + 1] = g0 * ez - g2 * ex;
+                        gR12[r * 3 + 2] = -g0 * ey + g1 * ex;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            gH[r * 3 + c] = f.R12[0 * 3 + r] * gE[0 * 3 + c] + f.R12[1 * 3 + r] * gE[1 * 3 + c] +
+                                            f.R12[2 * 3 + r] * gE[2 * 3 + c];
+                    const float gEt[3] = {gH[2 * 3 + 1] - gH[1 * 3 + 2], gH[0 * 3 + 2] - gH[2 * 3 + 0],
+                                          gH[1 * 3 + 0] - gH[0 * 3 + 1]};
+                    float gt12[3];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        gt12[a] = -(f.R12[a * 3 + 0] * gEt[0] + f.R12[a * 3 + 1] * gEt[1] + f.R12[a * 3 + 2] * gEt[2]);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) gR12[a * 3 + c] += -f.t12[a] * gEt[c] - gt12[a] * ti[c];
+                    if (side == 1) {   // frame n is camera 2 (j): gtc_j = gt12 ; gRc_j = gR12 Rc_i
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            ot[a] += gt12[a];
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                oR[a * 3 + c] += gR12[a * 3 + 0] * Ri[0 * 3 + c] + gR12[a * 3 + 1] * Ri[1 * 3 + c] +
+                                                 gR12[a * 3 + 2] * Ri[2 * 3 + c];
+                        }
+                    } else {           // frame n is camera 1 (i): gtc_i = -R12^T gt12 ; gRc_i = gR12^T Rc_j
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            ot[a] += -(f.R12[0 * 3 + a] * gt12[0] + f.R12[1 * 3 + a] * gt12[1] + f.R12[2 * 3 + a] * gt12[2]);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                oR[a * 3 + c] += gR12[0 * 3 + a] * Rj[0 * 3 + c] + gR12[1 * 3 + a] * Rj[1 * 3 + c] +
+                                                 gR12[2 * 3 + a] * Rj[2 * 3 + c];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 9; ++c) oR[c] = wave_allsum(oR[c]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ot[c] = wave_allsum(ot[c]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) oA[c] = wave_allsum(oA[c]);
+                if (lane == 0) {
+                    // back through tc = D T and Rc[a][b] = D[a] R[b][a]:  gR[b][a] = D[a] gRc[a][b]
+                    L.gT[n * 3 + 0] = -ot[0];
+                    L.gT[n * 3 + 1] = -ot[1];
+                    L.gT[n * 3 + 2] = ot[2];
+#pragma unroll
+                    for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+                        for (int aa = 0; aa < 3; ++aa) L.gR[n * 9 + bb * 3 + aa] = (aa < 2 ? -1.0f : 1.0f) * oR[aa * 3 + bb];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) L.gA[n * 4 + c] = oA[c];
+                }
+            }
+            __syncthreads();
+
+            // ---- P4 (wave 0): totals, early exit, quaternion/focal chain, clip, momentum SGD ----
+            if (wave == 0) {
+                float s_sum = 0.0f, s_cnt = 0.0f, s_cl = 0.0f;
+                for (int q = lane; q < n_items; q += 64) {
+                    s_sum += L.item[q * PD_ITEM_VALS + 9];
+                    s_cnt += L.item[q * PD_ITEM_VALS + 10];
+                    s_cl += L.item[q * PD_ITEM_VALS + 11];
+                }
+                s_sum = wave_allsum(s_sum);
+                s_cnt = wave_allsum(s_cnt);
+                s_cl = wave_allsum(s_cl);
+                float ga[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ga[c] = wave_allsum(lane < N ? L.gA[lane * 4 + c] : 0.0f);
+                last_print = s_cl * inv_M;
+                last_cnt = s_cnt;
+                // len(valid) / n_frames < min_matches -> break   (geometry_guided_sampling.py:104-108)
+                const bool done = (!P.eval_only) && P.min_matches > 0 && (s_cnt < (float)P.min_matches * (float)N);
+                if (!done) {
+                    const float loss = s_sum / s_cnt;                     // valid.mean()  :110
+                    last_loss = loss;
+                    const float inv_cnt = 1.0f / s_cnt;
+                    float g[9];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) g[c] = 0.0f;
+                    if (lane < N) {
+                        if (S.update_T) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) g[c] = L.gT[lane * 3 + c] * inv_cnt;
+                        }
+                        if (S.update_R) {
+                            // R = I + two_s * Pm(q): chain rule to the (unnormalised) quaternion
+                            const float r = xr[3], i = xr[4], j = xr[5], kq = xr[6];
+                            const float n2 = r * r + i * i + j * j + kq * kq;
+                            const float ts = 2.0f / n2;
+                            float gR[9];
+#pragma unroll
+                            for (int c = 0; c < 9; ++c) gR[c] = L.gR[lane * 9 + c];
+                            const float gts = gR[0] * -(j * j + kq * kq) + gR[1] * (i * j - kq * r) + gR[2] * (i * kq + j * r) +
+                                              gR[3] * (i * j + kq * r) + gR[4] * -(i * i + kq * kq) + gR[5] * (j * kq - i * r) +
+                                              gR[6] * (i * kq - j * r) + gR[7] * (j * kq + i * r) + gR[8] * -(i * i + j * j);
+                            float h[9];
+#pragma unroll
+                            for (int c = 0; c < 9; ++c) h[c] = ts * gR[c];
+                            const float qs = gts * (-4.0f / (n2 * n2));
+                            const float gq_r = -kq * h[1] + j * h[2] + kq * h[3] - i * h[5] - j * h[6] + i * h[7] + qs * r;
+                            const float gq_i = j * h[1] + kq * h[2] + j * h[3] - 2.0f * i * h[4] - r * h[5] + kq * h[6] +
+                                               r * h[7] - 2.0f * i * h[8] + qs * i;
+                            const float gq_j = -2.0f * j * h[0] + i * h[1] + r * h[2] + i * h[3] + kq * h[5] - r * h[6] +
+                                               kq * h[7] - 2.0f * j * h[8] + qs * j;
+                            const float gq_k = -2.0f * kq * h[0] - r * h[1] + i * h[2] + r * h[3] - 2.0f * kq * h[4] +
+                                               j * h[5] + i * h[6] + j * h[7] + qs * kq;
+                            g[3] = gq_r * inv_cnt;
+                            g[4] = gq_i * inv_cnt;
+                            g[5] = gq_j * inv_cnt;
+                            g[6] = gq_k * inv_cnt;
+                        }
+                        if (S.update_FL) {
+                            // A00 = 1/(f sc), A02 = -cx/(f sc): dA/df ; mean over frames ; exp ; clamp mask
+                            const float fbx = L.cam[4], fby = L.cam[5];
+                            const float gfx = ga[0] * (-1.0f / (fbx * fbx * D.sc)) + ga[1] * (D.cx / (fbx * fbx * D.sc));
+                            const float gfy = ga[2] * (-1.0f / (fby * fby * D.sc)) + ga[3] * (D.cy / (fby * fby * D.sc));
+                            g[7] = gfx / (float)N * L.fl[lane * 2 + 0] * L.flp[lane * 2 + 0] * inv_cnt;
+                            g[8] = gfy / (float)N * L.fl[lane * 2 + 1] * L.flp[lane * 2 + 1] * inv_cnt;
+                        }
+                    }
+                    if (P.eval_only) {
+                        if (lane < N) {
+#pragma unroll
+                            for (int c = 0; c < 9; ++c) P.grad_out[((size_t)b * N + lane) * 9 + c] = g[c];
+                        }
+                        if (lane == 0 && wg == 0) {
+                            P.loss_out[b * 4 + 0] = loss;
+                            P.loss_out[b * 4 + 1] = s_cnt;
+                            P.loss_out[b * 4 + 2] = last_print;
+                            P.loss_out[b * 4 + 3] = 0.0f;
+                        }
+                    } else {
+                        // masked-norm clip (:114-121) + SGD momentum step (:122)
+                        float gn2 = 0.0f, xn2 = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) {
+                            gn2 += g[c] * g[c];
+                            xn2 += (fabsf(g[c]) > 0.0f) ? xr[c] * xr[c] : 0.0f;
+                        }
+                        const float gnorm = sqrtf(wave_allsum(gn2));
+                        const float xnorm = sqrtf(wave_allsum(xn2));
+                        const float max_norm = P.alpha * xnorm / P.lr;
+                        const float coef = fminf(max_norm / (gnorm + 1e-6f), 1.0f);
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) {
+                            const float gc = g[c] * coef;
+                            mom[c] = (stepped == 0) ? gc : P.momentum * mom[c] + gc;
+                            xr[c] = xr[c] - P.lr * mom[c];
+                        }
+                        ++stepped;
+                        if (P.trace && wg == 0 && trace_row < P.trace_iters) {
+                            float *tr = P.trace + ((size_t)b * P.trace_iters + trace_row) * (N * 9 + 3);
+                            if (lane < N) {
+#pragma unroll
+                                for (int c = 0; c < 9; ++c) tr[lane * 9 + c] = xr[c];
+                            }
+                            if (lane == 0) {
+                                tr[N * 9 + 0] = loss;
+                                tr[N * 9 + 1] = s_cnt;
+                                tr[N * 9 + 2] = gnorm;
+                            }
+                        }
+                        ++trace_row;
+                        decode_all(L, xr, lane, N, D);
+                    }
+                }
+                if (lane == 0) L.ctl[0] = (done || P.eval_only) ? 1.0f : 0.0f;
+            }
+            __syncthreads();
+            if (L.ctl[0] != 0.0f) break;
+        }
+        if (wave == 0 && lane == 0 && wg == 0 && P.stats) {
+            float *so = P.stats + ((size_t)b * P.n_stages + st) * 4;
+            so[0] = last_print;
+            so[1] = (float)stepped;
+            so[2] = last_cnt;
+            so[3] = last_loss;
+        }
+        if (P.eval_only) break;
+    }
+    if (own && wg == 0 && !P.eval_only) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) xg[lane * 9 + c] = xr[c];
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------------
+void pd_ggs_free_seq(PdSeqHost &h) {
+    if (h.blob) (void)hipFree(h.blob);
+    h.blob = nullptr;
+    memset(&h.desc, 0, sizeof(h.desc));
+}
+
+static int upload_seq_table(pd_engine *eng) {
+    std::vector<PdSeqDesc> d(eng->max_B);
+    for (int i = 0; i < eng->max_B; ++i) d[i] = eng->seqs[i].desc;
+    PD_HIP_CHECK(hipMemcpy(eng->d_seqs, d.data(), sizeof(PdSeqDesc) * eng->max_B, hipMemcpyHostToDevice));
+    return PD_OK;
+}
+
+extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, const double *kp2, const int64_t *i12,
+                                  int64_t M, int n_frames, int height, int width) {
+    if (!eng || seq < 0 || seq >= eng->max_B) {
+        pd_set_error("pd_ggs_set_matches: bad engine or sequence slot %d", seq);
+        return PD_ERR_INVALID_ARG;
+    }
+    PD_HIP_CHECK(hipSetDevice(eng->device));
+    PD_HIP_CHECK(hipDeviceSynchronize());   // nothing in flight may still read the old tables
+    pd_ggs_free_seq(eng->seqs[seq]);
+    if (M == 0) return upload_seq_table(eng);
+    if (!kp1 || !kp2 || !i12 || M < 0 || n_frames <= 0 || n_frames > PD_MAX_FRAMES || n_frames > eng->max_N ||
+        height <= 0 || width <= 0) {
+        pd_set_error("pd_ggs_set_matches: invalid arguments (M=%lld n_frames=%d h=%d w=%d; n_frames <= %d)",
+                     (long long)M, n_frames, height, width, std::min(PD_MAX_FRAMES, eng->max_N));
+        return PD_ERR_INVALID_ARG;
+    }
+    const int N = n_frames;
+    // stable counting sort by pair key = i * N + j   (geometry_guided_sampling.py:26-27)
+    std::vector<int> cnt((size_t)N * N + 1, 0);
+    for (int64_t m = 0; m < M; ++m) {
+        const int64_t a = i12[2 * m], c = i12[2 * m + 1];
+        if (a < 0 || a >= N || c < 0 || c >= N) {
+            pd_set_error("pd_ggs_set_matches: frame index (%lld,%lld) out of range [0,%d) at match %lld",
+                         (long long)a, (long long)c, N, (long long)m);
+            return PD_ERR_INVALID_ARG;
+        }
+        cnt[a * N + c + 1]++;
+    }
+    std::vector<int> key_off((size_t)N * N + 1, 0);
+    for (int q = 0; q < N * N; ++q) key_off[q + 1] = key_off[q] + cnt[q + 1];
+    std::vector<float4> pts((size_t)M);
+    {
+        std::vector<int> cur(key_off.begin(), key_off.end() - 1);
+        for (int64_t m = 0; m < M; ++m) {
+            const int key = (int)(i12[2 * m] * N + i12[2 * m + 1]);
+            // .float() cast of geometry_guided_sampling.py:167 (round-to-nearest fp64 -> fp32)
+            pts[cur[key]++] = make_float4((float)kp1[2 * m], (float)kp1[2 * m + 1], (float)kp2[2 * m], (float)kp2[2 * m + 1]);
+        }
+    }
+    std::vector<int2> pair_ij;
+    std::vector<int> pair_item_off;
+    std::vector<int4> items;
+    for (int q = 0; q < N * N; ++q) {
+        const int m = key_off[q + 1] - key_off[q];
+        if (m == 0) continue;
+        const int p = (int)pair_ij.size();
+        pair_ij.push_back(make_int2(q / N, q % N));
+        pair_item_off.push_back((int)items.size());
+        const int nch = (m + PD_ITEM_MAX_MATCHES - 1) / PD_ITEM_MAX_MATCHES;
+        int start = key_off[q];
+        for (int c = 0; c < nch; ++c) {
+            const int len = m / nch + (c < m % nch ? 1 : 0);
+            items.push_back(make_int4(p, start, len, 0));
+            start += len;
+        }
+    }
+    pair_item_off.push_back((int)items.size());
+    const int n_pairs = (int)pair_ij.size(), n_items = (int)items.size();
+    std::vector<int> inc_off(N + 1, 0);
+    std::vector<int4> inc;
+    for (int n = 0; n < N; ++n) {
+        inc_off[n] = (int)inc.size();
+        for (int p = 0; p < n_pairs; ++p) {
+            const int nit = pair_item_off[p + 1] - pair_item_off[p];
+            if (nit > 0xffff) {
+                pd_set_error("pd_ggs_set_matches: a frame pair holds too many matches");
+                return PD_ERR_UNSUPPORTED;
+            }
+            if (pair_ij[p].x == n) inc.push_back(make_int4(pair_ij[p].x, pair_ij[p].y, pair_item_off[p], nit | (0 << 16)));
+            if (pair_ij[p].y == n) inc.push_back(make_int4(pair_ij[p].x, pair_ij[p].y, pair_item_off[p], nit | (1 << 16)));
+        }
+    }
+    inc_off[N] = (int)inc.size();
+
+    // one blob: pts | pair_ij | pair_item_off | items | inc_off | inc   (16-byte aligned pieces)
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_pts = 0;
+    const size_t o_pij = al(o_pts + sizeof(float4) * pts.size());
+    const size_t o_pio = al(o_pij + sizeof(int2) * pair_ij.size());
+    const size_t o_itm = al(o_pio + sizeof(int) * pair_item_off.size());
+    const size_t o_ino = al(o_itm + sizeof(int4) * items.size());
+    const size_t o_inc = al(o_ino + sizeof(int) * inc_off.size());
+    const size_t total = al(o_inc + sizeof(int4) * inc.size());
+    std::vector<char> host(total, 0);
+    memcpy(host.data() + o_pts, pts.data(), sizeof(float4) * pts.size());
+    memcpy(host.data() + o_pij, pair_ij.data(), sizeof(int2) * pair_ij.size());
+    memcpy(host.data() + o_pio, pair_item_off.data(), sizeof(int) * pair_item_off.size());
+    memcpy(host.data() + o_itm, items.data(), sizeof(int4) * items.size());
+    memcpy(host.data() + o_ino, inc_off.data(), sizeof(int) * inc_off.size());
+    memcpy(host.data() + o_inc, inc.data(), sizeof(int4) * inc.size());
+    PdSeqHost &h = eng->seqs[seq];
+    PD_HIP_CHECK(hipMalloc(&h.blob, total));
+    PD_HIP_CHECK(hipMemcpy(h.blob, host.data(), total, hipMemcpyHostToDevice));
+    char *base = (char *)h.blob;
+    h.desc.pts = (const float4 *)(base + o_pts);
+    h.desc.pair_ij = (const int2 *)(base + o_pij);
+    h.desc.pair_item_off = (const int *)(base + o_pio);
+    h.desc.items = (const int4 *)(base + o_itm);
+    h.desc.inc_off = (const int *)(base + o_ino);
+    h.desc.inc = (const int4 *)(base + o_inc);
+    h.desc.M = (int)M;
+    h.desc.n_pairs = n_pairs;
+    h.desc.n_items = n_items;
+    h.desc.n_frames = N;
+    h.desc.sc = (float)std::min(height, width) / 2.0f;   // opencv_from_cameras_projection scale
+    h.desc.cx = (float)width / 2.0f;
+    h.desc.cy = (float)height / 2.0f;
+    return upload_seq_table(eng);
+}
+
+int pd_ggs_init() {
+    PD_HIP_CHECK(hipFuncSetAttribute((const void *)pd_ggs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return PD_OK;
+}
+
+int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stages, int n_stages,
+                  const pd_ggs_cfg *cfg, int eval_only, float *stats, float *trace, int trace_iters,
+                  float *loss_out, float *grad_out, hipStream_t s) {
+    if (!eng || !x || !cfg || B <= 0 || B > eng->max_B || N <= 0 || N > eng->max_N || N > PD_MAX_FRAMES ||
+        n_stages <= 0 || n_stages > PD_GGS_MAX_STAGES) {
+        pd_set_error("pd_ggs: invalid arguments (B=%d N=%d stages=%d)", B, N, n_stages);
+        return PD_ERR_INVALID_ARG;
+    }
+    int max_items = 0;
+    for (int b = 0; b < B; ++b) {
+        const PdSeqDesc &d = eng->seqs[b].desc;
+        if (d.M <= 0 || !eng->seqs[b].blob) {
+            pd_set_error("pd_ggs: sequence slot %d has no matches (call pd_ggs_set_matches)", b);
+            return PD_ERR_STATE;
+        }
+        if (d.n_frames != N) {
+            pd_set_error("pd_ggs: slot %d matches were uploaded for %d frames, called with N=%d", b, d.n_frames, N);
+            return PD_ERR_INVALID_ARG;
+        }
+        max_items = std::max(max_items, d.n_items);
+    }
+    // workgroups per sequence: one item per wave if the chip has room (<= 256 resident workgroups)
+    int device_cus = 256;
+    int k = cfg->wgs_per_seq > 0 ? cfg->wgs_per_seq : (max_items + PD_GGS_WAVES - 1) / PD_GGS_WAVES;
+    k = std::max(1, std::min(k, device_cus / B));
+    if ((size_t)max_items * PD_ITEM_VALS > eng->xchg_granules) k = 1;
+    int n_slots = 0;
+    size_t lds = 0;
+    for (;;) {
+        const int rounds = (max_items + k * PD_GGS_WAVES - 1) / (k * PD_GGS_WAVES);
+        n_slots = rounds * PD_GGS_WAVES;
+        lds = ggs_lds_bytes(n_slots, max_items);
+        if (lds <= 160 * 1024 || k >= device_cus / B) break;
+        ++k;
+    }
+    if (lds > 160 * 1024) {
+        pd_set_error("pd_ggs: %d work items need %zu B of LDS per workgroup (> 160 KiB) at B=%d", max_items, lds, B);
+        return PD_ERR_UNSUPPORTED;
+    }
+    PdGgsParams P;
+    memset(&P, 0, sizeof(P));
+    P.seqs = eng->d_seqs;
+    P.x = x;
+    P.N = N;
+    P.k = k;
+    for (int i = 0; i < n_stages; ++i) P.stages[i] = stages[i];
+    P.n_stages = n_stages;
+    P.alpha = cfg->alpha;
+    P.lr = cfg->learning_rate;
+    P.sampson_max = cfg->sampson_max;
+    P.momentum = cfg->momentum;
+    P.min_matches = cfg->min_matches;
+    P.eval_only = eval_only;
+    P.stats = stats;
+    P.trace = trace;
+    P.trace_iters = trace_iters;
+    P.loss_out = loss_out;
+    P.grad_out = grad_out;
+    P.xchg = (k > 1) ? eng->d_xchg : nullptr;
+    P.xchg_stride = (int)eng->xchg_granules;
+    P.err_flag = eng->d_err;
+    if (k > 1) {
+        // tags restart at 1 every launch: zero every polled word first (guide G16 "re-initialise")
+        PD_HIP_CHECK(hipMemsetAsync(eng->d_xchg, 0, sizeof(u64) * 2 * eng->xchg_granules * B, s));
+    }
+    hipLaunchKernelGGL(pd_ggs_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots);
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}

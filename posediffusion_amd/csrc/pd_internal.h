@@ -1,0 +1,116 @@
+// pd_internal.h -- engine-private declarations shared by the HIP translation units.
+// gfx950 / CDNA4 only: 64-wide wavefronts, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pd_engine.h"
+
+#define PD_WAVE 64
+#define PD_MAX_FRAMES 64          // one wavefront lane per frame in the GGS update phase
+#define PD_GGS_THREADS 512        // 8 waves per GGS workgroup
+#define PD_GGS_WAVES (PD_GGS_THREADS / PD_WAVE)
+#define PD_GGS_MAX_STAGES 5
+#define PD_ITEM_MAX_MATCHES 512   // one work item = <= 512 matches of one frame pair (8 per lane)
+#define PD_ITEM_VALS 12           // 9 dL/dF sums + sum(s valid) + n_valid + sum(min(s, max))
+
+void pd_set_error(const char *fmt, ...);
+
+#define PD_HIP_CHECK(expr)                                                                     \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            pd_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return PD_ERR_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+// ---- GGS match container (device view) ---------------------------------------------------------
+// Matches of one sequence, sorted by frame pair so that a wavefront owns one pair at a time
+// (geometry_guided_sampling.py:26-27 builds pair_idx = i*N + j; hloc already groups by pair).
+struct PdSeqDesc {
+    const float4 *pts;         // [M] (u1, v1, u2, v2) fp32, pair-sorted
+    const int2 *pair_ij;       // [n_pairs] (i, j) frame indices, p2^T F p1 = 0 with 1 = i, 2 = j
+    const int *pair_item_off;  // [n_pairs + 1] items of pair p are items[off[p] .. off[p+1])
+    const int4 *items;         // [n_items] (pair, first match, match count, 0)
+    const int *inc_off;        // [n_frames + 1] incidence CSR: pairs touching frame n
+    const int4 *inc;           // [2 * n_pairs] (i, j, first item, n_items | side << 16); side 0: frame is i
+    int M, n_pairs, n_items, n_frames;
+    float sc, cx, cy;          // min(h, w) / 2, w / 2, h / 2 (opencv_from_cameras_projection)
+    int pad;
+};
+
+struct PdGgsStage {
+    int update_R, update_T, update_FL, iters;
+};
+
+struct PdGgsParams {
+    const PdSeqDesc *seqs;     // [B]
+    float *x;                  // [B, N, 9] in/out
+    int N, k;                  // frames, workgroups per sequence
+    PdGgsStage stages[PD_GGS_MAX_STAGES];
+    int n_stages;
+    float alpha, lr, sampson_max, momentum;
+    int min_matches;
+    int eval_only;             // 1: single forward/backward, no update (pd_ggs_loss_grad)
+    float *stats;              // [B, n_stages, 4] or null
+    float *trace;              // [B, trace_iters, N*9 + 3] or null
+    int trace_iters;
+    float *loss_out;           // [B, 4]   (eval_only)
+    float *grad_out;           // [B, N, 9] (eval_only)
+    unsigned long long *xchg;  // [B, 2, max_items * 12] tagged granules (k > 1)
+    int xchg_stride;           // granules per (sequence, slot)
+    unsigned int *err_flag;    // device word: nonzero = a bounded spin gave up
+};
+
+struct PdSeqHost {
+    void *blob = nullptr;      // one hipMalloc holding every array of the PdSeqDesc
+    PdSeqDesc desc{};
+    int n_local_max_k1 = 0;
+};
+
+// ---- denoiser -----------------------------------------------------------------------------------
+struct PdDenoiserDev;   // defined in pd_denoiser.hip
+
+struct pd_engine {
+    int device = 0;
+    int max_B = 0, max_N = 0;
+    int d_model = 0, nhead = 0, dim_ff = 0, num_layers = 0, z_dim = 0, timesteps = 0;
+    PdDenoiserDev *den = nullptr;
+    // schedule tables (host copies; kernels take the per-step scalars by value)
+    std::vector<float> c_recip, c_recipm1, coef1, coef2, logvar;
+    // GGS
+    std::vector<PdSeqHost> seqs;
+    PdSeqDesc *d_seqs = nullptr;         // [max_B] device copy of the descriptors
+    unsigned long long *d_xchg = nullptr;
+    size_t xchg_granules = 0;            // per (sequence, slot)
+    unsigned int *d_err = nullptr;
+    float *d_stats_scratch = nullptr;
+    // sampler buffers (fixed addresses so a captured graph can be replayed)
+    float *d_z = nullptr, *d_noise = nullptr, *d_process = nullptr, *d_mean = nullptr, *d_stats = nullptr;
+    // graph cache
+    struct GraphKey {
+        int B, N, cond_start, has_ggs;
+        pd_ggs_cfg cfg;
+    };
+    std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
+    hipStream_t own_stream = nullptr;
+};
+
+// pd_denoiser.hip
+int pd_denoiser_create(pd_engine *eng, const pd_weights *w);
+void pd_denoiser_destroy(pd_engine *eng);
+// eps_out / mean_out / x_next_out may each be null. noise null => 0.
+int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, int B, int N, float *eps_out,
+                       float *mean_out, float *x0_out, const float *noise, float *x_next_out, hipStream_t s);
+
+// pd_ggs.hip
+int pd_ggs_init();
+int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stages, int n_stages,
+                  const pd_ggs_cfg *cfg, int eval_only, float *stats, float *trace, int trace_iters,
+                  float *loss_out, float *grad_out, hipStream_t s);
+void pd_ggs_free_seq(PdSeqHost &h);

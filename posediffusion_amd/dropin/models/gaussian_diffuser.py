@@ -1,0 +1,98 @@
+"""Drop-in `GaussianDiffusion` (pose_diffusion/models/gaussian_diffuser.py:75-306, sampling half).
+
+Same constructor, same 13 persistent buffers (checkpoint keys `diffuser.betas` ...), same
+``sample(shape, z, cond_fn=None, cond_start_step=0) -> (pose [B,N,9], process [T+1,B,N,9])``.
+The loop itself -- 100 denoiser evaluations, posterior updates and (when cond_fn is the shipped
+GGS partial) the 7000 guided iterations -- runs as one hipGraph replay of hand-written kernels.
+Training (`forward`/`p_losses`, :308-332) is out of scope and raises."""
+import os
+
+import torch
+from torch import nn
+
+from posediffusion_amd import host
+from posediffusion_amd.schedule import BUFFER_NAMES, diffusion_buffers
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, timesteps=100, sampling_timesteps=None, beta_1=0.0001, beta_T=0.1, loss_type="l1",
+                 objective="pred_noise", beta_schedule="custom", p2_loss_weight_gamma=0.0, p2_loss_weight_k=1):
+        super().__init__()
+        if objective not in {"pred_noise", "pred_x0"}:
+            raise AssertionError("objective must be either pred_noise (predict noise) or pred_x0 (predict image start)")
+        if objective != "pred_noise":
+            raise NotImplementedError("the HIP engine implements objective='pred_noise' (cfgs/default.yaml)")
+        self.objective, self.loss_type, self.beta_schedule = objective, loss_type, beta_schedule
+        self.timesteps, self.beta_1, self.beta_T = timesteps, beta_1, beta_T
+        bufs = diffusion_buffers(beta_schedule, timesteps, beta_1, beta_T, p2_loss_weight_gamma, p2_loss_weight_k)
+        for name in BUFFER_NAMES:
+            self.register_buffer(name, bufs[name])
+        self.num_timesteps = int(timesteps)
+        self.sampling_timesteps = timesteps if sampling_timesteps is None else sampling_timesteps
+        assert self.sampling_timesteps <= timesteps
+        self.model = None          # the Denoiser, assigned after construction (pose_diffusion_model.py:61)
+        self.use_graph = os.environ.get("PD_USE_GRAPH", "1") != "0"
+        self.last_ggs_stats = None
+
+    # ---- step-level pieces (same names as the reference) ------------------------------------
+    def p_mean_variance(self, x, t, z, x_self_cond=None, clip_denoised=False):
+        if clip_denoised:
+            raise NotImplementedError("We don't clip the output because pose does not have a clear bound.")
+        B, N, _ = x.shape
+        eng = host.get_engine(self.model, self, B, N)
+        tt = int(torch.as_tensor(t).reshape(-1)[0])
+        mean, x0 = eng.p_mean(x, z, tt)
+        shape = (B,) + (1,) * (x.dim() - 1)
+        return (mean, self.posterior_variance[tt].expand(shape), self.posterior_log_variance_clipped[tt].expand(shape), x0)
+
+    @torch.no_grad()
+    def p_sample(self, x, t: int, z, x_self_cond=None, clip_denoised=False, cond_fn=None, cond_start_step=0):
+        B, N, _ = x.shape
+        eng = host.get_engine(self.model, self, B, N)
+        mean, x0 = eng.p_mean(x, z, int(t))
+        if cond_fn is not None and t < cond_start_step:           # gaussian_diffuser.py:270-276
+            mean = cond_fn(mean, t)
+            noise = None
+        else:
+            noise = torch.randn_like(x) if t > 0 else None        # :278
+        return eng.p_finish(mean, noise, int(t)), x0
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, z, cond_fn=None, cond_start_step=0):
+        B, N, _ = shape
+        device = self.betas.device
+        eng = host.get_engine(self.model, self, B, N)
+        parsed = host.parse_ggs_cond_fn(cond_fn) if cond_fn is not None else None
+        if cond_fn is not None and parsed is None:
+            # unknown guidance callable: reference control flow in Python, arithmetic on the HIP kernels
+            pose = torch.randn(shape, device=device)
+            process = [pose.unsqueeze(0)]
+            for t in reversed(range(self.num_timesteps)):
+                pose, _ = self.p_sample(pose, t, z, cond_fn=cond_fn, cond_start_step=cond_start_step)
+                process.append(pose.unsqueeze(0))
+            return pose, torch.cat(process)
+        has_ggs = parsed is not None and cond_start_step > 0
+        noise = host.draw_noise(tuple(shape), self.num_timesteps, device, cond_start_step, has_ggs)
+        cfg = None
+        if has_ggs:
+            matches, cfg = parsed
+            host.upload_matches(eng, matches, B)
+        pose, process, stats = eng.sample(z, noise, cond_start_step if has_ggs else 0, cfg, use_graph=self.use_graph)
+        self.last_ggs_stats = stats
+        if stats is not None and os.environ.get("PD_GGS_VERBOSE"):
+            st = stats.cpu()
+            for k in range(st.shape[0]):
+                for s in range(5):
+                    print(f"t={cond_start_step - 1 - k:02d} | sampson={float(st[k, 0, s, 0]):05f}")
+        return pose, process
+
+    @torch.no_grad()
+    def sample(self, shape, z, cond_fn=None, cond_start_step=0):
+        return self.p_sample_loop(shape, z=z, cond_fn=cond_fn, cond_start_step=cond_start_step)
+
+    # ---- training half: out of scope ---------------------------------------------------------
+    def p_losses(self, *a, **k):
+        raise NotImplementedError("training is out of scope of the MI355X sampling engine (SURVEY.md section 2.1)")
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training is out of scope of the MI355X sampling engine (SURVEY.md section 2.1)")

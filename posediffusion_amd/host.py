@@ -1,0 +1,115 @@
+"""Host glue between the drop-in modules and the HIP engine.
+
+* engine cache keyed on a fingerprint of the live parameters (data_ptr + in-place version), so
+  ``load_state_dict`` / ``.to(device)`` transparently rebuild the repacked weights;
+* recognition of the shipped guidance plug-in: ``functools.partial(geometry_guided_sampling,
+  matches_dict=..., GGS_cfg=...)`` (demo.py:89, test.py:186) is turned into one match upload +
+  the fused GGS kernel; any other callable ``cond_fn(model_mean, t)`` still works through the
+  step-level API (denoiser and DDPM update stay on the HIP kernels);
+* the reference's RNG call order (gaussian_diffuser.py:289, :276-278) so that the same seed draws
+  the same noise the reference would draw on this device.
+"""
+from __future__ import annotations
+
+import functools
+from typing import Dict, Optional
+
+import torch
+
+from .engine import PoseEngine, make_ggs_cfg
+
+_DENOISER_PREFIXES = ("time_embed.", "_first.", "_trunk.", "_last.")
+
+
+def _fingerprint(denoiser: torch.nn.Module, diffuser: Optional[torch.nn.Module]):
+    fp = [(p.data_ptr(), p._version, tuple(p.shape)) for p in denoiser.parameters()]
+    if diffuser is not None:
+        fp += [(b.data_ptr(), b._version) for n, b in diffuser.named_buffers(recurse=False)]
+    return tuple(fp)
+
+
+def denoiser_state(denoiser: torch.nn.Module) -> Dict[str, torch.Tensor]:
+    return {k: v for k, v in denoiser.state_dict().items() if k.startswith(_DENOISER_PREFIXES)}
+
+
+def get_engine(denoiser: torch.nn.Module, diffuser: Optional[torch.nn.Module], B: int, N: int) -> PoseEngine:
+    """Engine for these live modules (rebuilt when weights, device or capacity change)."""
+    dev = next(denoiser.parameters()).device
+    if dev.type != "cuda":
+        raise RuntimeError("the PoseDiffusion sampling path of posediffusion_amd runs only on an AMD GPU "
+                           f"(model is on {dev}); move the model with .to('cuda'). There is no CPU fallback.")
+    fp = _fingerprint(denoiser, diffuser)
+    cache = denoiser.__dict__.setdefault("_pd_engine_cache", {})
+    ent = cache.get("e")
+    if ent is not None and ent[0] == fp and ent[1].max_B >= B and ent[1].max_N >= N:
+        return ent[1]
+    if ent is not None:
+        ent[1].close()
+    if diffuser is not None:
+        tables = {n: b for n, b in diffuser.named_buffers(recurse=False)}
+    else:
+        from .schedule import diffusion_buffers
+        tables = diffusion_buffers()
+    layers = len(denoiser._trunk.layers)
+    nhead = denoiser._trunk.layers[0].self_attn.num_heads
+    eng = PoseEngine(denoiser_state(denoiser), tables, device=dev, max_B=max(B, 1), max_N=max(N, 1),
+                     num_layers=layers, nhead=nhead)
+    cache["e"] = (fp, eng)
+    _ENGINES[dev.index if dev.index is not None else torch.cuda.current_device()] = eng
+    return eng
+
+
+def parse_ggs_cond_fn(cond_fn):
+    """-> (matches_dict, GGS_cfg) if cond_fn is the shipped GGS partial, else None."""
+    if not isinstance(cond_fn, functools.partial):
+        return None
+    if getattr(cond_fn.func, "__name__", "") != "geometry_guided_sampling":
+        return None
+    kw = cond_fn.keywords or {}
+    if "matches_dict" not in kw or "GGS_cfg" not in kw or cond_fn.args:
+        return None
+    return kw["matches_dict"], dict(kw["GGS_cfg"])
+
+
+def draw_noise(shape, timesteps: int, device, guided_from: int = 0, has_cond: bool = False,
+               generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """[T+1, *shape] noise in the reference's draw order: randn(shape) (gaussian_diffuser.py:289), then
+    one randn_like per step t = T-1..0 that is unguided and has t > 0 (:276-278); other slots stay 0."""
+    out = torch.zeros((timesteps + 1, *shape), device=device, dtype=torch.float32)
+    out[0] = torch.randn(shape, device=device, generator=generator)
+    for step in range(timesteps):
+        t = timesteps - 1 - step
+        guided = has_cond and t < guided_from
+        if not guided and t > 0:
+            out[step + 1] = torch.randn(shape, device=device, generator=generator)
+    return out
+
+
+_ENGINES = {}   # device index -> most recently built engine (used by the free functions of dropin/util)
+
+
+def current_engine(device) -> PoseEngine:
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("posediffusion_amd runs only on an AMD GPU; got tensors on " + str(dev))
+    eng = _ENGINES.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    if eng is None:
+        raise RuntimeError("no PoseEngine exists on this device yet: build one with "
+                           "posediffusion_amd.host.get_engine(denoiser, diffuser, B, N) or run the model once")
+    return eng
+
+
+def upload_matches(engine: PoseEngine, matches, B: int):
+    """matches: one reference-style matches_dict (B == 1) or a list of B of them.  Uploads are
+    cached on the engine by object identity so the five calls per guided step upload once."""
+    lst = list(matches) if isinstance(matches, (list, tuple)) else [matches]
+    if len(lst) != B:
+        raise ValueError(f"GGS needs one matches_dict per sequence: got {len(lst)} for B={B} "
+                         "(the reference defines GGS only for B = 1, geometry_guided_sampling.py:16)")
+    cache = engine.__dict__.setdefault("_match_ids", {})
+    for b, md in enumerate(lst):
+        key = (id(md), id(md["kp1"]), len(md["kp1"]))
+        if cache.get(b) == key:
+            continue
+        engine.set_matches(b, md["kp1"], md["kp2"], md["i12"], tuple(md["img_shape"]))
+        cache[b] = key
