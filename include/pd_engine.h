@@ -188,6 +188,10 @@ int pd_time_kernel(pd_engine *eng, int what, int B, int N, const pd_ggs_cfg *cfg
  * cross-workgroup exchange gave up since the last check.  PD_OK otherwise. */
 int pd_check_async_error(pd_engine *eng);
 
+/* Debug aid: switch the GGS kernel's in-kernel phase cycle counters on/off and (out6 != NULL)
+ * read them: {P1 pair F, P2 matches, exchange, P3 backward, P4 update, iterations} of workgroup 0. */
+int pd_debug_ggs_prof(pd_engine *eng, int enable, long long *out6);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,9 @@ def load_reference():
         raise RuntimeError(f"reference not found under {REF_ROOT}")
     if "pytorch3d" in sys.modules or "hydra" in sys.modules:
         raise RuntimeError("real pytorch3d/hydra present; stubs not needed -- adapt ref_stubs")
+    stub_names = ("torchvision", "hydra", "hydra.utils", "pytorch3d", "pytorch3d.renderer", "pytorch3d.renderer.cameras",
+                  "pytorch3d.utils", "pytorch3d.transforms", "pytorch3d.transforms.so3",
+                  "pytorch3d.transforms.rotation_conversions")
 
     _mod("torchvision", transforms=types.SimpleNamespace(), utils=types.SimpleNamespace())
     _mod("hydra")
@@ -119,7 +122,16 @@ def load_reference():
          matrix_to_quaternion=None)
 
     # `util` is a plain package in the reference (empty __init__); models/denoiser.py does
-    # `from util.embedding import ...`, so the reference package dir goes on sys.path.
+    # `from util.embedding import ...`.  The product's drop-in packages use the same top-level names
+    # (`util`, `models`), so the reference is imported hermetically: our entries are parked, the
+    # reference modules are imported with its directory first on sys.path, and afterwards every
+    # `util*` / `models*` entry it created is removed again (its functions keep direct references).
+    def _ours():
+        return {k: v for k, v in sys.modules.items() if k in ("util", "models") or k.startswith(("util.", "models."))}
+
+    parked = _ours()
+    for k in parked:
+        del sys.modules[k]
     sys.path.insert(0, REF_PKG)
     try:
         ns = types.SimpleNamespace()
@@ -136,6 +148,7 @@ def load_reference():
         ggs = importlib.import_module("util.geometry_guided_sampling")
         fm = importlib.import_module("util.get_fundamental_matrix")
         ct = importlib.import_module("util.camera_transform")
+        assert ggs.__file__.startswith(REF_PKG) and fm.__file__.startswith(REF_PKG), "not the reference's util package"
         _REGISTRY["models.TransformerEncoderWrapper"] = dn.TransformerEncoderWrapper
         _REGISTRY["models.Denoiser"] = dn.Denoiser
         _REGISTRY["models.GaussianDiffusion"] = gd.GaussianDiffusion
@@ -150,6 +163,11 @@ def load_reference():
         ns.PerspectiveCameras = _PerspectiveCameras
     finally:
         sys.path.remove(REF_PKG)
+        for k in list(_ours()):
+            del sys.modules[k]
+        sys.modules.update(parked)
+        for k in stub_names:          # the stubs are only for the reference's import time
+            sys.modules.pop(k, None)
     _loaded = ns
     return ns
 

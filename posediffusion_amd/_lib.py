@@ -63,6 +63,7 @@ SIGNATURES = {
     "pd_pose_to_camera": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "pd_time_kernel": (_i, [_vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _i, C.POINTER(C.c_float), _vp]),
     "pd_check_async_error": (_i, [_vp]),
+    "pd_debug_ggs_prof": (_i, [_vp, _i, C.POINTER(C.c_longlong)]),
 }
 
 _lib = None

@@ -34,6 +34,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define ZD 384          // z_dim
 #define KFIRST 702      // 189 + 128 + 384 + 1   (denoiser.py:39)
 #define KFIRST_PAD 704
+// The engine permutes the K axis of _first so the wide pieces land 16-byte aligned in LDS:
+//   engine column k' : [0,384) z | [384,512) t_emb | [512,692) harmonic | [692,701) x | 701 pivot | 702,703 pad
+//   reference column : [0,180) harmonic | [180,189) x | [189,317) t_emb | [317,701) z | 701 pivot  (denoiser.py:68)
+__host__ __device__ inline int pd_first_col(int kp) {
+    if (kp < 384) return 317 + kp;
+    if (kp < 512) return 189 + (kp - 384);
+    if (kp < 692) return kp - 512;
+    if (kp < 701) return 180 + (kp - 692);
+    return kp;   // 701 pivot; 702/703 are padding (>= KFIRST -> zero)
+}
 #define HID 128         // mlp_hidden_dim
 
 struct PdLayerDev {
@@ -51,7 +61,7 @@ struct PdDenoiserDev {
     PdLayerDev layers[PD_MAX_LAYERS];
     float *last0_wp = nullptr, *last0_b = nullptr, *last_ln_w = nullptr, *last_ln_b = nullptr;
     float *last3_w = nullptr, *last3_b = nullptr;   // [9,128] plain
-    float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ff = nullptr;   // activations [m_cap, .]
+    float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ff = nullptr, *hid = nullptr;   // activations [m_cap, .]
     std::vector<void *> allocs;
 };
 
@@ -59,7 +69,8 @@ struct PdDenoiserDev {
 // weight repack: W[Nout][K] row-major  ->  Wp[nt][kc][lane][4], lane l holds
 // W[nt*32 + (l & 31)][kc*8 + 4*(l >> 5) + 0..3]   (zero padded)
 // --------------------------------------------------------------------------------------------
-__global__ void pd_repack_kernel(const float *__restrict__ W, int Nout, int K, int KC, float *__restrict__ Wp, size_t total) {
+__global__ void pd_repack_kernel(const float *__restrict__ W, int Nout, int K, int KC, float *__restrict__ Wp, size_t total,
+                                 int first_perm) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int e = idx & 3;
         const int l = (idx >> 2) & 63;
@@ -67,7 +78,8 @@ __global__ void pd_repack_kernel(const float *__restrict__ W, int Nout, int K, i
         const int kc = (int)(rest % KC);
         const int nt = (int)(rest / KC);
         const int n = nt * 32 + (l & 31);
-        const int k = kc * 8 + 4 * (l >> 5) + e;
+        int k = kc * 8 + 4 * (l >> 5) + e;
+        if (first_perm) k = pd_first_col(k);
         Wp[idx] = (n < Nout && k < K) ? W[(size_t)n * K + k] : 0.0f;
     }
 }
@@ -117,49 +129,75 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
     constexpr int LDA = K + 4;            // padded row stride (floats): conflict-free ds_read_b128
     constexpr int KC = K / 8;             // 8-wide k chunks
     constexpr int CPW = KC / 4;           // chunks per wave (split-K over the 4 waves)
+    constexpr int NB = (CPW > 16) ? 2 : 1;   // weight batches held in registers
+    constexpr int BATCH = CPW / NB;
+    static_assert(CPW % NB == 0, "chunk batching");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *As = lds;                      // [32][LDA]; later aliased by the cross-wave reduction
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
     const float4 *wp = (const float4 *)g.Wp + ((size_t)blockIdx.y * KC + (size_t)wave * CPW) * 64 + lane;
 
-    // ---- stage the 32 activation rows (fused LN / embedding) ---------------------------------
+    // ---- weights first: the whole first batch of this wave's fragments goes in flight before the
+    // activation staging, so the HBM/MALL latency of the weight stream hides under it --------------
+    float4 w0[BATCH];
+#pragma unroll
+    for (int c = 0; c < BATCH; ++c) w0[c] = wp[(size_t)c * 64];
+
+    // ---- stage the 32 activation rows (fused LN / embedding); no predicated loads ---------------
     {
         const int r = tid >> 3, sub = tid & 7;
         const int m = m0 + r;
+        const bool live = m < g.M;
+        const int mr = live ? m : g.M - 1;   // clamp: padded rows load a valid row and are zeroed
         float *dst = As + r * LDA;
         if constexpr (AMODE == 2) {
-            if (m < g.M) {
-                const float *xr = g.x + (size_t)m * 9;
-                // harmonic embedding: idx = s*90 + d*10 + k -> sin(x_d * 2^k + s * pi/2)
-                for (int idx = sub; idx < 180; idx += 8) {
-                    const int s = idx / 90, rem = idx - s * 90, d = rem / 10, kk = rem - d * 10;
-                    const float e = xr[d] * (float)(1 << kk);
-                    dst[idx] = sinf(s ? e + 1.5707963267948966f : e);
-                }
-                for (int idx = sub; idx < 9; idx += 8) dst[180 + idx] = xr[idx];
-                for (int idx = sub; idx < 128; idx += 8) dst[189 + idx] = g.temb[idx];
-                const float *zr = g.z + (size_t)m * ZD;
-                for (int idx = sub; idx < ZD; idx += 8) dst[317 + idx] = zr[idx];
-                if (sub == 0) {
-                    dst[701] = (m % g.n_frames == 0) ? 1.0f : 0.0f;   // pivot one-hot on frame 0
-                    dst[702] = 0.0f;
-                    dst[703] = 0.0f;
-                }
-            } else {
-                for (int idx = sub; idx < K; idx += 8) dst[idx] = 0.0f;
+            // engine column order (pd_first_col): z | t_emb | harmonic | x | pivot | pad
+            const float4 *zr = (const float4 *)(g.z + (size_t)mr * ZD);
+            const float4 *te = (const float4 *)g.temb;
+            float4 zv[ZD / 32], tv[4];
+#pragma unroll
+            for (int i = 0; i < ZD / 32; ++i) zv[i] = zr[sub + 8 * i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tv[i] = te[sub + 8 * i];
+            float xv[9];
+#pragma unroll
+            for (int d = 0; d < 9; ++d) xv[d] = g.x[(size_t)mr * 9 + d];
+            const float keep = live ? 1.0f : 0.0f;
+#pragma unroll
+            for (int i = 0; i < ZD / 32; ++i) {
+                float4 v = zv[i];
+                v.x *= keep; v.y *= keep; v.z *= keep; v.w *= keep;
+                *(float4 *)(dst + 4 * (sub + 8 * i)) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 v = tv[i];
+                v.x *= keep; v.y *= keep; v.z *= keep; v.w *= keep;
+                *(float4 *)(dst + 384 + 4 * (sub + 8 * i)) = v;
+            }
+            // harmonic embedding: idx = s*90 + d*10 + k -> sin(x_d * 2^k + s * pi/2)  (pytorch3d 0.7.x)
+            for (int idx = sub; idx < 180; idx += 8) {
+                const int s = idx / 90, rem = idx - s * 90, d = rem / 10, kk = rem - d * 10;
+                float xd = xv[0];
+#pragma unroll
+                for (int q = 1; q < 9; ++q) xd = (d == q) ? xv[q] : xd;
+                const float e = xd * (float)(1 << kk);
+                dst[512 + idx] = keep * sinf(s ? e + 1.5707963267948966f : e);
+            }
+            if (sub == 0) {
+#pragma unroll
+                for (int d = 0; d < 9; ++d) dst[692 + d] = keep * xv[d];
+                dst[701] = (live && (m % g.n_frames == 0)) ? 1.0f : 0.0f;   // pivot one-hot on frame 0
+                dst[702] = 0.0f;
+                dst[703] = 0.0f;
             }
         } else if constexpr (AMODE == 1) {
             static_assert(AMODE != 1 || K == 512, "LayerNorm staging is built for d_model = 512");
             float4 v[K / 32];
-            if (m < g.M) {
-                const float4 *src = (const float4 *)(g.A + (size_t)m * K);
+            const float4 *src = (const float4 *)(g.A + (size_t)mr * K);
 #pragma unroll
-                for (int i = 0; i < K / 32; ++i) v[i] = src[sub + 8 * i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < K / 32; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int i = 0; i < K / 32; ++i) v[i] = src[sub + 8 * i];
             float s = 0.0f;
 #pragma unroll
             for (int i = 0; i < K / 32; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -176,49 +214,66 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
             q += __shfl_xor(q, 1, 64);
             q += __shfl_xor(q, 2, 64);
             q += __shfl_xor(q, 4, 64);
-            const float rstd = 1.0f / sqrtf(q * (1.0f / K) + 1e-5f);
+            const float rstd = live ? 1.0f / sqrtf(q * (1.0f / K) + 1e-5f) : 0.0f;
             const float4 *gw = (const float4 *)g.ln_w, *gb = (const float4 *)g.ln_b;
 #pragma unroll
             for (int i = 0; i < K / 32; ++i) {
                 const float4 w = gw[sub + 8 * i], bb = gb[sub + 8 * i];
                 float4 o;
-                o.x = (v[i].x - mean) * rstd * w.x + bb.x;
-                o.y = (v[i].y - mean) * rstd * w.y + bb.y;
-                o.z = (v[i].z - mean) * rstd * w.z + bb.z;
-                o.w = (v[i].w - mean) * rstd * w.w + bb.w;
-                if (m >= g.M) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                o.x = (v[i].x - mean) * rstd * w.x + (live ? bb.x : 0.0f);
+                o.y = (v[i].y - mean) * rstd * w.y + (live ? bb.y : 0.0f);
+                o.z = (v[i].z - mean) * rstd * w.z + (live ? bb.z : 0.0f);
+                o.w = (v[i].w - mean) * rstd * w.w + (live ? bb.w : 0.0f);
                 *(float4 *)(dst + 4 * (sub + 8 * i)) = o;
             }
         } else {
-            const float4 *src = (const float4 *)(g.A + (size_t)m * K);
-#pragma unroll 8
-            for (int i = 0; i < K / 32; ++i) {
-                const float4 v = (m < g.M) ? src[sub + 8 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                *(float4 *)(dst + 4 * (sub + 8 * i)) = v;
+            const float4 *src = (const float4 *)(g.A + (size_t)mr * K);
+            const float keep = live ? 1.0f : 0.0f;
+            constexpr int NV = K / 32;
+            constexpr int VB = 16;        // loads in flight per pass
+#pragma unroll
+            for (int i0 = 0; i0 < NV; i0 += VB) {
+                float4 v[VB];
+#pragma unroll
+                for (int i = 0; i < VB; ++i) v[i] = src[sub + 8 * (i0 + i)];
+#pragma unroll
+                for (int i = 0; i < VB; ++i) {
+                    float4 o = v[i];
+                    o.x *= keep; o.y *= keep; o.z *= keep; o.w *= keep;
+                    *(float4 *)(dst + 4 * (sub + 8 * (i0 + i))) = o;
+                }
             }
         }
     }
     __syncthreads();
 
     // ---- split-K MFMA loop: wave w owns k-chunks [w*CPW, (w+1)*CPW) --------------------------
+    float4 w1[NB == 2 ? BATCH : 1];
+    if constexpr (NB == 2) {
+#pragma unroll
+        for (int c = 0; c < BATCH; ++c) w1[c] = wp[(size_t)(BATCH + c) * 64];
+        __builtin_amdgcn_sched_barrier(0);   // keep the second batch's loads ahead of the first MFMAs
+    }
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     const float *arow = As + (lane & 31) * LDA + wave * CPW * 8 + 4 * (lane >> 5);
-    constexpr int BATCH = (CPW % 16 == 0) ? 16 : ((CPW % 11 == 0) ? 11 : CPW);
-    static_assert(CPW % BATCH == 0, "chunk batching");
-#pragma unroll 1
-    for (int c0 = 0; c0 < CPW; c0 += BATCH) {
-        float4 wf[BATCH];
 #pragma unroll
-        for (int c = 0; c < BATCH; ++c) wf[c] = wp[(size_t)(c0 + c) * 64];
+    for (int c = 0; c < BATCH; ++c) {
+        const float4 af = *(const float4 *)(arow + c * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, w0[c].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, w0[c].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, w0[c].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, w0[c].w, acc, 0, 0, 0);
+    }
+    if constexpr (NB == 2) {
 #pragma unroll
         for (int c = 0; c < BATCH; ++c) {
-            const float4 af = *(const float4 *)(arow + (c0 + c) * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, wf[c].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, wf[c].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, wf[c].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, wf[c].w, acc, 0, 0, 0);
+            const float4 af = *(const float4 *)(arow + (BATCH + c) * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, w1[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, w1[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, w1[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, w1[c].w, acc, 0, 0, 0);
         }
     }
     __syncthreads();   // every wave is done reading As; reuse it for the reduction
@@ -249,73 +304,82 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
 }
 
 // --------------------------------------------------------------------------------------------
-// attention core: one workgroup per (sequence, head); N <= 64 frames, no mask
-// (nn.MultiheadAttention inside the encoder layer: softmax(q k^T / sqrt(dh)) v)
+// attention core: softmax(q k^T / sqrt(dh)) v for one (sequence, head), N <= 64 frames, no mask
+// (nn.MultiheadAttention inside the encoder layer).  grid = (B*heads, ceil(N/4)): every
+// workgroup stages K and V of its (sequence, head) and each of its 4 waves owns ONE query row:
+// lane j scores key j, softmax is a wave reduction, lanes then own 2 of the 128 output dims.
 // --------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pd_wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float pd_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void pd_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int N) {
     constexpr int LD = DH + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *Q = lds, *Kk = Q + N * LD, *V = Kk + N * LD, *S = V + N * LD;   // S [N][N+1]
-    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    float *Kk = lds, *V = Kk + N * LD, *Q = V + N * LD, *P = Q + 4 * LD;   // P [4][64]
+    const int b = blockIdx.x / NH, h = blockIdx.x % NH, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.y * 4 + wave;        // this wave's query row
     const float scale = 0.08838834764831845f;   // 1/sqrt(128)
+    const float *base = qkv + (size_t)b * N * (3 * DM) + h * DH;
     for (int idx = tid; idx < N * (DH / 4); idx += 256) {
-        const int i = idx / (DH / 4), d4 = idx % (DH / 4);
-        const float *row = qkv + (size_t)(b * N + i) * (3 * DM) + h * DH + d4 * 4;
-        float4 q = *(const float4 *)row;
-        const float4 kv = *(const float4 *)(row + DM);
-        const float4 vv = *(const float4 *)(row + 2 * DM);
+        const int j = idx / (DH / 4), d4 = idx % (DH / 4);
+        const float *row = base + (size_t)j * (3 * DM) + d4 * 4;
+        *(float4 *)(Kk + j * LD + d4 * 4) = *(const float4 *)(row + DM);
+        *(float4 *)(V + j * LD + d4 * 4) = *(const float4 *)(row + 2 * DM);
+    }
+    if (lane < DH / 4) {
+        const int ii = i < N ? i : N - 1;
+        float4 q = *(const float4 *)(base + (size_t)ii * (3 * DM) + lane * 4);
         q.x *= scale; q.y *= scale; q.z *= scale; q.w *= scale;
-        *(float4 *)(Q + i * LD + d4 * 4) = q;
-        *(float4 *)(Kk + i * LD + d4 * 4) = kv;
-        *(float4 *)(V + i * LD + d4 * 4) = vv;
+        *(float4 *)(Q + wave * LD + lane * 4) = q;
     }
     __syncthreads();
-    for (int idx = tid; idx < N * N; idx += 256) {
-        const int i = idx / N, j = idx % N;
-        const float4 *qa = (const float4 *)(Q + i * LD), *kb = (const float4 *)(Kk + j * LD);
-        float s = 0.0f;
+    const int jj = lane < N ? lane : N - 1;
+    const float4 *qa = (const float4 *)(Q + wave * LD), *kb = (const float4 *)(Kk + jj * LD);
+    float s = 0.0f;
 #pragma unroll 8
-        for (int d = 0; d < DH / 4; ++d) {
-            const float4 a = qa[d], c = kb[d];
-            s = fmaf(a.x, c.x, s);
-            s = fmaf(a.y, c.y, s);
-            s = fmaf(a.z, c.z, s);
-            s = fmaf(a.w, c.w, s);
-        }
-        S[i * (N + 1) + j] = s;
+    for (int d = 0; d < DH / 4; ++d) {
+        const float4 a = qa[d], c = kb[d];
+        s = fmaf(a.x, c.x, s);
+        s = fmaf(a.y, c.y, s);
+        s = fmaf(a.z, c.z, s);
+        s = fmaf(a.w, c.w, s);
     }
+    const float sv = lane < N ? s : -INFINITY;
+    const float mx = pd_wave_max(sv);
+    const float e = lane < N ? expf(sv - mx) : 0.0f;
+    const float inv = 1.0f / pd_wave_sum(e);
+    P[wave * 64 + lane] = e * inv;
     __syncthreads();
-    if (tid < N) {
-        float *row = S + tid * (N + 1);
-        float mx = row[0];
-        for (int j = 1; j < N; ++j) mx = fmaxf(mx, row[j]);
-        float sum = 0.0f;
+    if (i < N) {
+        const float *p = P + wave * 64;
+        float o0 = 0.0f, o1 = 0.0f;
         for (int j = 0; j < N; ++j) {
-            const float e = expf(row[j] - mx);
-            row[j] = e;
-            sum += e;
+            const float pj = p[j];
+            o0 = fmaf(pj, V[j * LD + lane], o0);
+            o1 = fmaf(pj, V[j * LD + 64 + lane], o1);
         }
-        const float inv = 1.0f / sum;
-        for (int j = 0; j < N; ++j) row[j] *= inv;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < N * DH; idx += 256) {
-        const int i = idx / DH, d = idx % DH;
-        const float *p = S + i * (N + 1);
-        float o = 0.0f;
-        for (int j = 0; j < N; ++j) o = fmaf(p[j], V[j * LD + d], o);
-        ctx[(size_t)(b * N + i) * DM + h * DH + d] = o;
+        float *out = ctx + (size_t)(b * N + i) * DM + h * DH;
+        out[lane] = o0;
+        out[64 + lane] = o1;
     }
 }
 
 // --------------------------------------------------------------------------------------------
-// head: _last MLP (Linear 512->128, LayerNorm(128), ReLU, Linear 128->9; denoiser.py:51,74) fused
-// with predict_start_from_noise / q_posterior / the sample update (gaussian_diffuser.py:190-209,:280)
-// one workgroup per 32 tokens; wave w computes hidden columns [32w, 32w+32) over the full K = 512
+// tail of the head: LayerNorm(128) -> ReLU -> Linear(128 -> 9) (denoiser.py:51,74 `_last.1..3`)
+// fused with predict_start_from_noise / q_posterior / the sample update
+// (gaussian_diffuser.py:190-209, :280).  One wave per token; lane holds 2 of the 128 hidden values.
 // --------------------------------------------------------------------------------------------
 struct HeadArgs {
-    const float *h;        // [M, 512]
-    const float *w0p, *b0, *lnw, *lnb, *w3, *b3;
+    const float *hid;      // [M, 128] = _last.0 output (bias included)
+    const float *lnw, *lnb, *w3, *b3;
     const float *x;        // [M, 9] current sample
     const float *noise;    // [M, 9] or null
     float *eps_out, *mean_out, *x0_out, *xnext_out;   // each [M, 9] or null
@@ -323,95 +387,33 @@ struct HeadArgs {
     int M;
 };
 
-__global__ __launch_bounds__(256) void pd_head_kernel(HeadArgs g) {
-    constexpr int K = DM, LDA = K + 4, KC = K / 8;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *As = lds;                       // [32][516]
-    float *Hd = lds + 32 * LDA;            // [32][132] hidden
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * 32;
-    {
-        const int r = tid >> 3, sub = tid & 7, m = m0 + r;
-        const float4 *src = (const float4 *)(g.h + (size_t)m * K);
-#pragma unroll 8
-        for (int i = 0; i < K / 32; ++i) {
-            const float4 v = (m < g.M) ? src[sub + 8 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            *(float4 *)(As + r * LDA + 4 * (sub + 8 * i)) = v;
-        }
+__global__ __launch_bounds__(256) void pd_tail_kernel(HeadArgs g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= g.M) return;
+    const float *row = g.hid + (size_t)m * HID;
+    const float v0 = row[lane], v1 = row[64 + lane];
+    const float mean = pd_wave_sum(v0 + v1) * (1.0f / HID);
+    const float d0 = v0 - mean, d1 = v1 - mean;
+    const float rstd = 1.0f / sqrtf(pd_wave_sum(d0 * d0 + d1 * d1) * (1.0f / HID) + 1e-5f);
+    const float a0 = fmaxf(d0 * rstd * g.lnw[lane] + g.lnb[lane], 0.0f);
+    const float a1 = fmaxf(d1 * rstd * g.lnw[64 + lane] + g.lnb[64 + lane], 0.0f);
+    float e = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+        const float part = pd_wave_sum(fmaf(a0, g.w3[o * HID + lane], a1 * g.w3[o * HID + 64 + lane]));
+        e = (lane == o) ? part : e;
     }
-    __syncthreads();
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    const float4 *wp = (const float4 *)g.w0p + ((size_t)wave * KC) * 64 + lane;
-    const float *arow = As + (lane & 31) * LDA + 4 * (lane >> 5);
-#pragma unroll 1
-    for (int c0 = 0; c0 < KC; c0 += 16) {
-        float4 wf[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) wf[c] = wp[(size_t)(c0 + c) * 64];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const float4 af = *(const float4 *)(arow + (c0 + c) * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, wf[c].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, wf[c].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, wf[c].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, wf[c].w, acc, 0, 0, 0);
-        }
-    }
-    {
-        const int col = wave * 32 + (lane & 31);
-        const float bias = g.b0[col];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-            Hd[row * (HID + 4) + col] = acc[i] + bias;
-        }
-    }
-    __syncthreads();
-    {   // LayerNorm(128) + ReLU, 8 threads per row
-        const int r = tid >> 3, sub = tid & 7;
-        float *row = Hd + r * (HID + 4);
-        float v[16];
-        float s = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            v[i] = row[sub + 8 * i];
-            s += v[i];
-        }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        const float mean = s * (1.0f / HID);
-        float q = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) q += (v[i] - mean) * (v[i] - mean);
-        q += __shfl_xor(q, 1, 64);
-        q += __shfl_xor(q, 2, 64);
-        q += __shfl_xor(q, 4, 64);
-        const float rstd = 1.0f / sqrtf(q * (1.0f / HID) + 1e-5f);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c = sub + 8 * i;
-            row[c] = fmaxf((v[i] - mean) * rstd * g.lnw[c] + g.lnb[c], 0.0f);
-        }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 32 * 9; idx += 256) {
-        const int r = idx / 9, o = idx % 9, m = m0 + r;
-        if (m >= g.M) continue;
-        const float *row = Hd + r * (HID + 4);
-        const float *w = g.w3 + o * HID;
-        float e = g.b3[o];
-        for (int k = 0; k < HID; ++k) e = fmaf(row[k], w[k], e);
-        const size_t at = (size_t)m * 9 + o;
+    if (lane < 9) {
+        e += g.b3[lane];
+        const size_t at = (size_t)m * 9 + lane;
         const float xv = g.x[at];
         const float x0 = g.c_recip * xv - g.c_recipm1 * e;          // gaussian_diffuser.py:190-194
-        const float mean = g.coef1 * x0 + g.coef2 * xv;             // :201-205
+        const float mu = g.coef1 * x0 + g.coef2 * xv;               // :201-205
         if (g.eps_out) g.eps_out[at] = e;
         if (g.x0_out) g.x0_out[at] = x0;
-        if (g.mean_out) g.mean_out[at] = mean;
-        if (g.xnext_out) g.xnext_out[at] = g.noise ? mean + g.sigma * g.noise[at] : mean;   // :280
+        if (g.mean_out) g.mean_out[at] = mu;
+        if (g.xnext_out) g.xnext_out[at] = g.noise ? mu + g.sigma * g.noise[at] : mu;   // :280
     }
 }
 
@@ -433,7 +435,7 @@ static int dev_copy(PdDenoiserDev *d, float **dst, const float *src, size_t n) {
     PD_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice));
     return PD_OK;
 }
-static int dev_pack(PdDenoiserDev *d, float **dst, const float *W, int Nout, int K, int Kpad) {
+static int dev_pack(PdDenoiserDev *d, float **dst, const float *W, int Nout, int K, int Kpad, int first_perm = 0) {
     if (!W) {
         pd_set_error("pd_engine_create: a weight pointer is NULL");
         return PD_ERR_INVALID_ARG;
@@ -442,7 +444,7 @@ static int dev_pack(PdDenoiserDev *d, float **dst, const float *W, int Nout, int
     const size_t total = (size_t)NT * KC * 256;
     int rc = dev_alloc(d, dst, total);
     if (rc) return rc;
-    hipLaunchKernelGGL(pd_repack_kernel, dim3(512), dim3(256), 0, 0, W, Nout, K, KC, *dst, total);
+    hipLaunchKernelGGL(pd_repack_kernel, dim3(512), dim3(256), 0, 0, W, Nout, K, KC, *dst, total, first_perm);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }
@@ -482,7 +484,7 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
         hipLaunchKernelGGL(pd_time_table_kernel, dim3(w->timesteps), dim3(128), 0, 0, w0, b0, w2, b2, d->t_table);
         PD_HIP_CHECK(hipGetLastError());
     }
-    PD_TRY(dev_pack(d, &d->first_wp, w->first_w, DM, KFIRST, KFIRST_PAD));
+    PD_TRY(dev_pack(d, &d->first_wp, w->first_w, DM, KFIRST, KFIRST_PAD, 1));
     PD_TRY(dev_copy(d, &d->first_b, w->first_b, DM));
     for (int l = 0; l < w->num_layers; ++l) {
         const pd_layer_weights &s = w->layers[l];
@@ -510,13 +512,14 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(dev_alloc(d, &d->qkv, (size_t)d->m_cap * 3 * DM));
     PD_TRY(dev_alloc(d, &d->ctx, (size_t)d->m_cap * DM));
     PD_TRY(dev_alloc(d, &d->ff, (size_t)d->m_cap * DFF));
+    PD_TRY(dev_alloc(d, &d->hid, (size_t)d->m_cap * HID));
     PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0>, 32 * (KFIRST_PAD + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 0>, 32 * (DM + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 1>, 32 * (DM + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DM, 0, 2>, 32 * (DM + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DFF, 0, 2>, 32 * (DFF + 4) * 4));
-    PD_TRY(set_lds(pd_head_kernel, (32 * (DM + 4) + 32 * (HID + 4)) * 4));
-    PD_TRY(set_lds(pd_attn_kernel, (3 * 64 * (DH + 4) + 64 * 65) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<DM, 0, 0>, 32 * (DM + 4) * 4));
+    PD_TRY(set_lds(pd_attn_kernel, ((2 * 64 + 4) * (DH + 4) + 4 * 64) * 4));
     PD_HIP_CHECK(hipDeviceSynchronize());
     return PD_OK;
 }
@@ -549,7 +552,7 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
         // x += MHA(LN1(x))
         g.A = d->h; g.Wp = L.qkv_wp; g.bias = L.qkv_b; g.C = d->qkv; g.Nout = 3 * DM; g.ln_w = L.ln1_w; g.ln_b = L.ln1_b;
         hipLaunchKernelGGL((pd_gemm_kernel<DM, 1, 0>), dim3(MT, 3 * DM / 32), dim3(256), 32 * (DM + 4) * 4, s, g);
-        hipLaunchKernelGGL(pd_attn_kernel, dim3(B, NH), dim3(256), (3 * N * (DH + 4) + N * (N + 1)) * 4, s, d->qkv, d->ctx, N);
+        hipLaunchKernelGGL(pd_attn_kernel, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
         g.A = d->ctx; g.Wp = L.out_wp; g.bias = L.out_b; g.C = d->h; g.Nout = DM;
         hipLaunchKernelGGL((pd_gemm_kernel<DM, 0, 2>), dim3(MT, DM / 32), dim3(256), 32 * (DM + 4) * 4, s, g);
         // x += W2 relu(W1 LN2(x))
@@ -558,15 +561,18 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
         g.A = d->ff; g.Wp = L.ff2_wp; g.bias = L.ff2_b; g.C = d->h; g.Nout = DM;
         hipLaunchKernelGGL((pd_gemm_kernel<DFF, 0, 2>), dim3(MT, DM / 32), dim3(256), 32 * (DFF + 4) * 4, s, g);
     }
+    // _last.0 as a plain tile GEMM (4 N-tiles), then the fused LN/ReLU/Linear(128->9)/DDPM tail
+    g.A = d->h; g.Wp = d->last0_wp; g.bias = d->last0_b; g.C = d->hid; g.Nout = HID;
+    hipLaunchKernelGGL((pd_gemm_kernel<DM, 0, 0>), dim3(MT, HID / 32), dim3(256), 32 * (DM + 4) * 4, s, g);
     HeadArgs ha;
     memset(&ha, 0, sizeof(ha));
-    ha.h = d->h; ha.w0p = d->last0_wp; ha.b0 = d->last0_b; ha.lnw = d->last_ln_w; ha.lnb = d->last_ln_b;
+    ha.hid = d->hid; ha.lnw = d->last_ln_w; ha.lnb = d->last_ln_b;
     ha.w3 = d->last3_w; ha.b3 = d->last3_b; ha.x = x; ha.noise = noise;
     ha.eps_out = eps_out; ha.mean_out = mean_out; ha.x0_out = x0_out; ha.xnext_out = x_next_out;
     ha.c_recip = eng->c_recip[t]; ha.c_recipm1 = eng->c_recipm1[t]; ha.coef1 = eng->coef1[t]; ha.coef2 = eng->coef2[t];
     ha.sigma = expf(0.5f * eng->logvar[t]);
     ha.M = M;
-    hipLaunchKernelGGL(pd_head_kernel, dim3(MT), dim3(256), (32 * (DM + 4) + 32 * (HID + 4)) * 4, s, ha);
+    hipLaunchKernelGGL(pd_tail_kernel, dim3((M + 3) / 4), dim3(256), 0, s, ha);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }

@@ -120,7 +120,7 @@ extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_en
     }
         PD_ALLOC(eng->d_seqs, sizeof(PdSeqDesc) * max_B);
         PD_ALLOC(eng->d_xchg, sizeof(unsigned long long) * 2 * eng->xchg_granules * max_B);
-        PD_ALLOC(eng->d_err, 64);
+        PD_ALLOC(eng->d_err, 256);
         PD_ALLOC(eng->d_z, sizeof(float) * max_B * max_N * w->z_dim);
         PD_ALLOC(eng->d_noise, sizeof(float) * (T + 1) * bn9);
         PD_ALLOC(eng->d_process, sizeof(float) * (T + 1) * bn9);
@@ -128,7 +128,7 @@ extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_en
         PD_ALLOC(eng->d_stats, sizeof(float) * (size_t)T * max_B * 5 * 4);
 #undef PD_ALLOC
         if (hipMemset(eng->d_seqs, 0, sizeof(PdSeqDesc) * max_B) != hipSuccess ||
-            hipMemset(eng->d_err, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            hipMemset(eng->d_err, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
             pd_set_error("pd_engine_create: hipMemset failed");
             rc = PD_ERR_HIP;
             break;
@@ -389,6 +389,18 @@ extern "C" int pd_check_async_error(pd_engine *eng) {
         pd_set_error("GGS cross-workgroup exchange timed out (flag=%u)", v);
         (void)hipMemset(eng->d_err, 0, sizeof(v));
         return PD_ERR_STATE;
+    }
+    return PD_OK;
+}
+
+// debug: enable/read the GGS kernel's phase cycle counters (P1, P2, exchange, P3, P4, iterations)
+// of workgroup 0.  out6 may be NULL to just switch collection on/off.
+extern "C" int pd_debug_ggs_prof(pd_engine *eng, int enable, long long *out6) {
+    if (!eng) return PD_ERR_INVALID_ARG;
+    eng->ggs_prof_on = enable;
+    if (out6) {
+        PD_HIP_CHECK(hipDeviceSynchronize());
+        PD_HIP_CHECK(hipMemcpy(out6, eng->d_err + 2, sizeof(long long) * 6, hipMemcpyDeviceToHost));
     }
     return PD_OK;
 }

@@ -37,11 +37,23 @@ typedef unsigned long long u64;
 // --------------------------------------------------------------------------------------------
 // device helpers
 // --------------------------------------------------------------------------------------------
+// 64-lane sum on the DPP cross-lane network (no LDS round trips): xor-1, xor-2 quad permutes,
+// half-row and row mirrors give every lane its 16-lane row sum; row_bcast15/31 chain the four rows;
+// lane 63 holds the total, read back into an SGPR.  Fixed tree -> bitwise reproducible, and the
+// result is wave-uniform by construction.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
 __device__ __forceinline__ float wave_allsum(float v) {
-    // xor-butterfly: every lane ends with bitwise the same sum (fp add is commutative).
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);   // row_mirror
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 -> rows 1, 3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 -> rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 struct Cam {   // shared intrinsics of the step: A = K^-1 = [[a0,0,c0],[0,a1,c1],[0,0,1]]
@@ -107,11 +119,13 @@ struct Lds {
     float *gA;     // [64*4]  per-frame partial dL/dA {00,02,11,12}
     float *ctl;    // [8]     ctl[0] = stage done flag, ctl[1] = abort
     int4 *itab;    // [n_slots] (first match, count, i, j) of the local items
+    int4 *inc;     // [n_inc] incidence entries (only when they fit; else read from global)
+    int *incoff;   // [68] incidence CSR offsets per frame
     float *F;      // [n_slots*9]
     float *item;   // [n_items*12]
 };
 
-__device__ __forceinline__ Lds carve(float *base, int n_slots) {
+__device__ __forceinline__ Lds carve(float *base, int n_slots, int n_inc_lds) {
     Lds L;
     L.Rc = base;
     L.tc = L.Rc + 64 * 9;
@@ -123,14 +137,16 @@ __device__ __forceinline__ Lds carve(float *base, int n_slots) {
     L.gA = L.gR + 64 * 9;
     L.ctl = L.gA + 64 * 4;
     L.itab = (int4 *)(L.ctl + 8);
-    L.F = (float *)(L.itab + n_slots);
+    L.inc = L.itab + n_slots;
+    L.incoff = (int *)(L.inc + n_inc_lds);
+    L.F = (float *)(L.incoff + 68);
     L.item = L.F + n_slots * 9 + ((4 - ((n_slots * 9) & 3)) & 3);
     return L;
 }
-static size_t ggs_lds_bytes(int n_slots, int n_items) {
+static size_t ggs_lds_bytes(int n_slots, int n_items, int n_inc_lds) {
     size_t f9 = (size_t)n_slots * 9;
     f9 += (4 - (f9 & 3)) & 3;
-    return ((size_t)PD_GGS_LDS_FIXED + f9 + (size_t)n_items * PD_ITEM_VALS) * 4 + (size_t)n_slots * 16;
+    return ((size_t)PD_GGS_LDS_FIXED + 68 + f9 + (size_t)n_items * PD_ITEM_VALS) * 4 + (size_t)(n_slots + n_inc_lds) * 16;
 }
 
 // decode one frame's 9-vector into R_cv, t_cv, focal (camera_transform.py:80-97 + pytorch3d
@@ -190,7 +206,7 @@ __device__ __forceinline__ void decode_all(const Lds &L, const float *xr, int la
 // --------------------------------------------------------------------------------------------
 // the kernel
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, int B, int n_slots) {
+__global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, int B, int n_slots, int n_inc_lds) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x % B, wg = blockIdx.x / B;   // XCD-aware: see header comment
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
     const int N = P.N, k = P.k;
     const int nW = k * PD_GGS_WAVES;
     const int n_items = D.n_items;
-    const Lds L = carve(smem, n_slots);
+    const Lds L = carve(smem, n_slots, n_inc_lds);
     float *xg = P.x + (size_t)b * N * PD_POSE_DIM;
     u64 *xchg = P.xchg ? P.xchg + (size_t)b * 2 * P.xchg_stride : nullptr;
 
@@ -221,21 +237,42 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
         }
         L.itab[s] = e;
     }
+    for (int q = tid; q <= N; q += PD_GGS_THREADS) L.incoff[q] = D.inc_off[q];
+    for (int q = tid; q < n_inc_lds; q += PD_GGS_THREADS) L.inc[q] = D.inc[q];
+    const bool inc_lds = n_inc_lds > 0;
     if (tid == 0) {
         L.ctl[0] = 0.0f;
         L.ctl[1] = 0.0f;
     }
     if (wave == 0) decode_all(L, xr, lane, N, D);
     __syncthreads();
+    // matches of this wave's first item stay in registers for the whole launch when every wave owns
+    // at most one item (the k = ceil(items/8) regime): no per-iteration match traffic at all
+    const bool resident = (n_slots == PD_GGS_WAVES);
+    float4 mres[8];
+    {
+        const int4 e = L.itab[wave];
+        const int last = e.y > 0 ? e.y - 1 : 0;
+        const float4 *pts = D.pts + e.x;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int m = lane + 64 * st;
+            mres[st] = (resident && e.y > 0) ? pts[m < e.y ? m : last] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
 
     unsigned epoch = 0;
     int trace_row = 0;
+    const bool prof = P.prof != nullptr && blockIdx.x == 0 && wave == 1;   // a worker wave of WG 0
+    long long pt[6] = {0, 0, 0, 0, 0, 0}, pc = 0;
+#define PD_PROF(i) do { if (prof) { const long long _n = __builtin_readcyclecounter(); pt[i] += _n - pc; pc = _n; } } while (0)
     const float inv_M = 1.0f / (float)D.M;
     for (int st = 0; st < P.n_stages; ++st) {
         const PdGgsStage S = P.stages[st];
         int stepped = 0;
         float last_print = __int_as_float(0x7fc00000), last_cnt = 0.0f, last_loss = __int_as_float(0x7fc00000);
         for (int it = 0; it < S.iters; ++it) {
+            if (prof) pc = __builtin_readcyclecounter();
             // ---- P1: F for the pairs of this workgroup's items -------------------------------
             const Cam cam = {L.cam[0], L.cam[1], L.cam[2], L.cam[3]};
             for (int s = tid; s < n_slots; s += PD_GGS_THREADS) {
@@ -261,6 +298,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 }
             }
             __syncthreads();
+            PD_PROF(0);
 
             // ---- P2: per-match Sampson residual + dL/dF, one (pair, chunk) item per wave ------
             ++epoch;
@@ -275,36 +313,55 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 float acc[PD_ITEM_VALS];
 #pragma unroll
                 for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = 0.0f;
-                const float4 *pts = D.pts + e.x;
-                for (int m = lane; m < e.y; m += 64) {
-                    const float4 pt = pts[m];
-                    const float u1 = pt.x, v1 = pt.y, u2 = pt.z, v2 = pt.w;
-                    // left = x1^T F, right = F x2   (geometry_guided_sampling.py:158-159)
-                    const float l0 = fmaf(u1, F00, fmaf(v1, F10, F20));
-                    const float l1 = fmaf(u1, F01, fmaf(v1, F11, F21));
-                    const float l2 = fmaf(u1, F02, fmaf(v1, F12, F22));
-                    const float r0 = fmaf(F00, u2, fmaf(F01, v2, F02));
-                    const float r1 = fmaf(F10, u2, fmaf(F11, v2, F12));
-                    const float ee = fmaf(l0, u2, fmaf(l1, v2, l2));
-                    const float bottom = l0 * l0 + l1 * l1 + r0 * r0 + r1 * r1;   // :161
-                    const float sam = (ee * ee) / bottom;                             // :162-164
-                    acc[11] += fminf(sam, P.sampson_max);                             // :169
-                    const bool valid = sam < P.sampson_max;                           // :170
-                    const float inv = 1.0f / bottom;
-                    const float ca = valid ? 2.0f * ee * inv : 0.0f;
-                    const float cb = valid ? 2.0f * sam * inv : 0.0f;
-                    acc[9] += valid ? sam : 0.0f;
-                    acc[10] += valid ? 1.0f : 0.0f;
-                    // d sam / dF[r][c] = ca x1[r] x2[c] - cb (l_c x1[r] [c<2] + r_r x2[c] [r<2])
-                    acc[0] += ca * u1 * u2 - cb * (l0 * u1 + r0 * u2);
-                    acc[1] += ca * u1 * v2 - cb * (l1 * u1 + r0 * v2);
-                    acc[2] += ca * u1 - cb * r0;
-                    acc[3] += ca * v1 * u2 - cb * (l0 * v1 + r1 * u2);
-                    acc[4] += ca * v1 * v2 - cb * (l1 * v1 + r1 * v2);
-                    acc[5] += ca * v1 - cb * r1;
-                    acc[6] += ca * u2 - cb * l0;
-                    acc[7] += ca * v2 - cb * l1;
-                    acc[8] += ca;
+                float4 mb[8];
+                if (resident) {
+#pragma unroll
+                    for (int st = 0; st < 8; ++st) mb[st] = mres[st];
+                } else {
+                    // stream this item: all (<= 8) lines in flight at once, indices clamped (no
+                    // predicated loads), out-of-range lanes are masked in the arithmetic instead
+                    const float4 *pts = D.pts + e.x;
+                    const int last = e.y - 1;
+#pragma unroll
+                    for (int st = 0; st < 8; ++st) {
+                        const int m = lane + 64 * st;
+                        mb[st] = pts[m < e.y ? m : last];
+                    }
+                }
+                const int nsteps = (e.y + 63) >> 6;
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    if (st < nsteps) {
+                        const bool in = (lane + 64 * st) < e.y;
+                        const float4 pt = mb[st];
+                        const float u1 = pt.x, v1 = pt.y, u2 = pt.z, v2 = pt.w;
+                        // left = x1^T F, right = F x2   (geometry_guided_sampling.py:158-159)
+                        const float l0 = fmaf(u1, F00, fmaf(v1, F10, F20));
+                        const float l1 = fmaf(u1, F01, fmaf(v1, F11, F21));
+                        const float l2 = fmaf(u1, F02, fmaf(v1, F12, F22));
+                        const float r0 = fmaf(F00, u2, fmaf(F01, v2, F02));
+                        const float r1 = fmaf(F10, u2, fmaf(F11, v2, F12));
+                        const float ee = fmaf(l0, u2, fmaf(l1, v2, l2));
+                        const float bottom = l0 * l0 + l1 * l1 + r0 * r0 + r1 * r1;   // :161
+                        const float sam = (ee * ee) / bottom;                             // :162-164
+                        acc[11] += in ? fminf(sam, P.sampson_max) : 0.0f;                 // :169
+                        const bool valid = in && (sam < P.sampson_max);                   // :170
+                        const float inv = 1.0f / bottom;
+                        const float ca = valid ? 2.0f * ee * inv : 0.0f;
+                        const float cb = valid ? 2.0f * sam * inv : 0.0f;
+                        acc[9] += valid ? sam : 0.0f;
+                        acc[10] += valid ? 1.0f : 0.0f;
+                        // d sam / dF[r][c] = ca x1[r] x2[c] - cb (l_c x1[r] [c<2] + r_r x2[c] [r<2])
+                        acc[0] += ca * u1 * u2 - cb * (l0 * u1 + r0 * u2);
+                        acc[1] += ca * u1 * v2 - cb * (l1 * u1 + r0 * v2);
+                        acc[2] += ca * u1 - cb * r0;
+                        acc[3] += ca * v1 * u2 - cb * (l0 * v1 + r1 * u2);
+                        acc[4] += ca * v1 * v2 - cb * (l1 * v1 + r1 * v2);
+                        acc[5] += ca * v1 - cb * r1;
+                        acc[6] += ca * u2 - cb * l0;
+                        acc[7] += ca * v2 - cb * l1;
+                        acc[8] += ca;
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = wave_allsum(acc[c]);
@@ -324,25 +381,37 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                     }
                 }
             }
+            PD_PROF(1);
             if (k > 1) {
                 // all-gather of every item's 12 sums: the data IS the flag (tag == epoch)
                 const u64 *slot = xchg + (size_t)(epoch & 1) * P.xchg_stride;
                 bool fail = false;
-                for (int g = tid; g < n_items * PD_ITEM_VALS; g += PD_GGS_THREADS) {
-                    u64 v;
+                const int n_gran = n_items * PD_ITEM_VALS;
+                for (int g0 = tid; g0 < n_gran; g0 += 8 * PD_GGS_THREADS) {
+                    u64 v[8];
                     unsigned spins = 0;
                     for (;;) {
-                        v = __hip_atomic_load(slot + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((unsigned)(v >> 32) == epoch) break;
-                        if (++spins > (1u << 22) ||
-                            ((spins & 1023u) == 0 &&
+                        bool ok = true;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {   // 8 independent polls in flight per pass
+                            const int g = g0 + u * PD_GGS_THREADS;
+                            v[u] = __hip_atomic_load(slot + (g < n_gran ? g : g0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ok && ((unsigned)(v[u] >> 32) == epoch);
+                        }
+                        if (ok) break;
+                        if (++spins > (1u << 20) ||
+                            ((spins & 255u) == 0 &&
                              __hip_atomic_load(P.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                             fail = true;
                             break;
                         }
                         __builtin_amdgcn_s_sleep(1);
                     }
-                    L.item[g] = __uint_as_float((unsigned)v);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int g = g0 + u * PD_GGS_THREADS;
+                        if (g < n_gran) L.item[g] = __uint_as_float((unsigned)v[u]);
+                    }
                 }
                 if (fail) {
                     atomicOr(P.err_flag, 1u);
@@ -351,17 +420,18 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
             }
             __syncthreads();
             if (L.ctl[1] != 0.0f) return;   // a bounded spin gave up: abort the whole workgroup
+            PD_PROF(2);
 
             // ---- P3: per-frame backward, one frame per wave, one incident pair per lane ------
             for (int n = wave; n < N; n += PD_GGS_WAVES) {
-                const int e0 = D.inc_off[n], deg = D.inc_off[n + 1] - e0;
+                const int e0 = L.incoff[n], deg = L.incoff[n + 1] - e0;
                 float oR[9], ot[3], oA[4];
 #pragma unroll
                 for (int c = 0; c < 9; ++c) oR[c] = 0.0f;
                 ot[0] = ot[1] = ot[2] = 0.0f;
                 oA[0] = oA[1] = oA[2] = oA[3] = 0.0f;
                 for (int q = lane; q < deg; q += 64) {
-                    const int4 ie = D.inc[e0 + q];   // (i, j, first item, n_items | side << 16)
+                    const int4 ie = inc_lds ? L.inc[e0 + q] : D.inc[e0 + q];   // (i, j, first item, n_items | side << 16)
                     const int pi = ie.x, pj = ie.y, side = ie.w >> 16, nit = ie.w & 0xffff;
                     float G[9];
 #pragma unroll
@@ -482,6 +552,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 }
             }
             __syncthreads();
+            PD_PROF(3);
 
             // ---- P4 (wave 0): totals, early exit, quaternion/focal chain, clip, momentum SGD ----
             if (wave == 0) {
@@ -598,6 +669,8 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 if (lane == 0) L.ctl[0] = (done || P.eval_only) ? 1.0f : 0.0f;
             }
             __syncthreads();
+            PD_PROF(4);
+            if (prof) pt[5] += 1;
             if (L.ctl[0] != 0.0f) break;
         }
         if (wave == 0 && lane == 0 && wg == 0 && P.stats) {
@@ -608,6 +681,9 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
             so[3] = last_loss;
         }
         if (P.eval_only) break;
+    }
+    if (prof && lane == 0) {
+        for (int i = 0; i < 6; ++i) P.prof[i] = pt[i];
     }
     if (own && wg == 0 && !P.eval_only) {
 #pragma unroll
@@ -772,12 +848,18 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     int k = cfg->wgs_per_seq > 0 ? cfg->wgs_per_seq : (max_items + PD_GGS_WAVES - 1) / PD_GGS_WAVES;
     k = std::max(1, std::min(k, device_cus / B));
     if ((size_t)max_items * PD_ITEM_VALS > eng->xchg_granules) k = 1;
-    int n_slots = 0;
+    int n_slots = 0, n_inc_lds = 0, max_inc = 0;
+    for (int b = 0; b < B; ++b) max_inc = std::max(max_inc, 2 * eng->seqs[b].desc.n_pairs);
     size_t lds = 0;
     for (;;) {
         const int rounds = (max_items + k * PD_GGS_WAVES - 1) / (k * PD_GGS_WAVES);
         n_slots = rounds * PD_GGS_WAVES;
-        lds = ggs_lds_bytes(n_slots, max_items);
+        n_inc_lds = max_inc;
+        lds = ggs_lds_bytes(n_slots, max_items, n_inc_lds);
+        if (lds > 160 * 1024) {   // incidence table stays in global memory if LDS is short
+            n_inc_lds = 0;
+            lds = ggs_lds_bytes(n_slots, max_items, 0);
+        }
         if (lds <= 160 * 1024 || k >= device_cus / B) break;
         ++k;
     }
@@ -807,11 +889,12 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     P.xchg = (k > 1) ? eng->d_xchg : nullptr;
     P.xchg_stride = (int)eng->xchg_granules;
     P.err_flag = eng->d_err;
+    P.prof = eng->ggs_prof_on ? (long long *)(eng->d_err + 2) : nullptr;
     if (k > 1) {
         // tags restart at 1 every launch: zero every polled word first (guide G16 "re-initialise")
         PD_HIP_CHECK(hipMemsetAsync(eng->d_xchg, 0, sizeof(u64) * 2 * eng->xchg_granules * B, s));
     }
-    hipLaunchKernelGGL(pd_ggs_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots);
+    hipLaunchKernelGGL(pd_ggs_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots, n_inc_lds);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }

@@ -65,6 +65,7 @@ struct PdGgsParams {
     unsigned long long *xchg;  // [B, 2, max_items * 12] tagged granules (k > 1)
     int xchg_stride;           // granules per (sequence, slot)
     unsigned int *err_flag;    // device word: nonzero = a bounded spin gave up
+    long long *prof;           // [6] optional phase cycle counters (debug), else null
 };
 
 struct PdSeqHost {
@@ -88,7 +89,8 @@ struct pd_engine {
     PdSeqDesc *d_seqs = nullptr;         // [max_B] device copy of the descriptors
     unsigned long long *d_xchg = nullptr;
     size_t xchg_granules = 0;            // per (sequence, slot)
-    unsigned int *d_err = nullptr;
+    unsigned int *d_err = nullptr;       // [0] async error word; [2..] debug phase counters
+    int ggs_prof_on = 0;
     float *d_stats_scratch = nullptr;
     // sampler buffers (fixed addresses so a captured graph can be replayed)
     float *d_z = nullptr, *d_noise = nullptr, *d_process = nullptr, *d_mean = nullptr, *d_stats = nullptr;

@@ -157,6 +157,7 @@ class PoseEngine:
         if kp1.ndim != 2 or kp1.shape[1] != 2 or kp1.shape != kp2.shape or i12.shape != kp1.shape:
             raise ValueError("kp1/kp2/i12 must all be [M, 2]")
         n, _, h, w = (int(v) for v in img_shape)
+        self.__dict__.setdefault("_match_ids", {}).pop(int(seq), None)   # host.upload_matches' identity cache
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pd_ggs_set_matches(self._h, int(seq), kp1.ctypes.data, kp2.ctypes.data, i12.ctypes.data,
                                                    kp1.shape[0], n, h, w), "pd_ggs_set_matches")
@@ -230,3 +231,11 @@ class PoseEngine:
         _lib.check(self.lib.pd_time_kernel(self._h, int(what), B, N, C.byref(c), int(reps), C.byref(ms), self._stream()),
                    "pd_time_kernel")
         return float(ms.value)
+
+    def ggs_prof(self, enable: bool = True):
+        """Debug: enable the GGS phase counters / read them -> dict of cycles per iteration."""
+        buf = (C.c_longlong * 6)()
+        _lib.check(self.lib.pd_debug_ggs_prof(self._h, int(enable), buf), "pd_debug_ggs_prof")
+        v = list(buf)
+        it = max(v[5], 1)
+        return {"P1": v[0] / it, "P2": v[1] / it, "xchg": v[2] / it, "P3": v[3] / it, "P4": v[4] / it, "iters": v[5]}

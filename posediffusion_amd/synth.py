@@ -98,12 +98,14 @@ def make_cameras(N: int, seed: int = 2000, f_ndc: float = 3.0) -> np.ndarray:
     return enc
 
 
-def project(enc: np.ndarray, X: np.ndarray, H: int, W: int) -> Tuple[np.ndarray, np.ndarray]:
+def project(enc: np.ndarray, X: np.ndarray, H: int, W: int, f=None) -> Tuple[np.ndarray, np.ndarray]:
     """PyTorch3D NDC projection of world points X [P,3] into every camera: X_cam = X R + T,
     x_ndc = f X/Z, u = W/2 - x_ndc s, v = H/2 - y_ndc s (s = min(H,W)/2).  -> (uv [N,P,2], z [N,P])."""
     R = _quat_to_R(enc[:, 3:7])
     T = enc[:, 0:3]
-    f = np.clip(np.exp(enc[:, 7:9] + 1.8), 0.1, 20.0).mean(0, keepdims=True).repeat(len(enc), 0)
+    if f is None:   # GGS uses the mean focal of ALL cameras of the sequence (geometry_guided_sampling.py:142)
+        f = np.clip(np.exp(enc[:, 7:9] + 1.8), 0.1, 20.0).mean(0)
+    f = np.broadcast_to(np.asarray(f, dtype=np.float64), (len(enc), 2))
     Xc = np.einsum("pk,nkc->npc", X, R) + T[:, None, :]
     s = min(H, W) / 2.0
     u = W / 2.0 - f[:, None, 0] * Xc[..., 0] / Xc[..., 2] * s
@@ -120,12 +122,13 @@ def make_matches(enc: np.ndarray, H: int = 224, W: int = 224, per_pair: int = 30
     N = len(enc)
     kp1, kp2, i12 = [], [], []
     pairs = [(i, j) for i in range(N) for j in range(N) if (i < j or (ordered_pairs and i != j))]
+    fbar = np.clip(np.exp(enc[:, 7:9] + 1.8), 0.1, 20.0).mean(0)
     for (i, j) in pairs:
         got1, got2 = [], []
         need = per_pair
         while need > 0:
             X = rng.uniform(-1.0, 1.0, (4 * need + 16, 3))
-            uv, z = project(enc[[i, j]], X, H, W)
+            uv, z = project(enc[[i, j]], X, H, W, fbar)
             ok = (z > 0.5).all(0) & (uv[..., 0] >= 0).all(0) & (uv[..., 0] < W).all(0) & (uv[..., 1] >= 0).all(0) & \
                  (uv[..., 1] < H).all(0)
             sel = np.nonzero(ok)[0][:need]
@@ -154,3 +157,68 @@ def perturb_pose(enc: np.ndarray, seed: int = 7, sigma_T: float = 0.05, sigma_q:
     e[:, 3:7] += rng.normal(0, sigma_q, (len(e), 4))
     e[:, 7:9] += rng.normal(0, sigma_f, (len(e), 2))
     return torch.from_numpy(e[None].astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# pairwise-consistent matches for ARBITRARY cameras (bench: cameras = the engine's own model mean)
+# ------------------------------------------------------------------------------------------------
+def fundamental_matrices_np(enc: np.ndarray, H: int, W: int) -> np.ndarray:
+    """Fo[i, j] (x_j^T Fo x_i = 0) for every ordered frame pair, in fp64, with the conventions of
+    get_fundamental_matrix.py:38-51 + opencv_from_cameras_projection and the mean focal of
+    geometry_guided_sampling.py:142."""
+    N = len(enc)
+    R = _quat_to_R(enc[:, 3:7])
+    D = np.array([-1.0, -1.0, 1.0])
+    Rc = D[None, :, None] * R.transpose(0, 2, 1)
+    tc = D[None] * enc[:, 0:3]
+    f = np.clip(np.exp(enc[:, 7:9] + 1.8), 0.1, 20.0).mean(0)
+    s = min(H, W) / 2.0
+    K = np.array([[f[0] * s, 0, W / 2.0], [0, f[1] * s, H / 2.0], [0, 0, 1.0]])
+    A = np.linalg.inv(K)
+    F = np.zeros((N, N, 3, 3))
+    for i in range(N):
+        for j in range(N):
+            R12 = Rc[j] @ Rc[i].T
+            t12 = tc[j] - R12 @ tc[i]
+            Et = -R12.T @ t12
+            Hm = np.array([[0, -Et[2], Et[1]], [Et[2], 0, -Et[0]], [-Et[1], Et[0], 0]])
+            F[i, j] = A.T @ (R12 @ Hm) @ A
+    return F
+
+
+def make_epipolar_matches(enc: np.ndarray, H: int = 224, W: int = 224, per_pair: int = 300, noise_px: float = 0.5,
+                          outlier_frac: float = 0.1, seed: int = 2000) -> Dict:
+    """Matches for all C(N,2) pairs that satisfy the epipolar constraint of the given cameras pair by
+    pair: x1 uniform in image i; x2 on its epipolar line in image j, within +-W/2 of the point of the
+    line closest to the image centre (so x2 is inside the image whenever the line crosses it, and
+    may fall outside for the wild cameras a random-weight denoiser produces -- the constraint, and
+    therefore the GGS workload, is the same).  Plus N(0, noise_px) pixel noise and uniform outliers;
+    grouped by pair like hloc's output."""
+    rng = np.random.default_rng(seed)
+    N = len(enc)
+    F = fundamental_matrices_np(np.asarray(enc, dtype=np.float64), H, W)
+    kp1, kp2, i12 = [], [], []
+    ctr = np.array([W / 2.0, H / 2.0])
+    for i in range(N):
+        for j in range(i + 1, N):
+            n = per_pair
+            x1 = np.stack([rng.uniform(0, W, n), rng.uniform(0, H, n), np.ones(n)], 1)
+            l = x1 @ F[i, j].T                       # line in image j: l . x2 = 0
+            nrm = np.sqrt(l[:, 0] ** 2 + l[:, 1] ** 2)
+            nrm = np.where(nrm > 0, nrm, 1.0)
+            a, b, c = l[:, 0] / nrm, l[:, 1] / nrm, l[:, 2] / nrm
+            dist = a * ctr[0] + b * ctr[1] + c
+            p0 = ctr[None] - dist[:, None] * np.stack([a, b], 1)
+            sft = rng.uniform(-W / 2.0, W / 2.0, n)
+            a2 = p0 + sft[:, None] * np.stack([-b, a], 1)
+            a1 = x1[:, :2] + rng.normal(0, noise_px, (n, 2))
+            a2 = a2 + rng.normal(0, noise_px, (n, 2))
+            n_out = int(round(outlier_frac * per_pair))
+            if n_out:
+                idx = rng.choice(per_pair, n_out, replace=False)
+                a2[idx] = rng.uniform(0, [W, H], (n_out, 2))
+            kp1.append(a1)
+            kp2.append(a2)
+            i12.append(np.repeat(np.array([[i, j]], dtype=np.int64), per_pair, 0))
+    return {"kp1": np.concatenate(kp1).astype(np.float64), "kp2": np.concatenate(kp2).astype(np.float64),
+            "i12": np.concatenate(i12).astype(np.int64), "img_shape": torch.Size((N, 3, H, W))}

@@ -1,0 +1,141 @@
+"""CPU: host logic, the drop-in interface contract, and the C-ABI surface (no compute calls)."""
+import ctypes
+import functools
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pd_oracle as O
+from posediffusion_amd import _lib, host, schedule, shard, synth
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    assert os.path.isfile(_lib.LIB_PATH), "run `python -c 'import __graft_entry__ as g; g.build()'` first"
+    header = open(_lib.HEADER_PATH).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(pd_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.pd_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.pd_version()
+
+
+def test_struct_layouts_match_header():
+    # 10 int32 + 6 pointers + 16 layers x 12 pointers + 11 pointers
+    assert ctypes.sizeof(_lib.pd_layer_weights) == 12 * 8
+    assert ctypes.sizeof(_lib.pd_weights) == 10 * 4 + 6 * 8 + 16 * 12 * 8 + 11 * 8
+    assert ctypes.sizeof(_lib.pd_ggs_cfg) == 32
+
+
+def test_engine_fails_loudly_without_gpu(seeded_diffuser):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="GPU"):
+        host.get_engine(seeded_diffuser.model, seeded_diffuser, 1, 20)
+    x, z = torch.zeros(1, 5, 9), torch.zeros(1, 5, 384)
+    with pytest.raises(RuntimeError, match="no CPU fallback|GPU"):
+        seeded_diffuser.model(x, torch.zeros(1, dtype=torch.long), z)
+    with pytest.raises(RuntimeError):
+        seeded_diffuser.sample([1, 5, 9], z)
+
+
+def test_schedule_buffers_equal_oracle_and_names(seeded_diffuser):
+    t = O.diffusion_tables()
+    b = schedule.diffusion_buffers()
+    assert tuple(b) == O.TABLE_NAMES == schedule.BUFFER_NAMES
+    for n in O.TABLE_NAMES:
+        assert torch.equal(b[n], t[n]) and torch.equal(getattr(seeded_diffuser, n), t[n])
+    with pytest.raises(ValueError):
+        schedule.make_betas("nope", 100, 1e-4, 0.1)
+
+
+def test_state_dict_key_contract(seeded_diffuser):
+    """Checkpoint keys of the reference (SURVEY.md section 5 'Checkpoint'): strict load must work."""
+    class Wrapper(torch.nn.Module):
+        def __init__(s, d):
+            super().__init__()
+            s.diffuser = d
+    keys = set(Wrapper(seeded_diffuser).state_dict().keys())
+    must = {"diffuser.betas", "diffuser.posterior_log_variance_clipped", "diffuser.p2_loss_weight",
+            "diffuser.model.time_embed.linear.0.weight", "diffuser.model.time_embed.linear.2.bias",
+            "diffuser.model._first.weight", "diffuser.model._trunk.layers.7.self_attn.in_proj_weight",
+            "diffuser.model._trunk.layers.0.self_attn.out_proj.bias", "diffuser.model._trunk.layers.3.linear2.weight",
+            "diffuser.model._trunk.layers.3.norm2.bias", "diffuser.model._last.0.weight", "diffuser.model._last.1.bias",
+            "diffuser.model._last.3.weight"}
+    assert must <= keys
+    assert sum(p.numel() for p in seeded_diffuser.model.parameters()) == 17_298_697
+    # a checkpoint from an older pytorch3d carries the harmonic frequencies: tolerated, still strict
+    sd = seeded_diffuser.model.state_dict()
+    sd["pose_embed._emb_pose._frequencies"] = torch.zeros(10)
+    seeded_diffuser.model.load_state_dict(sd, strict=True)
+
+
+def test_dropin_registry_and_error_conventions():
+    models = synth._dropin()
+    for name in ("PoseDiffusionModel", "Denoiser", "TransformerEncoderWrapper", "GaussianDiffusion",
+                 "MultiScaleImageFeatureExtractor"):
+        assert hasattr(models, name)
+    from util.camera_transform import pose_encoding_to_camera
+    with pytest.raises(ValueError, match="Unknown pose encoding"):
+        pose_encoding_to_camera(torch.zeros(1, 2, 9), pose_encoding_type="nope")
+    d = models.GaussianDiffusion()
+    with pytest.raises(NotImplementedError):
+        d.p_mean_variance(torch.zeros(1, 2, 9), torch.zeros(1, dtype=torch.long), torch.zeros(1, 2, 384), clip_denoised=True)
+    with pytest.raises(NotImplementedError):
+        d.forward(torch.zeros(1, 2, 9))
+    from posediffusion_amd.compat import instantiate, AttrDict
+    cfg = {"_target_": "models.GaussianDiffusion", "beta_schedule": "custom"}
+    assert isinstance(instantiate(AttrDict(cfg), _recursive_=False), models.GaussianDiffusion)
+
+
+def test_cond_fn_recognition():
+    from util.geometry_guided_sampling import geometry_guided_sampling
+    md, cfg = {"kp1": np.zeros((1, 2))}, {"iter_num": 3}
+    p = functools.partial(geometry_guided_sampling, matches_dict=md, GGS_cfg=cfg)
+    got = host.parse_ggs_cond_fn(p)
+    assert got is not None and got[0] is md and got[1] == cfg
+    assert host.parse_ggs_cond_fn(lambda m, t: m) is None
+    assert host.parse_ggs_cond_fn(functools.partial(geometry_guided_sampling, matches_dict=md)) is None
+
+
+def test_noise_draw_order_matches_reference_protocol():
+    T, shape = 100, (2, 5, 9)
+    for has_cond, start in [(False, 0), (True, 10)]:
+        a = host.draw_noise(shape, T, "cpu", start, has_cond, generator=torch.Generator().manual_seed(7))
+        init, noises = O.draw_reference_noise(shape, torch.Generator().manual_seed(7), T, start, has_cond)
+        assert torch.equal(a[0], init)
+        for step in range(T):
+            t = T - 1 - step
+            if noises[t] is None:
+                assert (a[step + 1] == 0).all()
+            else:
+                assert torch.equal(a[step + 1], noises[t])
+
+
+def test_partition_covers_everything():
+    for n in (1, 7, 8, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [shard.partition(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_synthetic_matches_are_consistent():
+    enc = synth.make_cameras(6, seed=3)
+    md = synth.make_matches(enc, 224, 224, per_pair=50, outlier_frac=0.0, noise_px=0.0, seed=3)
+    assert md["kp1"].dtype == np.float64 and md["i12"].dtype == np.int64 and md["kp1"].shape == (15 * 50, 2)
+    pm = O.prepare_matches(md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+    v, _ = O.compute_sampson_distance(torch.from_numpy(enc[None]), pm)      # fp64, exact cameras
+    assert len(v) == 750 and v.max().item() < 1e-16
+    wild = np.random.default_rng(0).normal(0, 20, (6, 9))
+    md2 = synth.make_epipolar_matches(wild, 224, 224, 50, noise_px=0.0, outlier_frac=0.0, seed=1)
+    pm2 = O.prepare_matches(md2["kp1"], md2["kp2"], md2["i12"], md2["img_shape"])
+    v2, _ = O.compute_sampson_distance(torch.from_numpy(wild[None]), pm2)
+    assert len(v2) == 750 and v2.max().item() < 1e-12
