@@ -22,10 +22,11 @@ _DENOISER_PREFIXES = ("time_embed.", "_first.", "_trunk.", "_last.")
 
 
 def _fingerprint(denoiser: torch.nn.Module, diffuser: Optional[torch.nn.Module]):
-    fp = [(p.data_ptr(), p._version, tuple(p.shape)) for p in denoiser.parameters()]
+    fp_den = tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in denoiser.parameters())
+    fp_diff = None
     if diffuser is not None:
-        fp += [(b.data_ptr(), b._version) for n, b in diffuser.named_buffers(recurse=False)]
-    return tuple(fp)
+        fp_diff = tuple((b.data_ptr(), b._version) for n, b in diffuser.named_buffers(recurse=False))
+    return fp_den, fp_diff
 
 
 def denoiser_state(denoiser: torch.nn.Module) -> Dict[str, torch.Tensor]:
@@ -38,13 +39,18 @@ def get_engine(denoiser: torch.nn.Module, diffuser: Optional[torch.nn.Module], B
     if dev.type != "cuda":
         raise RuntimeError("the PoseDiffusion sampling path of posediffusion_amd runs only on an AMD GPU "
                            f"(model is on {dev}); move the model with .to('cuda'). There is no CPU fallback.")
-    fp = _fingerprint(denoiser, diffuser)
+    fp_den, fp_diff = _fingerprint(denoiser, diffuser)
     cache = denoiser.__dict__.setdefault("_pd_engine_cache", {})
     ent = cache.get("e")
-    if ent is not None and ent[0] == fp and ent[1].max_B >= B and ent[1].max_N >= N:
+    # Denoiser.forward alone (diffuser None) never needs the schedule tables: any engine built from
+    # these weights serves it.  With a diffuser the tables must match too.
+    if ent is not None and ent[0][0] == fp_den and (fp_diff is None or ent[0][1] == fp_diff) \
+            and ent[1].max_B >= B and ent[1].max_N >= N:
         return ent[1]
     if ent is not None:
+        B, N = max(B, ent[1].max_B), max(N, ent[1].max_N)     # never shrink capacity on a rebuild
         ent[1].close()
+    fp = (fp_den, fp_diff)
     if diffuser is not None:
         tables = {n: b for n, b in diffuser.named_buffers(recurse=False)}
     else:
