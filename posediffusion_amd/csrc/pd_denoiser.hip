@@ -26,6 +26,7 @@
 #include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DM 512          // d_model
 #define NH 4            // heads
@@ -46,42 +47,61 @@ __host__ __device__ inline int pd_first_col(int kp) {
 }
 #define HID 128         // mlp_hidden_dim
 
-struct PdLayerDev {
-    float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
-    float *qkv_wp, *qkv_b;     // packed [1536/32][512/8][64][4]
-    float *out_wp, *out_b;
-    float *ff1_wp, *ff1_b;
-    float *ff2_wp, *ff2_b;
+struct PdLayerDev {          // [0] = 32-wide-tile packing, [1] = 16-wide-tile packing of the same weights
+    float *qkv_wp[2], *qkv_b;  // LayerNorm-1 gamma folded into the columns, beta into the bias
+    float *out_wp[2], *out_b;
+    float *ff1_wp[2], *ff1_b;  // LayerNorm-2 folded likewise
+    float *ff2_wp[2], *ff2_b;
 };
 
 struct PdDenoiserDev {
     int num_layers = 0, timesteps = 0, m_cap = 0;
     float *t_table = nullptr;          // [T,128] time embeddings
-    float *first_wp = nullptr, *first_b = nullptr;
+    float *first_wp[2] = {nullptr, nullptr}, *first_b = nullptr;
     PdLayerDev layers[PD_MAX_LAYERS];
-    float *last0_wp = nullptr, *last0_b = nullptr, *last_ln_w = nullptr, *last_ln_b = nullptr;
+    float *last0_wp[2] = {nullptr, nullptr}, *last0_b = nullptr, *last_ln_w = nullptr, *last_ln_b = nullptr;
     float *last3_w = nullptr, *last3_b = nullptr;   // [9,128] plain
     float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ff = nullptr, *hid = nullptr;   // activations [m_cap, .]
     std::vector<void *> allocs;
 };
 
 // --------------------------------------------------------------------------------------------
-// weight repack: W[Nout][K] row-major  ->  Wp[nt][kc][lane][4], lane l holds
-// W[nt*32 + (l & 31)][kc*8 + 4*(l >> 5) + 0..3]   (zero padded)
+// weight repack: W[Nout][K] row-major -> MFMA-fragment order (zero padded), optionally with a
+// LayerNorm gamma folded in as a column scale (W' = W diag(gamma): LN(x) W^T = xhat (W diag(gamma))^T + W beta)
+//   NT = 32 (v_mfma_f32_32x32x2_f32):  Wp[nt][kc][lane][4] = W[nt*32 + (l & 31)][kc*8  + 4*(l >> 5) + e]
+//   NT = 16 (v_mfma_f32_16x16x4_f32):  Wp[nt][kc][lane][4] = W[nt*16 + (l & 15)][kc*16 + 4*(l >> 4) + e]
 // --------------------------------------------------------------------------------------------
 __global__ void pd_repack_kernel(const float *__restrict__ W, int Nout, int K, int KC, float *__restrict__ Wp, size_t total,
-                                 int first_perm) {
+                                 int first_perm, int nt_width, const float *__restrict__ colscale) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int e = idx & 3;
         const int l = (idx >> 2) & 63;
         const size_t rest = idx >> 8;
         const int kc = (int)(rest % KC);
         const int nt = (int)(rest / KC);
-        const int n = nt * 32 + (l & 31);
-        int k = kc * 8 + 4 * (l >> 5) + e;
+        int n, k;
+        if (nt_width == 32) {
+            n = nt * 32 + (l & 31);
+            k = kc * 8 + 4 * (l >> 5) + e;
+        } else {
+            n = nt * 16 + (l & 15);
+            k = kc * 16 + 4 * (l >> 4) + e;
+        }
         if (first_perm) k = pd_first_col(k);
-        Wp[idx] = (n < Nout && k < K) ? W[(size_t)n * K + k] : 0.0f;
+        float v = (n < Nout && k < K) ? W[(size_t)n * K + k] : 0.0f;
+        if (colscale && k < K) v *= colscale[k];
+        Wp[idx] = v;
     }
+}
+
+// b'[n] = b[n] + sum_k W[n][k] beta[k]   (the LayerNorm shift folded into the following bias)
+__global__ void pd_fold_bias_kernel(const float *__restrict__ W, const float *__restrict__ beta, const float *__restrict__ b,
+                                    int Nout, int K, float *__restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Nout) return;
+    float a = 0.0f;
+    for (int k = 0; k < K; ++k) a = fmaf(W[(size_t)n * K + k], beta[k], a);
+    out[n] = b[n] + a;
 }
 
 // time-step embedding table (util/embedding.py:28-37): one block per step t
@@ -117,25 +137,37 @@ struct GemmArgs {
     const float *Wp;       // packed weights
     const float *bias;     // [Nout]
     float *C;              // [M, Nout]
-    const float *ln_w, *ln_b;
     // AMODE 2
     const float *x, *z, *temb;   // x [M,9], z [M,384], temb [128] (row of the table for this t)
     int n_frames;
     int M, Nout;
 };
 
-template <int K, int AMODE, int EPI>
+// 8-lane (one activation row) sum on the DPP network: xor-1, xor-2 quad permutes + half-row mirror
+template <int CTRL>
+__device__ __forceinline__ float pd_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float pd_sum8(float v) {
+    v = pd_dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = pd_dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    return pd_dpp_add<0x141>(v);   // row_half_mirror
+}
+
+template <int K, int AMODE, int EPI, int NT>
 __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
     constexpr int LDA = K + 4;            // padded row stride (floats): conflict-free ds_read_b128
-    constexpr int KC = K / 8;             // 8-wide k chunks
+    constexpr int CW = (NT == 32) ? 8 : 16;   // k-chunk width per float4 fragment load
+    constexpr int KC = K / CW;
     constexpr int CPW = KC / 4;           // chunks per wave (split-K over the 4 waves)
     constexpr int NB = (CPW > 16) ? 2 : 1;   // weight batches held in registers
     constexpr int BATCH = CPW / NB;
-    static_assert(CPW % NB == 0, "chunk batching");
+    constexpr int NACC = (NT == 32) ? 16 : 8;
+    static_assert(KC % 4 == 0 && CPW % NB == 0, "chunk batching");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *As = lds;                      // [32][LDA]; later aliased by the cross-wave reduction
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * NT;
     const float4 *wp = (const float4 *)g.Wp + ((size_t)blockIdx.y * KC + (size_t)wave * CPW) * 64 + lane;
 
     // ---- weights first: the whole first batch of this wave's fragments goes in flight before the
@@ -193,6 +225,7 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
                 dst[703] = 0.0f;
             }
         } else if constexpr (AMODE == 1) {
+            // LayerNorm without affine: gamma is folded into the packed weights, beta into the bias
             static_assert(AMODE != 1 || K == 512, "LayerNorm staging is built for d_model = 512");
             float4 v[K / 32];
             const float4 *src = (const float4 *)(g.A + (size_t)mr * K);
@@ -201,29 +234,21 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
             float s = 0.0f;
 #pragma unroll
             for (int i = 0; i < K / 32; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 4, 64);
-            const float mean = s * (1.0f / K);
+            const float mean = pd_sum8(s) * (1.0f / K);
             float q = 0.0f;
 #pragma unroll
             for (int i = 0; i < K / 32; ++i) {
                 const float a = v[i].x - mean, b2 = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
                 q += (a * a + b2 * b2) + (c * c + d * d);
             }
-            q += __shfl_xor(q, 1, 64);
-            q += __shfl_xor(q, 2, 64);
-            q += __shfl_xor(q, 4, 64);
-            const float rstd = live ? 1.0f / sqrtf(q * (1.0f / K) + 1e-5f) : 0.0f;
-            const float4 *gw = (const float4 *)g.ln_w, *gb = (const float4 *)g.ln_b;
+            const float rstd = live ? 1.0f / sqrtf(pd_sum8(q) * (1.0f / K) + 1e-5f) : 0.0f;
 #pragma unroll
             for (int i = 0; i < K / 32; ++i) {
-                const float4 w = gw[sub + 8 * i], bb = gb[sub + 8 * i];
                 float4 o;
-                o.x = (v[i].x - mean) * rstd * w.x + (live ? bb.x : 0.0f);
-                o.y = (v[i].y - mean) * rstd * w.y + (live ? bb.y : 0.0f);
-                o.z = (v[i].z - mean) * rstd * w.z + (live ? bb.z : 0.0f);
-                o.w = (v[i].w - mean) * rstd * w.w + (live ? bb.w : 0.0f);
+                o.x = (v[i].x - mean) * rstd;
+                o.y = (v[i].y - mean) * rstd;
+                o.z = (v[i].z - mean) * rstd;
+                o.w = (v[i].w - mean) * rstd;
                 *(float4 *)(dst + 4 * (sub + 8 * i)) = o;
             }
         } else {
@@ -254,46 +279,68 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
         for (int c = 0; c < BATCH; ++c) w1[c] = wp[(size_t)(BATCH + c) * 64];
         __builtin_amdgcn_sched_barrier(0);   // keep the second batch's loads ahead of the first MFMAs
     }
-    f32x16 acc;
+    float accv[NACC];
+    if constexpr (NT == 32) {
+        f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    const float *arow = As + (lane & 31) * LDA + wave * CPW * 8 + 4 * (lane >> 5);
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        const float *arow = As + (lane & 31) * LDA + wave * CPW * 8 + 4 * (lane >> 5);
 #pragma unroll
-    for (int c = 0; c < BATCH; ++c) {
-        const float4 af = *(const float4 *)(arow + c * 8);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, w0[c].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, w0[c].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, w0[c].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, w0[c].w, acc, 0, 0, 0);
-    }
-    if constexpr (NB == 2) {
+        for (int c = 0; c < CPW; ++c) {
+            const float4 wf = (c < BATCH) ? w0[c < BATCH ? c : 0] : w1[(NB == 2 && c >= BATCH) ? c - BATCH : 0];
+            const float4 af = *(const float4 *)(arow + c * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, wf.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, wf.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, wf.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, wf.w, acc, 0, 0, 0);
+        }
 #pragma unroll
-        for (int c = 0; c < BATCH; ++c) {
-            const float4 af = *(const float4 *)(arow + (BATCH + c) * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, w1[c].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, w1[c].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, w1[c].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, w1[c].w, acc, 0, 0, 0);
+        for (int i = 0; i < 16; ++i) accv[i] = acc[i];
+    } else {
+        // two 16x16 tiles (rows 0-15, 16-31) share each weight fragment; independent accumulators
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float *arow = As + (lane & 15) * LDA + wave * CPW * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const float4 wf = (c < BATCH) ? w0[c < BATCH ? c : 0] : w1[(NB == 2 && c >= BATCH) ? c - BATCH : 0];
+            const float4 a0 = *(const float4 *)(arow + c * 16);
+            const float4 a1 = *(const float4 *)(arow + 16 * LDA + c * 16);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wf.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wf.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wf.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wf.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wf.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wf.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wf.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wf.w, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            accv[i] = acc0[i];
+            accv[4 + i] = acc1[i];
         }
     }
     __syncthreads();   // every wave is done reading As; reuse it for the reduction
 
     // ---- cross-wave reduction in fixed order + fused epilogue ---------------------------------
-    float *red = lds;   // [4][16][64]
+    float *red = lds;   // [4][NACC][64]
 #pragma unroll
-    for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
+    for (int i = 0; i < NACC; ++i) red[(wave * NACC + i) * 64 + lane] = accv[i];
     __syncthreads();
-    const int col = n0 + (lane & 31);
+    constexpr int RPW = NACC / 4;          // accumulator registers finished per wave
+    const int col = n0 + ((NT == 32) ? (lane & 31) : (lane & 15));
     const float bias = g.bias[col];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int reg = wave * 4 + i;
-        float v = red[(0 * 16 + reg) * 64 + lane];
-        v += red[(1 * 16 + reg) * 64 + lane];
-        v += red[(2 * 16 + reg) * 64 + lane];
-        v += red[(3 * 16 + reg) * 64 + lane];
+    for (int i = 0; i < RPW; ++i) {
+        const int reg = wave * RPW + i;
+        float v = red[(0 * NACC + reg) * 64 + lane];
+        v += red[(1 * NACC + reg) * 64 + lane];
+        v += red[(2 * NACC + reg) * 64 + lane];
+        v += red[(3 * NACC + reg) * 64 + lane];
         v += bias;
-        const int row = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        int row;
+        if constexpr (NT == 32) row = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        else row = m0 + 16 * (reg >> 2) + 4 * (lane >> 4) + (reg & 3);
         if (row < g.M) {
             float *cp = g.C + (size_t)row * g.Nout + col;
             if constexpr (EPI == 1) v = fmaxf(v, 0.0f);
@@ -435,16 +482,30 @@ static int dev_copy(PdDenoiserDev *d, float **dst, const float *src, size_t n) {
     PD_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice));
     return PD_OK;
 }
-static int dev_pack(PdDenoiserDev *d, float **dst, const float *W, int Nout, int K, int Kpad, int first_perm = 0) {
+// pack W for tile width nt (32 or 16); gamma (nullable) is folded in as a column scale
+static int dev_pack(PdDenoiserDev *d, float **dst, const float *W, int Nout, int K, int Kpad, int nt, int first_perm = 0,
+                    const float *gamma = nullptr) {
     if (!W) {
         pd_set_error("pd_engine_create: a weight pointer is NULL");
         return PD_ERR_INVALID_ARG;
     }
-    const int NT = (Nout + 31) / 32, KC = Kpad / 8;
+    const int NT = (Nout + nt - 1) / nt, KC = Kpad / (nt == 32 ? 8 : 16);
     const size_t total = (size_t)NT * KC * 256;
     int rc = dev_alloc(d, dst, total);
     if (rc) return rc;
-    hipLaunchKernelGGL(pd_repack_kernel, dim3(512), dim3(256), 0, 0, W, Nout, K, KC, *dst, total, first_perm);
+    hipLaunchKernelGGL(pd_repack_kernel, dim3(512), dim3(256), 0, 0, W, Nout, K, KC, *dst, total, first_perm, nt, gamma);
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}
+// b' = b + W beta
+static int dev_fold_bias(PdDenoiserDev *d, float **dst, const float *W, const float *beta, const float *b, int Nout, int K) {
+    if (!W || !beta || !b) {
+        pd_set_error("pd_engine_create: a weight pointer is NULL");
+        return PD_ERR_INVALID_ARG;
+    }
+    int rc = dev_alloc(d, dst, Nout);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pd_fold_bias_kernel, dim3((Nout + 127) / 128), dim3(128), 0, 0, W, beta, b, Nout, K, *dst);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }
@@ -484,25 +545,33 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
         hipLaunchKernelGGL(pd_time_table_kernel, dim3(w->timesteps), dim3(128), 0, 0, w0, b0, w2, b2, d->t_table);
         PD_HIP_CHECK(hipGetLastError());
     }
-    PD_TRY(dev_pack(d, &d->first_wp, w->first_w, DM, KFIRST, KFIRST_PAD, 1));
+    for (int v = 0; v < 2; ++v) {   // v = 0: 32-wide tiles, v = 1: 16-wide tiles
+        const int nt = v ? 16 : 32;
+        PD_TRY(dev_pack(d, &d->first_wp[v], w->first_w, DM, KFIRST, KFIRST_PAD, nt, 1));
+        PD_TRY(dev_pack(d, &d->last0_wp[v], w->last0_w, HID, DM, DM, nt));
+        for (int l = 0; l < w->num_layers; ++l) {
+            const pd_layer_weights &s = w->layers[l];
+            PdLayerDev &L = d->layers[l];
+            // LayerNorm affine folded: W' = W diag(gamma) (packed), b' = b + W beta
+            PD_TRY(dev_pack(d, &L.qkv_wp[v], s.in_proj_w, 3 * DM, DM, DM, nt, 0, s.norm1_w));
+            PD_TRY(dev_pack(d, &L.out_wp[v], s.out_proj_w, DM, DM, DM, nt));
+            PD_TRY(dev_pack(d, &L.ff1_wp[v], s.linear1_w, DFF, DM, DM, nt, 0, s.norm2_w));
+            PD_TRY(dev_pack(d, &L.ff2_wp[v], s.linear2_w, DM, DFF, DFF, nt));
+        }
+    }
     PD_TRY(dev_copy(d, &d->first_b, w->first_b, DM));
     for (int l = 0; l < w->num_layers; ++l) {
         const pd_layer_weights &s = w->layers[l];
         PdLayerDev &L = d->layers[l];
-        PD_TRY(dev_copy(d, &L.ln1_w, s.norm1_w, DM));
-        PD_TRY(dev_copy(d, &L.ln1_b, s.norm1_b, DM));
-        PD_TRY(dev_copy(d, &L.ln2_w, s.norm2_w, DM));
-        PD_TRY(dev_copy(d, &L.ln2_b, s.norm2_b, DM));
-        PD_TRY(dev_pack(d, &L.qkv_wp, s.in_proj_w, 3 * DM, DM, DM));
-        PD_TRY(dev_copy(d, &L.qkv_b, s.in_proj_b, 3 * DM));
-        PD_TRY(dev_pack(d, &L.out_wp, s.out_proj_w, DM, DM, DM));
+        if (!s.norm1_w || !s.norm2_w) {
+            pd_set_error("pd_engine_create: a LayerNorm weight pointer is NULL");
+            return PD_ERR_INVALID_ARG;
+        }
+        PD_TRY(dev_fold_bias(d, &L.qkv_b, s.in_proj_w, s.norm1_b, s.in_proj_b, 3 * DM, DM));
         PD_TRY(dev_copy(d, &L.out_b, s.out_proj_b, DM));
-        PD_TRY(dev_pack(d, &L.ff1_wp, s.linear1_w, DFF, DM, DM));
-        PD_TRY(dev_copy(d, &L.ff1_b, s.linear1_b, DFF));
-        PD_TRY(dev_pack(d, &L.ff2_wp, s.linear2_w, DM, DFF, DFF));
+        PD_TRY(dev_fold_bias(d, &L.ff1_b, s.linear1_w, s.norm2_b, s.linear1_b, DFF, DM));
         PD_TRY(dev_copy(d, &L.ff2_b, s.linear2_b, DM));
     }
-    PD_TRY(dev_pack(d, &d->last0_wp, w->last0_w, HID, DM, DM));
     PD_TRY(dev_copy(d, &d->last0_b, w->last0_b, HID));
     PD_TRY(dev_copy(d, &d->last_ln_w, w->last_ln_w, HID));
     PD_TRY(dev_copy(d, &d->last_ln_b, w->last_ln_b, HID));
@@ -513,12 +582,18 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(dev_alloc(d, &d->ctx, (size_t)d->m_cap * DM));
     PD_TRY(dev_alloc(d, &d->ff, (size_t)d->m_cap * DFF));
     PD_TRY(dev_alloc(d, &d->hid, (size_t)d->m_cap * HID));
-    PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0>, 32 * (KFIRST_PAD + 4) * 4));
-    PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 0>, 32 * (DM + 4) * 4));
-    PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 1>, 32 * (DM + 4) * 4));
-    PD_TRY(set_lds(pd_gemm_kernel<DM, 0, 2>, 32 * (DM + 4) * 4));
-    PD_TRY(set_lds(pd_gemm_kernel<DFF, 0, 2>, 32 * (DFF + 4) * 4));
-    PD_TRY(set_lds(pd_gemm_kernel<DM, 0, 0>, 32 * (DM + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0, 32>, 32 * (KFIRST_PAD + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0, 16>, 32 * (KFIRST_PAD + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 0, 32>, 32 * (DM + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 0, 16>, 32 * (DM + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 1, 32>, 32 * (DM + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 1, 16>, 32 * (DM + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<DM, 0, 2, 32>, 32 * (DM + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<DM, 0, 2, 16>, 32 * (DM + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<DFF, 0, 2, 32>, 32 * (DFF + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<DFF, 0, 2, 16>, 32 * (DFF + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<DM, 0, 0, 32>, 32 * (DM + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<DM, 0, 0, 16>, 32 * (DM + 4) * 4));
     PD_TRY(set_lds(pd_attn_kernel, ((2 * 64 + 4) * (DH + 4) + 4 * 64) * 4));
     PD_HIP_CHECK(hipDeviceSynchronize());
     return PD_OK;
@@ -529,6 +604,20 @@ void pd_denoiser_destroy(pd_engine *eng) {
     for (void *p : eng->den->allocs) (void)hipFree(p);
     delete eng->den;
     eng->den = nullptr;
+}
+
+// one GEMM launch; the tile width is chosen per problem: 16-wide tiles double the workgroup count (and
+// halve each wave's serial MFMA chain) whenever 32-wide tiles would leave most of the 256 CUs idle
+template <int K, int AMODE, int EPI>
+static void launch_gemm(GemmArgs &g, float *const wp[2], int MT, hipStream_t s) {
+    const int tiles32 = MT * (g.Nout / 32);
+    if (tiles32 >= 200) {
+        g.Wp = wp[0];
+        hipLaunchKernelGGL((pd_gemm_kernel<K, AMODE, EPI, 32>), dim3(MT, g.Nout / 32), dim3(256), 32 * (K + 4) * 4, s, g);
+    } else {
+        g.Wp = wp[1];
+        hipLaunchKernelGGL((pd_gemm_kernel<K, AMODE, EPI, 16>), dim3(MT, g.Nout / 16), dim3(256), 32 * (K + 4) * 4, s, g);
+    }
 }
 
 int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, int B, int N, float *eps_out,
@@ -544,26 +633,26 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     memset(&g, 0, sizeof(g));
     g.M = M;
     // _first with the embedding fused into the A staging
-    g.Wp = d->first_wp; g.bias = d->first_b; g.C = d->h; g.Nout = DM;
+    g.bias = d->first_b; g.C = d->h; g.Nout = DM;
     g.x = x; g.z = z; g.temb = d->t_table + (size_t)t * 128; g.n_frames = N;
-    hipLaunchKernelGGL((pd_gemm_kernel<KFIRST_PAD, 2, 0>), dim3(MT, DM / 32), dim3(256), 32 * (KFIRST_PAD + 4) * 4, s, g);
+    launch_gemm<KFIRST_PAD, 2, 0>(g, d->first_wp, MT, s);
     for (int l = 0; l < d->num_layers; ++l) {
         const PdLayerDev &L = d->layers[l];
         // x += MHA(LN1(x))
-        g.A = d->h; g.Wp = L.qkv_wp; g.bias = L.qkv_b; g.C = d->qkv; g.Nout = 3 * DM; g.ln_w = L.ln1_w; g.ln_b = L.ln1_b;
-        hipLaunchKernelGGL((pd_gemm_kernel<DM, 1, 0>), dim3(MT, 3 * DM / 32), dim3(256), 32 * (DM + 4) * 4, s, g);
+        g.A = d->h; g.bias = L.qkv_b; g.C = d->qkv; g.Nout = 3 * DM;
+        launch_gemm<DM, 1, 0>(g, L.qkv_wp, MT, s);
         hipLaunchKernelGGL(pd_attn_kernel, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
-        g.A = d->ctx; g.Wp = L.out_wp; g.bias = L.out_b; g.C = d->h; g.Nout = DM;
-        hipLaunchKernelGGL((pd_gemm_kernel<DM, 0, 2>), dim3(MT, DM / 32), dim3(256), 32 * (DM + 4) * 4, s, g);
+        g.A = d->ctx; g.bias = L.out_b; g.C = d->h; g.Nout = DM;
+        launch_gemm<DM, 0, 2>(g, L.out_wp, MT, s);
         // x += W2 relu(W1 LN2(x))
-        g.A = d->h; g.Wp = L.ff1_wp; g.bias = L.ff1_b; g.C = d->ff; g.Nout = DFF; g.ln_w = L.ln2_w; g.ln_b = L.ln2_b;
-        hipLaunchKernelGGL((pd_gemm_kernel<DM, 1, 1>), dim3(MT, DFF / 32), dim3(256), 32 * (DM + 4) * 4, s, g);
-        g.A = d->ff; g.Wp = L.ff2_wp; g.bias = L.ff2_b; g.C = d->h; g.Nout = DM;
-        hipLaunchKernelGGL((pd_gemm_kernel<DFF, 0, 2>), dim3(MT, DM / 32), dim3(256), 32 * (DFF + 4) * 4, s, g);
+        g.A = d->h; g.bias = L.ff1_b; g.C = d->ff; g.Nout = DFF;
+        launch_gemm<DM, 1, 1>(g, L.ff1_wp, MT, s);
+        g.A = d->ff; g.bias = L.ff2_b; g.C = d->h; g.Nout = DM;
+        launch_gemm<DFF, 0, 2>(g, L.ff2_wp, MT, s);
     }
-    // _last.0 as a plain tile GEMM (4 N-tiles), then the fused LN/ReLU/Linear(128->9)/DDPM tail
-    g.A = d->h; g.Wp = d->last0_wp; g.bias = d->last0_b; g.C = d->hid; g.Nout = HID;
-    hipLaunchKernelGGL((pd_gemm_kernel<DM, 0, 0>), dim3(MT, HID / 32), dim3(256), 32 * (DM + 4) * 4, s, g);
+    // _last.0 as a plain tile GEMM, then the fused LN/ReLU/Linear(128->9)/DDPM tail
+    g.A = d->h; g.bias = d->last0_b; g.C = d->hid; g.Nout = HID;
+    launch_gemm<DM, 0, 0>(g, d->last0_wp, MT, s);
     HeadArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.hid = d->hid; ha.lnw = d->last_ln_w; ha.lnb = d->last_ln_b;

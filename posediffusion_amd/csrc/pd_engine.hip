@@ -111,7 +111,7 @@ extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_en
         const size_t bn9 = (size_t)max_B * max_N * 9;
         // all-pairs upper bound on work items for the exchange buffer: N*(N-1) ordered pairs, 1 item each,
         // plus slack for pairs split into several items
-        eng->xchg_granules = (size_t)(max_N * max_N + 256) * PD_ITEM_VALS;
+        eng->xchg_granules = (size_t)(max_N * max_N + 256) * 16;   // one 128-byte line (16 granules) per item
 #define PD_ALLOC(ptr, bytes)                                             \
     if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) {             \
         pd_set_error("pd_engine_create: hipMalloc of %zu B failed", (size_t)(bytes)); \

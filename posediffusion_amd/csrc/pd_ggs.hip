@@ -33,6 +33,8 @@
 #include <string.h>
 
 typedef unsigned long long u64;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define PD_XCHG_LINE 16   // granules per item record in the exchange buffer (one 128-byte line)
 
 // --------------------------------------------------------------------------------------------
 // device helpers
@@ -55,6 +57,11 @@ __device__ __forceinline__ float wave_allsum(float v) {
     v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 -> rows 2, 3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+
+// 1-ulp hardware reciprocal / sqrt for scale factors on the serial per-iteration chain (the Sampson
+// value itself keeps IEEE division: it is compared against the hard sampson_max threshold)
+__device__ __forceinline__ float pd_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float pd_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 struct Cam {   // shared intrinsics of the step: A = K^-1 = [[a0,0,c0],[0,a1,c1],[0,0,1]]
     float a0, a1, c0, c1;
@@ -107,7 +114,7 @@ __device__ __forceinline__ void fundamental_from_E(const float *E, const Cam &c,
 }
 
 // LDS carve (floats).  Everything lives in the one dynamic region (guide G17).
-#define PD_GGS_LDS_FIXED (64 * 9 + 64 * 3 + 64 * 2 + 64 * 2 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8)
+#define PD_GGS_LDS_FIXED (64 * 9 + 64 * 3 + 64 * 2 + 64 * 2 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8 + PD_GGS_THREADS * 16 + 64 * 16)
 struct Lds {
     float *Rc;     // [64*9]  R_cv per frame  (opencv_from_cameras_projection)
     float *tc;     // [64*3]
@@ -118,6 +125,8 @@ struct Lds {
     float *gR;     // [64*9]  per-frame dL/dR  (PyTorch3D R, un-normalised)
     float *gA;     // [64*4]  per-frame partial dL/dA {00,02,11,12}
     float *ctl;    // [8]     ctl[0] = stage done flag, ctl[1] = abort
+    float *pinc;   // [512*16] per-incidence backward results of the current chunk (16-byte aligned)
+    float *psum;   // [64*16]  per-frame partial sums across chunks (N > 32 only)
     int4 *itab;    // [n_slots] (first match, count, i, j) of the local items
     int4 *inc;     // [n_inc] incidence entries (only when they fit; else read from global)
     int *incoff;   // [68] incidence CSR offsets per frame
@@ -136,7 +145,9 @@ __device__ __forceinline__ Lds carve(float *base, int n_slots, int n_inc_lds) {
     L.gR = L.gT + 64 * 3;
     L.gA = L.gR + 64 * 9;
     L.ctl = L.gA + 64 * 4;
-    L.itab = (int4 *)(L.ctl + 8);
+    L.pinc = L.ctl + 8;
+    L.psum = L.pinc + PD_GGS_THREADS * 16;
+    L.itab = (int4 *)(L.psum + 64 * 16);
     L.inc = L.itab + n_slots;
     L.incoff = (int *)(L.inc + n_inc_lds);
     L.F = (float *)(L.incoff + 68);
@@ -154,7 +165,7 @@ static size_t ggs_lds_bytes(int n_slots, int n_items, int n_inc_lds) {
 __device__ __forceinline__ void decode_frame(const float *x, float *Rc, float *tc, float &flx, float &fly,
                                              float &px, float &py) {
     const float r = x[3], i = x[4], j = x[5], k = x[6];
-    const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+    const float two_s = 2.0f * pd_rcp(r * r + i * i + j * j + k * k);
     float R[9];
     R[0] = 1.0f - two_s * (j * j + k * k);
     R[1] = two_s * (i * j - k * r);
@@ -173,7 +184,7 @@ __device__ __forceinline__ void decode_frame(const float *x, float *Rc, float *t
     tc[0] = -x[0];
     tc[1] = -x[1];
     tc[2] = x[2];
-    const float fx = expf(x[7] + 1.8f), fy = expf(x[8] + 1.8f);
+    const float fx = __expf(x[7] + 1.8f), fy = __expf(x[8] + 1.8f);
     px = (fx >= 0.1f && fx <= 20.0f) ? 1.0f : 0.0f;   // torch.clamp backward passes min <= v <= max
     py = (fy >= 0.1f && fy <= 20.0f) ? 1.0f : 0.0f;
     flx = fminf(fmaxf(fx, 0.1f), 20.0f);
@@ -191,9 +202,10 @@ __device__ __forceinline__ void decode_all(const Lds &L, const float *xr, int la
         L.flp[lane * 2 + 1] = py;
     }
     // focal_length.mean(dim=0) over all cameras (geometry_guided_sampling.py:142)
-    const float fbx = wave_allsum(flx) / (float)N, fby = wave_allsum(fly) / (float)N;
+    const float rN = pd_rcp((float)N);
+    const float fbx = wave_allsum(flx) * rN, fby = wave_allsum(fly) * rN;
     if (lane == 0) {
-        const float a0 = 1.0f / (fbx * D.sc), a1 = 1.0f / (fby * D.sc);
+        const float a0 = pd_rcp(fbx * D.sc), a1 = pd_rcp(fby * D.sc);
         L.cam[0] = a0;
         L.cam[1] = a1;
         L.cam[2] = -D.cx * a0;
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         const float sam = (ee * ee) / bottom;                             // :162-164
                         acc[11] += in ? fminf(sam, P.sampson_max) : 0.0f;                 // :169
                         const bool valid = in && (sam < P.sampson_max);                   // :170
-                        const float inv = 1.0f / bottom;
+                        const float inv = pd_rcp(bottom);
                         const float ca = valid ? 2.0f * ee * inv : 0.0f;
                         const float cb = valid ? 2.0f * sam * inv : 0.0f;
                         acc[9] += valid ? sam : 0.0f;
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
 #pragma unroll
                     for (int c = 1; c < PD_ITEM_VALS; ++c) v = (lane == c) ? acc[c] : v;
                     if (lane < PD_ITEM_VALS) {
-                        u64 *g = xchg + (size_t)(epoch & 1) * P.xchg_stride + (size_t)item * PD_ITEM_VALS + lane;
+                        u64 *g = xchg + (size_t)(epoch & 1) * P.xchg_stride + (size_t)item * PD_XCHG_LINE + lane;
                         __hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -386,18 +398,30 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 // all-gather of every item's 12 sums: the data IS the flag (tag == epoch)
                 const u64 *slot = xchg + (size_t)(epoch & 1) * P.xchg_stride;
                 bool fail = false;
-                const int n_gran = n_items * PD_ITEM_VALS;
-                for (int g0 = tid; g0 < n_gran; g0 += 8 * PD_GGS_THREADS) {
-                    u64 v[8];
+                // each item is one 128-byte line of 16 granules (12 used); a thread fetches 16-byte pieces
+                // (2 granules) with write-through-coherent (sc1) loads, up to 3 pieces in flight per pass
+                const int n_piece = n_items * 6;
+                for (int p0 = tid; p0 < n_piece; p0 += 3 * PD_GGS_THREADS) {
+                    const u64 *a[3];
+                    int pi_[3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int pc = p0 + u * PD_GGS_THREADS;
+                        pi_[u] = pc < n_piece ? pc : p0;
+                        a[u] = slot + (size_t)(pi_[u] / 6) * PD_XCHG_LINE + (pi_[u] % 6) * 2;
+                    }
+                    u32x4 v0, v1, v2;
                     unsigned spins = 0;
                     for (;;) {
-                        bool ok = true;
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {   // 8 independent polls in flight per pass
-                            const int g = g0 + u * PD_GGS_THREADS;
-                            v[u] = __hip_atomic_load(slot + (g < n_gran ? g : g0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok = ok && ((unsigned)(v[u] >> 32) == epoch);
-                        }
+                        asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
+                                     "global_load_dwordx4 %1, %4, off sc1\n\t"
+                                     "global_load_dwordx4 %2, %5, off sc1\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(v0), "=&v"(v1), "=&v"(v2)
+                                     : "v"(a[0]), "v"(a[1]), "v"(a[2])
+                                     : "memory");
+                        const bool ok = v0[1] == epoch && v0[3] == epoch && v1[1] == epoch && v1[3] == epoch &&
+                                        v2[1] == epoch && v2[3] == epoch;
                         if (ok) break;
                         if (++spins > (1u << 20) ||
                             ((spins & 255u) == 0 &&
@@ -407,10 +431,14 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         }
                         __builtin_amdgcn_s_sleep(1);
                     }
+                    const u32x4 vv[3] = {v0, v1, v2};
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int g = g0 + u * PD_GGS_THREADS;
-                        if (g < n_gran) L.item[g] = __uint_as_float((unsigned)v[u]);
+                    for (int u = 0; u < 3; ++u) {
+                        if (p0 + u * PD_GGS_THREADS < n_piece) {
+                            const int g = (pi_[u] / 6) * PD_ITEM_VALS + (pi_[u] % 6) * 2;
+                            L.item[g] = __uint_as_float(vv[u][0]);
+                            L.item[g + 1] = __uint_as_float(vv[u][2]);
+                        }
                     }
                 }
                 if (fail) {
@@ -422,16 +450,40 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
             if (L.ctl[1] != 0.0f) return;   // a bounded spin gave up: abort the whole workgroup
             PD_PROF(2);
 
-            // ---- P3: per-frame backward, one frame per wave, one incident pair per lane ------
-            for (int n = wave; n < N; n += PD_GGS_WAVES) {
-                const int e0 = L.incoff[n], deg = L.incoff[n + 1] - e0;
+            // ---- P3a: pair backward, one (frame, incident pair) per thread, flat over the workgroup ----
+            // chunks of PD_GGS_THREADS incidences (one chunk at N = 20); results go to LDS [chunk][16]:
+            // 9 dL/dRc_side + 3 dL/dtc_side + 4 dL/dA partials, then P3b sums them per frame in fixed order
+            const int n_inc = L.incoff[N];
+            const bool need_rt = S.update_R || S.update_T;
+            float fsum = 0.0f;                       // P3b accumulator of thread (frame, component)
+            const int fb_n = tid >> 4, fb_c = tid & 15;   // up to 32 frames per pass of P3b
+            if (wave == PD_GGS_WAVES - 1) {
+                // totals over all items (sum(s valid), n_valid, sum(min(s, max))) by the last wave, which owns
+                // no incidences at N <= 24: off wave 0's serial chain, overlapped with the pair backward
+                float s_sum = 0.0f, s_cnt = 0.0f, s_cl = 0.0f;
+                for (int q = lane; q < n_items; q += 64) {
+                    s_sum += L.item[q * PD_ITEM_VALS + 9];
+                    s_cnt += L.item[q * PD_ITEM_VALS + 10];
+                    s_cl += L.item[q * PD_ITEM_VALS + 11];
+                }
+                s_sum = wave_allsum(s_sum);
+                s_cnt = wave_allsum(s_cnt);
+                s_cl = wave_allsum(s_cl);
+                if (lane == 0) {
+                    L.cam[6] = s_sum;
+                    L.cam[7] = s_cnt;
+                    L.ctl[2] = s_cl;
+                }
+            }
+            for (int c0 = 0; c0 < n_inc; c0 += PD_GGS_THREADS) {
+                const int q = c0 + tid;
                 float oR[9], ot[3], oA[4];
 #pragma unroll
                 for (int c = 0; c < 9; ++c) oR[c] = 0.0f;
                 ot[0] = ot[1] = ot[2] = 0.0f;
                 oA[0] = oA[1] = oA[2] = oA[3] = 0.0f;
-                for (int q = lane; q < deg; q += 64) {
-                    const int4 ie = inc_lds ? L.inc[e0 + q] : D.inc[e0 + q];   // (i, j, first item, n_items | side << 16)
+                if (q < n_inc) {
+                    const int4 ie = inc_lds ? L.inc[q] : D.inc[q];   // (i, j, first item, n_items | side << 16)
                     const int pi = ie.x, pj = ie.y, side = ie.w >> 16, nit = ie.w & 0xffff;
                     float G[9];
 #pragma unroll
@@ -461,13 +513,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         AG[1 * 3 + c] = cam.a1 * g1 + cam.c1 * g2;
                         AG[2 * 3 + c] = g2;
                     }
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {   // gE = AG A^T : gE[r][c] = sum_q AG[r][q] A[c][q]
-                        gE[r * 3 + 0] = AG[r * 3 + 0] * cam.a0 + AG[r * 3 + 2] * cam.c0;
-                        gE[r * 3 + 1] = AG[r * 3 + 1] * cam.a1 + AG[r * 3 + 2] * cam.c1;
-                        gE[r * 3 + 2] = AG[r * 3 + 2];
-                    }
-                    if (side == 0) {
+                    if (S.update_FL && side == 0) {
                         // dL/dA = E A Gf^T + E^T A Gf, entries (0,0),(0,2),(1,1),(1,2); each pair once
                         float AGt[9];   // A Gf^T, Gf^T = G
 #pragma unroll
@@ -480,75 +526,95 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
 #define PD_DA(r, c)                                                                                      \
     (f.E[(r)*3 + 0] * AGt[0 * 3 + (c)] + f.E[(r)*3 + 1] * AGt[1 * 3 + (c)] + f.E[(r)*3 + 2] * AGt[2 * 3 + (c)] + \
      f.E[0 * 3 + (r)] * AG[0 * 3 + (c)] + f.E[1 * 3 + (r)] * AG[1 * 3 + (c)] + f.E[2 * 3 + (r)] * AG[2 * 3 + (c)])
-                        oA[0] += PD_DA(0, 0);
-                        oA[1] += PD_DA(0, 2);
-                        oA[2] += PD_DA(1, 1);
-                        oA[3] += PD_DA(1, 2);
+                        oA[0] = PD_DA(0, 0);
+                        oA[1] = PD_DA(0, 2);
+                        oA[2] = PD_DA(1, 1);
+                        oA[3] = PD_DA(1, 2);
 #undef PD_DA
                     }
-                    // E = R12 H : gR12 = gE H^T ; gH = R12^T gE
-                    const float ex = f.Et[0], ey = f.Et[1], ez = f.Et[2];
-                    float gR12[9], gH[9];
+                    if (need_rt) {
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) {   // (gE H^T)[r][c] = sum_q gE[r][q] H[c][q]
-                        const float g0 = gE[r * 3 + 0], g1 = gE[r * 3 + 1], g2 = gE[r * 3 + 2];
-                        gR12[r * 3 + 0] = -g1 * ez + g2 * ey;
-                        gR12[r * 3 + 1] = g0 * ez - g2 * ex;
-                        gR12[r * 3 + 2] = -g0 * ey + g1 * ex;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            gH[r * 3 + c] = f.R12[0 * 3 + r] * gE[0 * 3 + c] + f.R12[1 * 3 + r] * gE[1 * 3 + c] +
-                                            f.R12[2 * 3 + r] * gE[2 * 3 + c];
-                    const float gEt[3] = {gH[2 * 3 + 1] - gH[1 * 3 + 2], gH[0 * 3 + 2] - gH[2 * 3 + 0],
-                                          gH[1 * 3 + 0] - gH[0 * 3 + 1]};
-                    float gt12[3];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a)
-                        gt12[a] = -(f.R12[a * 3 + 0] * gEt[0] + f.R12[a * 3 + 1] * gEt[1] + f.R12[a * 3 + 2] * gEt[2]);
-#pragma unroll
-                    for (int a = 0; a < 3; ++a)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) gR12[a * 3 + c] += -f.t12[a] * gEt[c] - gt12[a] * ti[c];
-                    if (side == 1) {   // frame n is camera 2 (j): gtc_j = gt12 ; gRc_j = gR12 Rc_i
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            ot[a] += gt12[a];
-#pragma unroll
-                            for (int c = 0; c < 3; ++c)
-                                oR[a * 3 + c] += gR12[a * 3 + 0] * Ri[0 * 3 + c] + gR12[a * 3 + 1] * Ri[1 * 3 + c] +
-                                                 gR12[a * 3 + 2] * Ri[2 * 3 + c];
+                        for (int r = 0; r < 3; ++r) {   // gE = AG A^T : gE[r][c] = sum_q AG[r][q] A[c][q]
+                            gE[r * 3 + 0] = AG[r * 3 + 0] * cam.a0 + AG[r * 3 + 2] * cam.c0;
+                            gE[r * 3 + 1] = AG[r * 3 + 1] * cam.a1 + AG[r * 3 + 2] * cam.c1;
+                            gE[r * 3 + 2] = AG[r * 3 + 2];
                         }
-                    } else {           // frame n is camera 1 (i): gtc_i = -R12^T gt12 ; gRc_i = gR12^T Rc_j
+                        // E = R12 H : gR12 = gE H^T ; gH = R12^T gE
+                        const float ex = f.Et[0], ey = f.Et[1], ez = f.Et[2];
+                        float gR12[9], gH[9];
 #pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            ot[a] += -(f.R12[0 * 3 + a] * gt12[0] + f.R12[1 * 3 + a] * gt12[1] + f.R12[2 * 3 + a] * gt12[2]);
+                        for (int r = 0; r < 3; ++r) {   // (gE H^T)[r][c] = sum_q gE[r][q] H[c][q]
+                            const float g0 = gE[r * 3 + 0], g1 = gE[r * 3 + 1], g2 = gE[r * 3 + 2];
+                            gR12[r * 3 + 0] = -g1 * ez + g2 * ey;
+                            gR12[r * 3 + 1] = g0 * ez - g2 * ex;
+                            gR12[r * 3 + 2] = -g0 * ey + g1 * ex;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
 #pragma unroll
                             for (int c = 0; c < 3; ++c)
-                                oR[a * 3 + c] += gR12[0 * 3 + a] * Rj[0 * 3 + c] + gR12[1 * 3 + a] * Rj[1 * 3 + c] +
+                                gH[r * 3 + c] = f.R12[0 * 3 + r] * gE[0 * 3 + c] + f.R12[1 * 3 + r] * gE[1 * 3 + c] +
+                                                f.R12[2 * 3 + r] * gE[2 * 3 + c];
+                        const float gEt[3] = {gH[2 * 3 + 1] - gH[1 * 3 + 2], gH[0 * 3 + 2] - gH[2 * 3 + 0],
+                                              gH[1 * 3 + 0] - gH[0 * 3 + 1]};
+                        float gt12[3];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+                            gt12[a] = -(f.R12[a * 3 + 0] * gEt[0] + f.R12[a * 3 + 1] * gEt[1] + f.R12[a * 3 + 2] * gEt[2]);
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) gR12[a * 3 + c] += -f.t12[a] * gEt[c] - gt12[a] * ti[c];
+                        // side 1: frame is camera 2 (j): gtc_j = gt12 ; gRc_j = gR12 Rc_i
+                        // side 0: frame is camera 1 (i): gtc_i = -R12^T gt12 ; gRc_i = gR12^T Rc_j
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const float t1 = gt12[a];
+                            const float t0 = -(f.R12[0 * 3 + a] * gt12[0] + f.R12[1 * 3 + a] * gt12[1] + f.R12[2 * 3 + a] * gt12[2]);
+                            ot[a] = side ? t1 : t0;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const float r1 = gR12[a * 3 + 0] * Ri[0 * 3 + c] + gR12[a * 3 + 1] * Ri[1 * 3 + c] +
+                                                 gR12[a * 3 + 2] * Ri[2 * 3 + c];
+                                const float r0 = gR12[0 * 3 + a] * Rj[0 * 3 + c] + gR12[1 * 3 + a] * Rj[1 * 3 + c] +
                                                  gR12[2 * 3 + a] * Rj[2 * 3 + c];
+                                oR[a * 3 + c] = side ? r1 : r0;
+                            }
                         }
                     }
                 }
-#pragma unroll
-                for (int c = 0; c < 9; ++c) oR[c] = wave_allsum(oR[c]);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) ot[c] = wave_allsum(ot[c]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) oA[c] = wave_allsum(oA[c]);
-                if (lane == 0) {
-                    // back through tc = D T and Rc[a][b] = D[a] R[b][a]:  gR[b][a] = D[a] gRc[a][b]
-                    L.gT[n * 3 + 0] = -ot[0];
-                    L.gT[n * 3 + 1] = -ot[1];
-                    L.gT[n * 3 + 2] = ot[2];
-#pragma unroll
-                    for (int bb = 0; bb < 3; ++bb)
-#pragma unroll
-                        for (int aa = 0; aa < 3; ++aa) L.gR[n * 9 + bb * 3 + aa] = (aa < 2 ? -1.0f : 1.0f) * oR[aa * 3 + bb];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) L.gA[n * 4 + c] = oA[c];
+                float4 *dst = (float4 *)(L.pinc + tid * 16);
+                dst[0] = make_float4(oR[0], oR[1], oR[2], oR[3]);
+                dst[1] = make_float4(oR[4], oR[5], oR[6], oR[7]);
+                dst[2] = make_float4(oR[8], ot[0], ot[1], ot[2]);
+                dst[3] = make_float4(oA[0], oA[1], oA[2], oA[3]);
+                __syncthreads();
+                // ---- P3b: per-frame sums over the incidences of this chunk, fixed (ascending) order ----
+                for (int n0 = 0; n0 < N; n0 += PD_GGS_THREADS / 16) {
+                    const int n = n0 + fb_n;
+                    if (n < N) {
+                        const int lo = max(L.incoff[n], c0), hi = min(L.incoff[n + 1], c0 + PD_GGS_THREADS);
+                        float acc2 = (N <= PD_GGS_THREADS / 16) ? fsum : L.psum[n * 16 + fb_c];
+                        if (c0 == 0) acc2 = 0.0f;
+                        for (int e = lo; e < hi; ++e) acc2 += L.pinc[(e - c0) * 16 + fb_c];
+                        if (N <= PD_GGS_THREADS / 16) fsum = acc2; else L.psum[n * 16 + fb_c] = acc2;
+                    }
+                }
+                __syncthreads();
+            }
+            // scatter the per-frame totals: back through tc = D T and Rc[a][b] = D[a] R[b][a]
+            for (int n0 = 0; n0 < N; n0 += PD_GGS_THREADS / 16) {
+                const int n = n0 + fb_n;
+                if (n < N) {
+                    const float v = (N <= PD_GGS_THREADS / 16) ? fsum : L.psum[n * 16 + fb_c];
+                    if (fb_c < 9) {
+                        const int aa = fb_c / 3, bb = fb_c % 3;          // v = dL/dRc[aa][bb]
+                        L.gR[n * 9 + bb * 3 + aa] = (aa < 2 ? -v : v);  // gR[b][a] = D[a] gRc[a][b]
+                    } else if (fb_c < 12) {
+                        L.gT[n * 3 + (fb_c - 9)] = (fb_c - 9 < 2 ? -v : v);
+                    } else {
+                        L.gA[n * 4 + (fb_c - 12)] = v;
+                    }
                 }
             }
             __syncthreads();
@@ -556,15 +622,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
 
             // ---- P4 (wave 0): totals, early exit, quaternion/focal chain, clip, momentum SGD ----
             if (wave == 0) {
-                float s_sum = 0.0f, s_cnt = 0.0f, s_cl = 0.0f;
-                for (int q = lane; q < n_items; q += 64) {
-                    s_sum += L.item[q * PD_ITEM_VALS + 9];
-                    s_cnt += L.item[q * PD_ITEM_VALS + 10];
-                    s_cl += L.item[q * PD_ITEM_VALS + 11];
-                }
-                s_sum = wave_allsum(s_sum);
-                s_cnt = wave_allsum(s_cnt);
-                s_cl = wave_allsum(s_cl);
+                const float s_sum = L.cam[6], s_cnt = L.cam[7], s_cl = L.ctl[2];
                 float ga[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) ga[c] = wave_allsum(lane < N ? L.gA[lane * 4 + c] : 0.0f);
@@ -573,9 +631,9 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 // len(valid) / n_frames < min_matches -> break   (geometry_guided_sampling.py:104-108)
                 const bool done = (!P.eval_only) && P.min_matches > 0 && (s_cnt < (float)P.min_matches * (float)N);
                 if (!done) {
-                    const float loss = s_sum / s_cnt;                     // valid.mean()  :110
+                    const float inv_cnt = pd_rcp(s_cnt);
+                    const float loss = s_sum * inv_cnt;                   // valid.mean()  :110
                     last_loss = loss;
-                    const float inv_cnt = 1.0f / s_cnt;
                     float g[9];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) g[c] = 0.0f;
@@ -588,7 +646,8 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                             // R = I + two_s * Pm(q): chain rule to the (unnormalised) quaternion
                             const float r = xr[3], i = xr[4], j = xr[5], kq = xr[6];
                             const float n2 = r * r + i * i + j * j + kq * kq;
-                            const float ts = 2.0f / n2;
+                            const float rn2 = pd_rcp(n2);
+                            const float ts = 2.0f * rn2;
                             float gR[9];
 #pragma unroll
                             for (int c = 0; c < 9; ++c) gR[c] = L.gR[lane * 9 + c];
@@ -598,7 +657,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                             float h[9];
 #pragma unroll
                             for (int c = 0; c < 9; ++c) h[c] = ts * gR[c];
-                            const float qs = gts * (-4.0f / (n2 * n2));
+                            const float qs = gts * (-4.0f * rn2 * rn2);
                             const float gq_r = -kq * h[1] + j * h[2] + kq * h[3] - i * h[5] - j * h[6] + i * h[7] + qs * r;
                             const float gq_i = j * h[1] + kq * h[2] + j * h[3] - 2.0f * i * h[4] - r * h[5] + kq * h[6] +
                                                r * h[7] - 2.0f * i * h[8] + qs * i;
@@ -614,10 +673,11 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         if (S.update_FL) {
                             // A00 = 1/(f sc), A02 = -cx/(f sc): dA/df ; mean over frames ; exp ; clamp mask
                             const float fbx = L.cam[4], fby = L.cam[5];
-                            const float gfx = ga[0] * (-1.0f / (fbx * fbx * D.sc)) + ga[1] * (D.cx / (fbx * fbx * D.sc));
-                            const float gfy = ga[2] * (-1.0f / (fby * fby * D.sc)) + ga[3] * (D.cy / (fby * fby * D.sc));
-                            g[7] = gfx / (float)N * L.fl[lane * 2 + 0] * L.flp[lane * 2 + 0] * inv_cnt;
-                            g[8] = gfy / (float)N * L.fl[lane * 2 + 1] * L.flp[lane * 2 + 1] * inv_cnt;
+                            const float kx = pd_rcp(fbx * fbx * D.sc), ky = pd_rcp(fby * fby * D.sc), rNn = pd_rcp((float)N);
+                            const float gfx = (ga[1] * D.cx - ga[0]) * kx;
+                            const float gfy = (ga[3] * D.cy - ga[2]) * ky;
+                            g[7] = gfx * rNn * L.fl[lane * 2 + 0] * L.flp[lane * 2 + 0] * inv_cnt;
+                            g[8] = gfy * rNn * L.fl[lane * 2 + 1] * L.flp[lane * 2 + 1] * inv_cnt;
                         }
                     }
                     if (P.eval_only) {
@@ -639,10 +699,10 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                             gn2 += g[c] * g[c];
                             xn2 += (fabsf(g[c]) > 0.0f) ? xr[c] * xr[c] : 0.0f;
                         }
-                        const float gnorm = sqrtf(wave_allsum(gn2));
-                        const float xnorm = sqrtf(wave_allsum(xn2));
-                        const float max_norm = P.alpha * xnorm / P.lr;
-                        const float coef = fminf(max_norm / (gnorm + 1e-6f), 1.0f);
+                        const float gnorm = pd_sqrt(wave_allsum(gn2));
+                        const float xnorm = pd_sqrt(wave_allsum(xn2));
+                        const float max_norm = P.alpha * xnorm * pd_rcp(P.lr);
+                        const float coef = fminf(max_norm * pd_rcp(gnorm + 1e-6f), 1.0f);
 #pragma unroll
                         for (int c = 0; c < 9; ++c) {
                             const float gc = g[c] * coef;
@@ -847,7 +907,7 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     int device_cus = 256;
     int k = cfg->wgs_per_seq > 0 ? cfg->wgs_per_seq : (max_items + PD_GGS_WAVES - 1) / PD_GGS_WAVES;
     k = std::max(1, std::min(k, device_cus / B));
-    if ((size_t)max_items * PD_ITEM_VALS > eng->xchg_granules) k = 1;
+    if ((size_t)max_items * PD_XCHG_LINE > eng->xchg_granules) k = 1;
     int n_slots = 0, n_inc_lds = 0, max_inc = 0;
     for (int b = 0; b < B; ++b) max_inc = std::max(max_inc, 2 * eng->seqs[b].desc.n_pairs);
     size_t lds = 0;
