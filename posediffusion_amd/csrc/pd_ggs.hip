@@ -273,6 +273,28 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
         }
     }
 
+    // P3b role of this thread, constant for the launch: thread (fb_n, fb_c) sums component fb_c of the
+    // incidences of frame fb_n (frames 0..31 in one pass) and owns the matching gradient slot
+    const int fb_n = tid >> 4, fb_c = tid & 15;
+    const int fb_lo = fb_n < N ? L.incoff[fb_n] : 0, fb_hi = fb_n < N ? L.incoff[fb_n + 1] : 0;
+    float *fb_dst;
+    float fb_sign;
+    if (fb_c < 9) {          // value = dL/dRc[aa][bb]; gR[b][a] = D[a] gRc[a][b]
+        const int aa = fb_c / 3, bb = fb_c % 3;
+        fb_dst = &L.gR[fb_n * 9 + bb * 3 + aa];
+        fb_sign = aa < 2 ? -1.0f : 1.0f;
+    } else if (fb_c < 12) {  // dL/dT = D dL/dtc
+        fb_dst = &L.gT[fb_n * 3 + (fb_c - 9)];
+        fb_sign = (fb_c - 9) < 2 ? -1.0f : 1.0f;
+    } else {
+        fb_dst = &L.gA[fb_n * 4 + (fb_c - 12)];
+        fb_sign = 1.0f;
+    }
+    const bool small_n = N <= PD_GGS_THREADS / 16;              // every frame has its own thread group
+    const bool spare_wave = N * 16 <= (PD_GGS_WAVES - 1) * 64;   // the last wave is entirely idle in P3b
+    const int n_inc = L.incoff[N];
+    // this thread's incidence of chunk 0 (constant for the launch)
+    const int4 my_inc = (tid < n_inc) ? (inc_lds ? L.inc[tid] : D.inc[tid]) : make_int4(0, 0, 0, 0);
     unsigned epoch = 0;
     int trace_row = 0;
     const bool prof = P.prof != nullptr && blockIdx.x == 0 && wave == 1;   // a worker wave of WG 0
@@ -355,10 +377,12 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         const float r1 = fmaf(F10, u2, fmaf(F11, v2, F12));
                         const float ee = fmaf(l0, u2, fmaf(l1, v2, l2));
                         const float bottom = l0 * l0 + l1 * l1 + r0 * r0 + r1 * r1;   // :161
-                        const float sam = (ee * ee) / bottom;                             // :162-164
+                        // 1-ulp reciprocal instead of an IEEE divide: F itself already differs from the
+                        // reference's by fp32 rounding order, so the threshold test is equally (in)exact
+                        const float inv = pd_rcp(bottom);
+                        const float sam = (ee * ee) * inv;                                // :162-164
                         acc[11] += in ? fminf(sam, P.sampson_max) : 0.0f;                 // :169
                         const bool valid = in && (sam < P.sampson_max);                   // :170
-                        const float inv = pd_rcp(bottom);
                         const float ca = valid ? 2.0f * ee * inv : 0.0f;
                         const float cb = valid ? 2.0f * sam * inv : 0.0f;
                         acc[9] += valid ? sam : 0.0f;
@@ -453,28 +477,8 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
             // ---- P3a: pair backward, one (frame, incident pair) per thread, flat over the workgroup ----
             // chunks of PD_GGS_THREADS incidences (one chunk at N = 20); results go to LDS [chunk][16]:
             // 9 dL/dRc_side + 3 dL/dtc_side + 4 dL/dA partials, then P3b sums them per frame in fixed order
-            const int n_inc = L.incoff[N];
             const bool need_rt = S.update_R || S.update_T;
             float fsum = 0.0f;                       // P3b accumulator of thread (frame, component)
-            const int fb_n = tid >> 4, fb_c = tid & 15;   // up to 32 frames per pass of P3b
-            if (wave == PD_GGS_WAVES - 1) {
-                // totals over all items (sum(s valid), n_valid, sum(min(s, max))) by the last wave, which owns
-                // no incidences at N <= 24: off wave 0's serial chain, overlapped with the pair backward
-                float s_sum = 0.0f, s_cnt = 0.0f, s_cl = 0.0f;
-                for (int q = lane; q < n_items; q += 64) {
-                    s_sum += L.item[q * PD_ITEM_VALS + 9];
-                    s_cnt += L.item[q * PD_ITEM_VALS + 10];
-                    s_cl += L.item[q * PD_ITEM_VALS + 11];
-                }
-                s_sum = wave_allsum(s_sum);
-                s_cnt = wave_allsum(s_cnt);
-                s_cl = wave_allsum(s_cl);
-                if (lane == 0) {
-                    L.cam[6] = s_sum;
-                    L.cam[7] = s_cnt;
-                    L.ctl[2] = s_cl;
-                }
-            }
             for (int c0 = 0; c0 < n_inc; c0 += PD_GGS_THREADS) {
                 const int q = c0 + tid;
                 float oR[9], ot[3], oA[4];
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 ot[0] = ot[1] = ot[2] = 0.0f;
                 oA[0] = oA[1] = oA[2] = oA[3] = 0.0f;
                 if (q < n_inc) {
-                    const int4 ie = inc_lds ? L.inc[q] : D.inc[q];   // (i, j, first item, n_items | side << 16)
+                    const int4 ie = (c0 == 0) ? my_inc : (inc_lds ? L.inc[q] : D.inc[q]);   // (i, j, first item, n_items | side << 16)
                     const int pi = ie.x, pj = ie.y, side = ie.w >> 16, nit = ie.w & 0xffff;
                     float G[9];
 #pragma unroll
@@ -491,19 +495,21 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                     for (int u = 0; u < nit; ++u)
 #pragma unroll
                         for (int c = 0; c < 9; ++c) G[c] += L.item[(ie.z + u) * PD_ITEM_VALS + c];
-                    float Ri[9], Rj[9], ti[3], tj[3];
+                    float Ri[9], Rj[9], ti[3];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) {
                         Ri[c] = L.Rc[pi * 9 + c];
                         Rj[c] = L.Rc[pj * 9 + c];
                     }
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        ti[c] = L.tc[pi * 3 + c];
-                        tj[c] = L.tc[pj * 3 + c];
-                    }
+                    for (int c = 0; c < 3; ++c) ti[c] = L.tc[pi * 3 + c];
                     PairFwd f;
-                    pair_forward(Ri, ti, Rj, tj, f);
+                    {
+                        float tj[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) tj[c] = L.tc[pj * 3 + c];
+                        pair_forward(Ri, ti, Rj, tj, f);
+                    }
                     // Gf = dL/dFo = G^T ; gE = A Gf A^T  (A = [[a0,0,c0],[0,a1,c1],[0,0,1]])
                     float AG[9], gE[9];
 #pragma unroll
@@ -590,30 +596,83 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 dst[3] = make_float4(oA[0], oA[1], oA[2], oA[3]);
                 __syncthreads();
                 // ---- P3b: per-frame sums over the incidences of this chunk, fixed (ascending) order ----
-                for (int n0 = 0; n0 < N; n0 += PD_GGS_THREADS / 16) {
-                    const int n = n0 + fb_n;
-                    if (n < N) {
-                        const int lo = max(L.incoff[n], c0), hi = min(L.incoff[n + 1], c0 + PD_GGS_THREADS);
-                        float acc2 = (N <= PD_GGS_THREADS / 16) ? fsum : L.psum[n * 16 + fb_c];
-                        if (c0 == 0) acc2 = 0.0f;
-                        for (int e = lo; e < hi; ++e) acc2 += L.pinc[(e - c0) * 16 + fb_c];
-                        if (N <= PD_GGS_THREADS / 16) fsum = acc2; else L.psum[n * 16 + fb_c] = acc2;
+                if (small_n) {
+                    if (fb_n < N) {
+                        const int lo = max(fb_lo, c0), hi = min(fb_hi, c0 + PD_GGS_THREADS);
+                        float acc2 = (c0 == 0) ? 0.0f : fsum;
+                        for (int e = lo; e < hi; e += 24) {   // 24 LDS loads in flight, summed in order
+                            float t24[24];
+#pragma unroll
+                            for (int u = 0; u < 24; ++u) t24[u] = L.pinc[(min(e + u, hi - 1) - c0) * 16 + fb_c];
+#pragma unroll
+                            for (int u = 0; u < 24; ++u) acc2 += (e + u < hi) ? t24[u] : 0.0f;
+                        }
+                        fsum = acc2;
+                    } else if (spare_wave && wave == PD_GGS_WAVES - 1 && c0 == 0) {
+                        // totals over all items by an otherwise idle wave: one 16-byte read per item gets
+                        // {dF22, sum(s valid), n_valid, sum(min(s, max))}
+                        float s_sum = 0.0f, s_cnt = 0.0f, s_cl = 0.0f;
+                        for (int q2 = lane; q2 < n_items; q2 += 64) {
+                            const float4 v4 = *(const float4 *)&L.item[q2 * PD_ITEM_VALS + 8];
+                            s_sum += v4.y;
+                            s_cnt += v4.z;
+                            s_cl += v4.w;
+                        }
+                        s_sum = wave_allsum(s_sum);
+                        s_cnt = wave_allsum(s_cnt);
+                        s_cl = wave_allsum(s_cl);
+                        if (lane == 0) {
+                            L.cam[6] = s_sum;
+                            L.cam[7] = s_cnt;
+                            L.ctl[2] = s_cl;
+                        }
+                    }
+                } else {
+                    for (int n0 = 0; n0 < N; n0 += PD_GGS_THREADS / 16) {
+                        const int n = n0 + fb_n;
+                        if (n < N) {
+                            const int lo = max(L.incoff[n], c0), hi = min(L.incoff[n + 1], c0 + PD_GGS_THREADS);
+                            float acc2 = (c0 == 0) ? 0.0f : L.psum[n * 16 + fb_c];
+                            for (int e = lo; e < hi; ++e) acc2 += L.pinc[(e - c0) * 16 + fb_c];
+                            L.psum[n * 16 + fb_c] = acc2;
+                        }
                     }
                 }
                 __syncthreads();
             }
+            if (!spare_wave && wave == 0) {
+                float s_sum = 0.0f, s_cnt = 0.0f, s_cl = 0.0f;
+                for (int q2 = lane; q2 < n_items; q2 += 64) {
+                    const float4 v4 = *(const float4 *)&L.item[q2 * PD_ITEM_VALS + 8];
+                    s_sum += v4.y;
+                    s_cnt += v4.z;
+                    s_cl += v4.w;
+                }
+                s_sum = wave_allsum(s_sum);
+                s_cnt = wave_allsum(s_cnt);
+                s_cl = wave_allsum(s_cl);
+                if (lane == 0) {
+                    L.cam[6] = s_sum;
+                    L.cam[7] = s_cnt;
+                    L.ctl[2] = s_cl;
+                }
+            }
             // scatter the per-frame totals: back through tc = D T and Rc[a][b] = D[a] R[b][a]
-            for (int n0 = 0; n0 < N; n0 += PD_GGS_THREADS / 16) {
-                const int n = n0 + fb_n;
-                if (n < N) {
-                    const float v = (N <= PD_GGS_THREADS / 16) ? fsum : L.psum[n * 16 + fb_c];
-                    if (fb_c < 9) {
-                        const int aa = fb_c / 3, bb = fb_c % 3;          // v = dL/dRc[aa][bb]
-                        L.gR[n * 9 + bb * 3 + aa] = (aa < 2 ? -v : v);  // gR[b][a] = D[a] gRc[a][b]
-                    } else if (fb_c < 12) {
-                        L.gT[n * 3 + (fb_c - 9)] = (fb_c - 9 < 2 ? -v : v);
-                    } else {
-                        L.gA[n * 4 + (fb_c - 12)] = v;
+            if (small_n) {
+                if (fb_n < N) *fb_dst = fb_sign * fsum;
+            } else {
+                for (int n0 = 0; n0 < N; n0 += PD_GGS_THREADS / 16) {
+                    const int n = n0 + fb_n;
+                    if (n < N) {
+                        const float v = L.psum[n * 16 + fb_c];
+                        if (fb_c < 9) {
+                            const int aa = fb_c / 3, bb = fb_c % 3;
+                            L.gR[n * 9 + bb * 3 + aa] = (aa < 2 ? -v : v);
+                        } else if (fb_c < 12) {
+                            L.gT[n * 3 + (fb_c - 9)] = (fb_c - 9 < 2 ? -v : v);
+                        } else {
+                            L.gA[n * 4 + (fb_c - 12)] = v;
+                        }
                     }
                 }
             }
