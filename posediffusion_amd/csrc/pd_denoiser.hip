@@ -141,6 +141,7 @@ struct GemmArgs {
     const float *x, *z, *temb;   // x [M,9], z [M,384], temb [128] (row of the table for this t)
     int n_frames;
     int M, Nout;
+    int MT;                // number of 32-row M tiles (XCD-aware block mapping)
 };
 
 // 8-lane (one activation row) sum on the DPP network: xor-1, xor-2 quad permutes + half-row mirror
@@ -167,8 +168,14 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *As = lds;                      // [32][LDA]; later aliased by the cross-wave reduction
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * NT;
-    const float4 *wp = (const float4 *)g.Wp + ((size_t)blockIdx.y * KC + (size_t)wave * CPW) * 64 + lane;
+    // XCD-aware tile mapping (guide T1): the dispatcher places block id on XCD id % 8; all M-tiles that share
+    // an N-tile are given ids with the same id % 8, so each weight tile is fetched into ONE L2 once and the
+    // other M-tile workgroups hit it there (the naive (m + MT*n) order spread them over MT different XCDs
+    // and re-fetched every weight byte MT times).  Needs (Nout / NT) % 8 == 0 -- true for every layer here.
+    const int bid = blockIdx.x, slot = bid >> 3;
+    const int ntile = (bid & 7) + 8 * (slot / g.MT), mtile = slot % g.MT;
+    const int m0 = mtile * 32, n0 = ntile * NT;
+    const float4 *wp = (const float4 *)g.Wp + ((size_t)ntile * KC + (size_t)wave * CPW) * 64 + lane;
 
     // ---- weights first: the whole first batch of this wave's fragments goes in flight before the
     // activation staging, so the HBM/MALL latency of the weight stream hides under it --------------
@@ -611,12 +618,13 @@ void pd_denoiser_destroy(pd_engine *eng) {
 template <int K, int AMODE, int EPI>
 static void launch_gemm(GemmArgs &g, float *const wp[2], int MT, hipStream_t s) {
     const int tiles32 = MT * (g.Nout / 32);
+    g.MT = MT;
     if (tiles32 >= 200) {
         g.Wp = wp[0];
-        hipLaunchKernelGGL((pd_gemm_kernel<K, AMODE, EPI, 32>), dim3(MT, g.Nout / 32), dim3(256), 32 * (K + 4) * 4, s, g);
+        hipLaunchKernelGGL((pd_gemm_kernel<K, AMODE, EPI, 32>), dim3(MT * (g.Nout / 32)), dim3(256), 32 * (K + 4) * 4, s, g);
     } else {
         g.Wp = wp[1];
-        hipLaunchKernelGGL((pd_gemm_kernel<K, AMODE, EPI, 16>), dim3(MT, g.Nout / 16), dim3(256), 32 * (K + 4) * 4, s, g);
+        hipLaunchKernelGGL((pd_gemm_kernel<K, AMODE, EPI, 16>), dim3(MT * (g.Nout / 16)), dim3(256), 32 * (K + 4) * 4, s, g);
     }
 }
 
