@@ -638,7 +638,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         }
                     }
                 }
-                __syncthreads();
+                if (c0 + PD_GGS_THREADS < n_inc) __syncthreads();   // pinc is rewritten by the next chunk
             }
             if (!spare_wave && wave == 0) {
                 float s_sum = 0.0f, s_cnt = 0.0f, s_cl = 0.0f;
