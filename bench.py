@@ -170,7 +170,11 @@ def main():
     # one resident batch per context (different sequences: seeds offset by the global batch size)
     inputs = [build_inputs(engines[j], diff, B, dev, seed0=g0 + j * total) for j in range(depth)]
     z, noise = inputs[0]
-    cfg = make_ggs_cfg(synth.GGS_CFG)
+    # GGS workgroups per sequence: alone on the chip -> one work item per wave (24 WGs/sequence, lowest latency);
+    # with `depth` batches in flight each batch's persistent GGS kernel gets an equal share of 192 CUs so that
+    # the kernels of different batches run CONCURRENTLY (64 CUs stay free for the other batches' denoiser steps)
+    wgs = 0 if depth == 1 else max(1, 192 // (B * depth))
+    cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=wgs)
     use_graph = not args.no_graph
     torch.cuda.synchronize()
 
@@ -229,7 +233,7 @@ def main():
                         "unguided model mean at t=9",
             "sequences_per_gpu": B, "frames": N_FRAMES, "matches_per_sequence": M, "diffusion_steps": 100,
             "ggs_iterations_per_sequence_run": float(iters.min().item()), "hip_graph": use_graph,
-            "pipeline_depth": depth, "pass_latency_ms_unpipelined": pass_latency_ms,
+            "pipeline_depth": depth, "pass_latency_ms_unpipelined": pass_latency_ms, "ggs_workgroups_per_sequence": wgs or 24,
             "parallelism": f"dp{world} (independent sequences, one final all_gather)", "outputs_finite": finite,
         },
         "roofline": {

@@ -91,6 +91,10 @@ extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_en
             rc = PD_ERR_HIP;
             break;
         }
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, eng->device) == hipSuccess) eng->num_cus = prop.multiProcessorCount;
+        }
         eng->max_B = max_B;
         eng->max_N = max_N;
         eng->d_model = w->d_model;

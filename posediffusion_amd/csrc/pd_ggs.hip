@@ -936,6 +936,14 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     return upload_seq_table(eng);
 }
 
+// Zeroes the exchange granules before every launch (tags restart at 1 per launch).  A KERNEL rather than
+// hipMemsetAsync: under hipGraph replay with a second graph running concurrently, the memset NODE was observed
+// not to be ordered against the neighbouring kernel nodes (stale tags of the previous launch were accepted ->
+// silently wrong sums; tests/test_gpu_parity.py::test_two_engines_overlapped...); kernel -> kernel edges are.
+__global__ void pd_ggs_zero_kernel(unsigned long long *p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0ull;
+}
+
 int pd_ggs_init() {
     PD_HIP_CHECK(hipFuncSetAttribute((const void *)pd_ggs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return PD_OK;
@@ -963,7 +971,7 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
         max_items = std::max(max_items, d.n_items);
     }
     // workgroups per sequence: one item per wave if the chip has room (<= 256 resident workgroups)
-    int device_cus = 256;
+    int device_cus = eng->num_cus > 0 ? eng->num_cus : 256;
     int k = cfg->wgs_per_seq > 0 ? cfg->wgs_per_seq : (max_items + PD_GGS_WAVES - 1) / PD_GGS_WAVES;
     k = std::max(1, std::min(k, device_cus / B));
     if ((size_t)max_items * PD_XCHG_LINE > eng->xchg_granules) k = 1;
@@ -1010,8 +1018,9 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     P.err_flag = eng->d_err;
     P.prof = eng->ggs_prof_on ? (long long *)(eng->d_err + 2) : nullptr;
     if (k > 1) {
-        // tags restart at 1 every launch: zero every polled word first (guide G16 "re-initialise")
-        PD_HIP_CHECK(hipMemsetAsync(eng->d_xchg, 0, sizeof(u64) * 2 * eng->xchg_granules * B, s));
+        // tags restart at 1 every launch: zero every polled word first (guide G16 "re-initialise every call")
+        const size_t n_zero = 2 * eng->xchg_granules * B;
+        hipLaunchKernelGGL(pd_ggs_zero_kernel, dim3(256), dim3(256), 0, s, eng->d_xchg, n_zero);
     }
     hipLaunchKernelGGL(pd_ggs_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots, n_inc_lds);
     PD_HIP_CHECK(hipGetLastError());

@@ -79,6 +79,7 @@ struct PdDenoiserDev;   // defined in pd_denoiser.hip
 
 struct pd_engine {
     int device = 0;
+    int num_cus = 0;           // multiProcessorCount (bounds the resident workgroups of the GGS exchange)
     int max_B = 0, max_N = 0;
     int d_model = 0, nhead = 0, dim_ff = 0, num_layers = 0, z_dim = 0, timesteps = 0;
     PdDenoiserDev *den = nullptr;

@@ -366,3 +366,46 @@ def test_long_sequence_n50(engine):
         outs.append(o)
     ref, _, _ = O.ggs_optimize(x0.clone(), pm, iter_num=2)
     assert rel_err(outs[0], ref) < TOL and torch.equal(outs[0], outs[1])
+
+
+def test_two_engines_overlapped_on_two_streams_match_serial(seeded_diffuser):
+    """bench.py double-buffers passes on two engine contexts / HIP streams.  Overlap must not change a bit:
+    this caught a hipGraph memset-node ordering problem (exchange tags were zeroed late under concurrent replay),
+    fixed by zeroing with a kernel node (pd_ggs_zero_kernel)."""
+    from posediffusion_amd.engine import PoseEngine
+    from posediffusion_amd.host import denoiser_state, draw_noise
+    dev = torch.device(DEV)
+    diff = seeded_diffuser.to(dev)
+    B, N = 4, 12
+    tables = {k: v for k, v in diff.named_buffers(recurse=False)}
+    engs = [PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=B, max_N=N) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    data = []
+    for e, eng in enumerate(engs):
+        z = synth.make_z(B, N, seed=300 + 10 * e).to(dev)
+        noise = torch.stack([draw_noise((N, 9), 100, dev, 4, True, generator=torch.Generator(device=dev).manual_seed(10 * e + b))
+                             for b in range(B)], dim=1)
+        for b in range(B):
+            enc = synth.make_cameras(N, seed=40 + 10 * e + b)
+            md = synth.make_matches(enc, 224, 224, per_pair=150, seed=40 + 10 * e + b)
+            eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+        data.append((z, noise))
+    cfg = make_ggs_cfg(synth.GGS_CFG, iter_num=30, min_matches=0, wgs_per_seq=8)   # 4 seq x 8 WGs: both kernels co-resident
+    torch.cuda.synchronize()
+    refs = []
+    for j in range(2):
+        refs.append(engs[j].sample(data[j][0], data[j][1], 4, cfg, use_graph=True)[0].clone())
+        torch.cuda.synchronize()
+    for rep in range(3):
+        outs = []
+        for i in range(4):
+            j = i % 2
+            with torch.cuda.stream(streams[j]):
+                outs.append((j, engs[j].sample(data[j][0], data[j][1], 4, cfg, use_graph=True)[0]))
+        torch.cuda.synchronize()
+        for e in engs:
+            e.check_async()
+        for j, o in outs:
+            assert torch.equal(o, refs[j]), f"engine {j}: overlapped result differs from its serial result"
+    for e in engs:
+        e.close()

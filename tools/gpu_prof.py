@@ -10,13 +10,13 @@ dev = torch.device("cuda:0")
 diff = synth.make_diffuser(seed=0)
 eng = PoseEngine(denoiser_state(diff.model), {k: v for k, v in diff.named_buffers(recurse=False)}, device=dev, max_B=8, max_N=50)
 N, H, W = 20, 224, 224
-for B in (1, 8):
+for B in (8,):
     for b in range(B):
         enc = synth.make_cameras(N, seed=2000 + b)
         md = synth.make_matches(enc, H, W, per_pair=300, seed=2000 + b)
         eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
     x0 = torch.cat([synth.perturb_pose(synth.make_cameras(N, seed=2000 + b), seed=7 + b) for b in range(B)]).to(dev)
-    for k in (1, 4, 0):
+    for k in (0, 16, 12):
         cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=k)
         eng.ggs_prof(True)
         eng.ggs_guide(x0, 0, cfg)
