@@ -113,6 +113,53 @@ __device__ __forceinline__ void fundamental_from_E(const float *E, const Cam &c,
     }
 }
 
+// Two matches per lane at once on packed-fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): every per-match
+// quantity is a float2 (x = match A, y = match B).  P2 is VALU-issue bound (2 waves per SIMD x ~85 instructions per
+// match when the compiler packs within one match), so packing ACROSS matches nearly halves its instruction count.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pd_fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pd_splat(float a) { return (v2f){a, a}; }
+
+// Sampson residual + dL/dF of two matches (geometry_guided_sampling.py:157-170); acc[0..8] dL/dF sums,
+// acc[9] sum(s valid), acc[10] n_valid, acc[11] sum(min(s, max)), each as {match A, match B} partial sums
+__device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, bool ina, bool inb, const float *F, float smax,
+                                              v2f (&acc)[PD_ITEM_VALS]) {
+    const v2f u1 = {pa.x, pb.x}, v1 = {pa.y, pb.y}, u2 = {pa.z, pb.z}, v2 = {pa.w, pb.w};
+    // left = x1^T F, right = F x2   (:158-159)
+    const v2f l0 = pd_fma2(u1, pd_splat(F[0]), pd_fma2(v1, pd_splat(F[3]), pd_splat(F[6])));
+    const v2f l1 = pd_fma2(u1, pd_splat(F[1]), pd_fma2(v1, pd_splat(F[4]), pd_splat(F[7])));
+    const v2f l2 = pd_fma2(u1, pd_splat(F[2]), pd_fma2(v1, pd_splat(F[5]), pd_splat(F[8])));
+    const v2f r0 = pd_fma2(pd_splat(F[0]), u2, pd_fma2(pd_splat(F[1]), v2, pd_splat(F[2])));
+    const v2f r1 = pd_fma2(pd_splat(F[3]), u2, pd_fma2(pd_splat(F[4]), v2, pd_splat(F[5])));
+    const v2f ee = pd_fma2(l0, u2, pd_fma2(l1, v2, l2));
+    const v2f bottom = l0 * l0 + l1 * l1 + r0 * r0 + r1 * r1;          // :161
+    // 1-ulp reciprocal instead of an IEEE divide: F itself already differs from the reference's by fp32
+    // rounding order, so the threshold test is equally (in)exact
+    const v2f inv = {pd_rcp(bottom.x), pd_rcp(bottom.y)};
+    const v2f sam = (ee * ee) * inv;                                    // :162-164
+    const v2f clamped = __builtin_elementwise_min(sam, pd_splat(smax));
+    acc[11] += (v2f){ina ? clamped.x : 0.0f, inb ? clamped.y : 0.0f};   // :169
+    const bool va = ina && (sam.x < smax), vb = inb && (sam.y < smax);   // :170 (false for NaN)
+    const v2f valid = {va ? 1.0f : 0.0f, vb ? 1.0f : 0.0f};
+    const v2f two_inv = {va ? inv.x + inv.x : 0.0f, vb ? inv.y + inv.y : 0.0f};   // selects, not products: inv may be inf
+    const v2f ca = {va ? ee.x * two_inv.x : 0.0f, vb ? ee.y * two_inv.y : 0.0f};
+    const v2f cb = {va ? sam.x * two_inv.x : 0.0f, vb ? sam.y * two_inv.y : 0.0f};
+    acc[9] += (v2f){va ? sam.x : 0.0f, vb ? sam.y : 0.0f};
+    acc[10] += valid;
+    // d sam / dF[r][c] = ca x1[r] x2[c] - cb (l_c x1[r] [c<2] + r_r x2[c] [r<2])
+    const v2f a1 = ca * u1, a2 = ca * v1, bl0 = cb * l0, bl1 = cb * l1, br0 = cb * r0, br1 = cb * r1;
+    acc[0] += a1 * u2 - (bl0 * u1 + br0 * u2);
+    acc[1] += a1 * v2 - (bl1 * u1 + br0 * v2);
+    acc[2] += a1 - br0;
+    acc[3] += a2 * u2 - (bl0 * v1 + br1 * u2);
+    acc[4] += a2 * v2 - (bl1 * v1 + br1 * v2);
+    acc[5] += a2 - br1;
+    acc[6] += ca * u2 - bl0;
+    acc[7] += ca * v2 - bl1;
+    acc[8] += ca;
+}
+
 // LDS carve (floats).  Everything lives in the one dynamic region (guide G17).
 #define PD_GGS_LDS_FIXED (64 * 9 + 64 * 3 + 64 * 2 + 64 * 2 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8 + PD_GGS_THREADS * 16 + 64 * 16)
 struct Lds {
@@ -341,12 +388,9 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 if (item >= n_items) break;
                 const int s = wave + 8 * r;
                 const int4 e = L.itab[s];
-                const float F00 = L.F[s * 9 + 0], F01 = L.F[s * 9 + 1], F02 = L.F[s * 9 + 2];
-                const float F10 = L.F[s * 9 + 3], F11 = L.F[s * 9 + 4], F12 = L.F[s * 9 + 5];
-                const float F20 = L.F[s * 9 + 6], F21 = L.F[s * 9 + 7], F22 = L.F[s * 9 + 8];
-                float acc[PD_ITEM_VALS];
+                float Fm[9];
 #pragma unroll
-                for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = 0.0f;
+                for (int c = 0; c < 9; ++c) Fm[c] = L.F[s * 9 + c];
                 float4 mb[8];
                 if (resident) {
 #pragma unroll
@@ -362,43 +406,20 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         mb[st] = pts[m < e.y ? m : last];
                     }
                 }
-                const int nsteps = (e.y + 63) >> 6;
+                // two 64-match steps per pass: lane handles matches lane + 64*(2j) and lane + 64*(2j+1) together
+                v2f acc2[PD_ITEM_VALS];
 #pragma unroll
-                for (int st = 0; st < 8; ++st) {
-                    if (st < nsteps) {
-                        const bool in = (lane + 64 * st) < e.y;
-                        const float4 pt = mb[st];
-                        const float u1 = pt.x, v1 = pt.y, u2 = pt.z, v2 = pt.w;
-                        // left = x1^T F, right = F x2   (geometry_guided_sampling.py:158-159)
-                        const float l0 = fmaf(u1, F00, fmaf(v1, F10, F20));
-                        const float l1 = fmaf(u1, F01, fmaf(v1, F11, F21));
-                        const float l2 = fmaf(u1, F02, fmaf(v1, F12, F22));
-                        const float r0 = fmaf(F00, u2, fmaf(F01, v2, F02));
-                        const float r1 = fmaf(F10, u2, fmaf(F11, v2, F12));
-                        const float ee = fmaf(l0, u2, fmaf(l1, v2, l2));
-                        const float bottom = l0 * l0 + l1 * l1 + r0 * r0 + r1 * r1;   // :161
-                        // 1-ulp reciprocal instead of an IEEE divide: F itself already differs from the
-                        // reference's by fp32 rounding order, so the threshold test is equally (in)exact
-                        const float inv = pd_rcp(bottom);
-                        const float sam = (ee * ee) * inv;                                // :162-164
-                        acc[11] += in ? fminf(sam, P.sampson_max) : 0.0f;                 // :169
-                        const bool valid = in && (sam < P.sampson_max);                   // :170
-                        const float ca = valid ? 2.0f * ee * inv : 0.0f;
-                        const float cb = valid ? 2.0f * sam * inv : 0.0f;
-                        acc[9] += valid ? sam : 0.0f;
-                        acc[10] += valid ? 1.0f : 0.0f;
-                        // d sam / dF[r][c] = ca x1[r] x2[c] - cb (l_c x1[r] [c<2] + r_r x2[c] [r<2])
-                        acc[0] += ca * u1 * u2 - cb * (l0 * u1 + r0 * u2);
-                        acc[1] += ca * u1 * v2 - cb * (l1 * u1 + r0 * v2);
-                        acc[2] += ca * u1 - cb * r0;
-                        acc[3] += ca * v1 * u2 - cb * (l0 * v1 + r1 * u2);
-                        acc[4] += ca * v1 * v2 - cb * (l1 * v1 + r1 * v2);
-                        acc[5] += ca * v1 - cb * r1;
-                        acc[6] += ca * u2 - cb * l0;
-                        acc[7] += ca * v2 - cb * l1;
-                        acc[8] += ca;
-                    }
+                for (int c = 0; c < PD_ITEM_VALS; ++c) acc2[c] = (v2f){0.0f, 0.0f};
+                const int npairs = (e.y + 127) >> 7;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < npairs)
+                        sampson_step2(mb[2 * j], mb[2 * j + 1], (lane + 128 * j) < e.y, (lane + 128 * j + 64) < e.y, Fm,
+                                      P.sampson_max, acc2);
                 }
+                float acc[PD_ITEM_VALS];
+#pragma unroll
+                for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = acc2[c].x + acc2[c].y;
 #pragma unroll
                 for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = wave_allsum(acc[c]);
                 if (k == 1) {
