@@ -340,12 +340,15 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
     const bool small_n = N <= PD_GGS_THREADS / 16;              // every frame has its own thread group
     const bool spare_wave = N * 16 <= (PD_GGS_WAVES - 1) * 64;   // the last wave is entirely idle in P3b
     const int n_inc = L.incoff[N];
+    // pair-level backward is possible when every incidence slot fits the LDS result buffer at once
+    const bool pair_path = n_inc <= PD_GGS_THREADS;
+    const int4 my_pair = (pair_path && tid < D.n_pairs) ? D.ptab[tid] : make_int4(0, 0, 0, 0);
     // this thread's incidence of chunk 0 (constant for the launch)
     const int4 my_inc = (tid < n_inc) ? (inc_lds ? L.inc[tid] : D.inc[tid]) : make_int4(0, 0, 0, 0);
     unsigned epoch = 0;
     int trace_row = 0;
-    const bool prof = P.prof != nullptr && blockIdx.x == 0 && wave == 1;   // a worker wave of WG 0
-    long long pt[6] = {0, 0, 0, 0, 0, 0}, pc = 0;
+    const bool prof = P.prof != nullptr && blockIdx.x == 0 && wave == P.prof_wave;   // one wave of WG 0
+    long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pc = 0, pq = 0;
 #define PD_PROF(i) do { if (prof) { const long long _n = __builtin_readcyclecounter(); pt[i] += _n - pc; pc = _n; } } while (0)
     const float inv_M = 1.0f / (float)D.M;
     for (int st = 0; st < P.n_stages; ++st) {
@@ -501,121 +504,243 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
             const bool need_rt = S.update_R || S.update_T;
             float fsum = 0.0f;                       // P3b accumulator of thread (frame, component)
             for (int c0 = 0; c0 < n_inc; c0 += PD_GGS_THREADS) {
-                const int q = c0 + tid;
-                float oR[9], ot[3], oA[4];
+                if (pair_path) {
+                    // ---- P3a (pair level): ONE thread per frame pair runs the shared backward chain once and
+                    // writes both sides' results straight into their incidence slots.  190 threads = 3 waves, one
+                    // per SIMD: cost is per wave-instruction, so this halves the critical path of the per-incidence
+                    // form (6 waves, two SIMDs carrying two waves each).
+                    if (tid < D.n_pairs) {
+                        const int pi = my_pair.x & 0xff, pj = my_pair.x >> 8, nit = my_pair.z;
+                        float G[9];
 #pragma unroll
-                for (int c = 0; c < 9; ++c) oR[c] = 0.0f;
-                ot[0] = ot[1] = ot[2] = 0.0f;
-                oA[0] = oA[1] = oA[2] = oA[3] = 0.0f;
-                if (q < n_inc) {
-                    const int4 ie = (c0 == 0) ? my_inc : (inc_lds ? L.inc[q] : D.inc[q]);   // (i, j, first item, n_items | side << 16)
-                    const int pi = ie.x, pj = ie.y, side = ie.w >> 16, nit = ie.w & 0xffff;
-                    float G[9];
+                        for (int c = 0; c < 9; ++c) G[c] = 0.0f;
+                        for (int u = 0; u < nit; ++u)
 #pragma unroll
-                    for (int c = 0; c < 9; ++c) G[c] = 0.0f;
-                    for (int u = 0; u < nit; ++u)
+                            for (int c = 0; c < 9; ++c) G[c] += L.item[(my_pair.y + u) * PD_ITEM_VALS + c];
+                        float Ri[9], Rj[9], ti[3], tj[3];
 #pragma unroll
-                        for (int c = 0; c < 9; ++c) G[c] += L.item[(ie.z + u) * PD_ITEM_VALS + c];
-                    float Ri[9], Rj[9], ti[3];
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) {
-                        Ri[c] = L.Rc[pi * 9 + c];
-                        Rj[c] = L.Rc[pj * 9 + c];
-                    }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) ti[c] = L.tc[pi * 3 + c];
-                    PairFwd f;
-                    {
-                        float tj[3];
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) tj[c] = L.tc[pj * 3 + c];
-                        pair_forward(Ri, ti, Rj, tj, f);
-                    }
-                    // Gf = dL/dFo = G^T ; gE = A Gf A^T  (A = [[a0,0,c0],[0,a1,c1],[0,0,1]])
-                    float AG[9], gE[9];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {   // AG = A Gf, Gf[r][c] = G[c][r]
-                        const float g0 = G[c * 3 + 0], g1 = G[c * 3 + 1], g2 = G[c * 3 + 2];
-                        AG[0 * 3 + c] = cam.a0 * g0 + cam.c0 * g2;
-                        AG[1 * 3 + c] = cam.a1 * g1 + cam.c1 * g2;
-                        AG[2 * 3 + c] = g2;
-                    }
-                    if (S.update_FL && side == 0) {
-                        // dL/dA = E A Gf^T + E^T A Gf, entries (0,0),(0,2),(1,1),(1,2); each pair once
-                        float AGt[9];   // A Gf^T, Gf^T = G
+                        for (int c = 0; c < 9; ++c) {
+                            Ri[c] = L.Rc[pi * 9 + c];
+                            Rj[c] = L.Rc[pj * 9 + c];
+                        }
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            const float g0 = G[0 * 3 + c], g1 = G[1 * 3 + c], g2 = G[2 * 3 + c];
-                            AGt[0 * 3 + c] = cam.a0 * g0 + cam.c0 * g2;
-                            AGt[1 * 3 + c] = cam.a1 * g1 + cam.c1 * g2;
-                            AGt[2 * 3 + c] = g2;
+                            ti[c] = L.tc[pi * 3 + c];
+                            tj[c] = L.tc[pj * 3 + c];
                         }
+                        PairFwd f;
+                        pair_forward(Ri, ti, Rj, tj, f);
+                        float AG[9];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {   // AG = A Gf, Gf[r][c] = G[c][r]
+                            const float g0 = G[c * 3 + 0], g1 = G[c * 3 + 1], g2 = G[c * 3 + 2];
+                            AG[0 * 3 + c] = cam.a0 * g0 + cam.c0 * g2;
+                            AG[1 * 3 + c] = cam.a1 * g1 + cam.c1 * g2;
+                            AG[2 * 3 + c] = g2;
+                        }
+                        float oA[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (S.update_FL) {   // dL/dA = E A Gf^T + E^T A Gf, entries (0,0),(0,2),(1,1),(1,2)
+                            float AGt[9];
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const float g0 = G[0 * 3 + c], g1 = G[1 * 3 + c], g2 = G[2 * 3 + c];
+                                AGt[0 * 3 + c] = cam.a0 * g0 + cam.c0 * g2;
+                                AGt[1 * 3 + c] = cam.a1 * g1 + cam.c1 * g2;
+                                AGt[2 * 3 + c] = g2;
+                            }
 #define PD_DA(r, c)                                                                                      \
     (f.E[(r)*3 + 0] * AGt[0 * 3 + (c)] + f.E[(r)*3 + 1] * AGt[1 * 3 + (c)] + f.E[(r)*3 + 2] * AGt[2 * 3 + (c)] + \
      f.E[0 * 3 + (r)] * AG[0 * 3 + (c)] + f.E[1 * 3 + (r)] * AG[1 * 3 + (c)] + f.E[2 * 3 + (r)] * AG[2 * 3 + (c)])
-                        oA[0] = PD_DA(0, 0);
-                        oA[1] = PD_DA(0, 2);
-                        oA[2] = PD_DA(1, 1);
-                        oA[3] = PD_DA(1, 2);
+                            oA[0] = PD_DA(0, 0);
+                            oA[1] = PD_DA(0, 2);
+                            oA[2] = PD_DA(1, 1);
+                            oA[3] = PD_DA(1, 2);
 #undef PD_DA
+                        }
+                        // side 1 = frame j (camera 2), side 0 = frame i (camera 1); one side at a time (register pressure)
+                        float4 *d0 = (float4 *)(L.pinc + (my_pair.w & 0xffff) * 16), *d1 = (float4 *)(L.pinc + (my_pair.w >> 16) * 16);
+                        if (need_rt) {
+                            float gE[9];
+#pragma unroll
+                            for (int r = 0; r < 3; ++r) {   // gE = AG A^T
+                                gE[r * 3 + 0] = AG[r * 3 + 0] * cam.a0 + AG[r * 3 + 2] * cam.c0;
+                                gE[r * 3 + 1] = AG[r * 3 + 1] * cam.a1 + AG[r * 3 + 2] * cam.c1;
+                                gE[r * 3 + 2] = AG[r * 3 + 2];
+                            }
+                            const float ex = f.Et[0], ey = f.Et[1], ez = f.Et[2];
+                            float gR12[9], gH[9];
+#pragma unroll
+                            for (int r = 0; r < 3; ++r) {   // gR12 = gE H^T
+                                const float g0 = gE[r * 3 + 0], g1 = gE[r * 3 + 1], g2 = gE[r * 3 + 2];
+                                gR12[r * 3 + 0] = -g1 * ez + g2 * ey;
+                                gR12[r * 3 + 1] = g0 * ez - g2 * ex;
+                                gR12[r * 3 + 2] = -g0 * ey + g1 * ex;
+                            }
+#pragma unroll
+                            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                                for (int c = 0; c < 3; ++c)   // gH = R12^T gE
+                                    gH[r * 3 + c] = f.R12[0 * 3 + r] * gE[0 * 3 + c] + f.R12[1 * 3 + r] * gE[1 * 3 + c] +
+                                                    f.R12[2 * 3 + r] * gE[2 * 3 + c];
+                            const float gEt[3] = {gH[2 * 3 + 1] - gH[1 * 3 + 2], gH[0 * 3 + 2] - gH[2 * 3 + 0],
+                                                  gH[1 * 3 + 0] - gH[0 * 3 + 1]};
+                            float gt12[3];
+#pragma unroll
+                            for (int a = 0; a < 3; ++a)
+                                gt12[a] = -(f.R12[a * 3 + 0] * gEt[0] + f.R12[a * 3 + 1] * gEt[1] + f.R12[a * 3 + 2] * gEt[2]);
+#pragma unroll
+                            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) gR12[a * 3 + c] += -f.t12[a] * gEt[c] - gt12[a] * ti[c];
+                            float oR[9];
+#pragma unroll
+                            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                                for (int c = 0; c < 3; ++c)   // gRc_j = gR12 Rc_i
+                                    oR[a * 3 + c] = gR12[a * 3 + 0] * Ri[0 * 3 + c] + gR12[a * 3 + 1] * Ri[1 * 3 + c] +
+                                                    gR12[a * 3 + 2] * Ri[2 * 3 + c];
+                            d1[0] = make_float4(oR[0], oR[1], oR[2], oR[3]);
+                            d1[1] = make_float4(oR[4], oR[5], oR[6], oR[7]);
+                            d1[2] = make_float4(oR[8], gt12[0], gt12[1], gt12[2]);          // gtc_j = gt12
+                            d1[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            float ot[3];
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) {
+                                ot[a] = -(f.R12[0 * 3 + a] * gt12[0] + f.R12[1 * 3 + a] * gt12[1] + f.R12[2 * 3 + a] * gt12[2]);   // -R12^T gt12
+#pragma unroll
+                                for (int c = 0; c < 3; ++c)   // gRc_i = gR12^T Rc_j
+                                    oR[a * 3 + c] = gR12[0 * 3 + a] * Rj[0 * 3 + c] + gR12[1 * 3 + a] * Rj[1 * 3 + c] +
+                                                    gR12[2 * 3 + a] * Rj[2 * 3 + c];
+                            }
+                            d0[0] = make_float4(oR[0], oR[1], oR[2], oR[3]);
+                            d0[1] = make_float4(oR[4], oR[5], oR[6], oR[7]);
+                            d0[2] = make_float4(oR[8], ot[0], ot[1], ot[2]);
+                        } else {
+                            const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            d1[0] = z4; d1[1] = z4; d1[2] = z4; d1[3] = z4;
+                            d0[0] = z4; d0[1] = z4; d0[2] = z4;
+                        }
+                        d0[3] = make_float4(oA[0], oA[1], oA[2], oA[3]);
                     }
-                    if (need_rt) {
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) {   // gE = AG A^T : gE[r][c] = sum_q AG[r][q] A[c][q]
-                            gE[r * 3 + 0] = AG[r * 3 + 0] * cam.a0 + AG[r * 3 + 2] * cam.c0;
-                            gE[r * 3 + 1] = AG[r * 3 + 1] * cam.a1 + AG[r * 3 + 2] * cam.c1;
-                            gE[r * 3 + 2] = AG[r * 3 + 2];
+                } else {
+                    const int q = c0 + tid;
+                    float oR[9], ot[3], oA[4];
+    #pragma unroll
+                    for (int c = 0; c < 9; ++c) oR[c] = 0.0f;
+                    ot[0] = ot[1] = ot[2] = 0.0f;
+                    oA[0] = oA[1] = oA[2] = oA[3] = 0.0f;
+                    if (q < n_inc) {
+                        const int4 ie = (c0 == 0) ? my_inc : (inc_lds ? L.inc[q] : D.inc[q]);   // (i, j, first item, n_items | side << 16)
+                        const int pi = ie.x, pj = ie.y, side = ie.w >> 16, nit = ie.w & 0xffff;
+                        float G[9];
+    #pragma unroll
+                        for (int c = 0; c < 9; ++c) G[c] = 0.0f;
+                        for (int u = 0; u < nit; ++u)
+    #pragma unroll
+                            for (int c = 0; c < 9; ++c) G[c] += L.item[(ie.z + u) * PD_ITEM_VALS + c];
+                        float Ri[9], Rj[9], ti[3];
+    #pragma unroll
+                        for (int c = 0; c < 9; ++c) {
+                            Ri[c] = L.Rc[pi * 9 + c];
+                            Rj[c] = L.Rc[pj * 9 + c];
                         }
-                        // E = R12 H : gR12 = gE H^T ; gH = R12^T gE
-                        const float ex = f.Et[0], ey = f.Et[1], ez = f.Et[2];
-                        float gR12[9], gH[9];
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) {   // (gE H^T)[r][c] = sum_q gE[r][q] H[c][q]
-                            const float g0 = gE[r * 3 + 0], g1 = gE[r * 3 + 1], g2 = gE[r * 3 + 2];
-                            gR12[r * 3 + 0] = -g1 * ez + g2 * ey;
-                            gR12[r * 3 + 1] = g0 * ez - g2 * ex;
-                            gR12[r * 3 + 2] = -g0 * ey + g1 * ex;
+    #pragma unroll
+                        for (int c = 0; c < 3; ++c) ti[c] = L.tc[pi * 3 + c];
+                        PairFwd f;
+                        {
+                            float tj[3];
+    #pragma unroll
+                            for (int c = 0; c < 3; ++c) tj[c] = L.tc[pj * 3 + c];
+                            pair_forward(Ri, ti, Rj, tj, f);
                         }
-#pragma unroll
-                        for (int r = 0; r < 3; ++r)
-#pragma unroll
-                            for (int c = 0; c < 3; ++c)
-                                gH[r * 3 + c] = f.R12[0 * 3 + r] * gE[0 * 3 + c] + f.R12[1 * 3 + r] * gE[1 * 3 + c] +
-                                                f.R12[2 * 3 + r] * gE[2 * 3 + c];
-                        const float gEt[3] = {gH[2 * 3 + 1] - gH[1 * 3 + 2], gH[0 * 3 + 2] - gH[2 * 3 + 0],
-                                              gH[1 * 3 + 0] - gH[0 * 3 + 1]};
-                        float gt12[3];
-#pragma unroll
-                        for (int a = 0; a < 3; ++a)
-                            gt12[a] = -(f.R12[a * 3 + 0] * gEt[0] + f.R12[a * 3 + 1] * gEt[1] + f.R12[a * 3 + 2] * gEt[2]);
-#pragma unroll
-                        for (int a = 0; a < 3; ++a)
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) gR12[a * 3 + c] += -f.t12[a] * gEt[c] - gt12[a] * ti[c];
-                        // side 1: frame is camera 2 (j): gtc_j = gt12 ; gRc_j = gR12 Rc_i
-                        // side 0: frame is camera 1 (i): gtc_i = -R12^T gt12 ; gRc_i = gR12^T Rc_j
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            const float t1 = gt12[a];
-                            const float t0 = -(f.R12[0 * 3 + a] * gt12[0] + f.R12[1 * 3 + a] * gt12[1] + f.R12[2 * 3 + a] * gt12[2]);
-                            ot[a] = side ? t1 : t0;
-#pragma unroll
+                        // Gf = dL/dFo = G^T ; gE = A Gf A^T  (A = [[a0,0,c0],[0,a1,c1],[0,0,1]])
+                        float AG[9], gE[9];
+    #pragma unroll
+                        for (int c = 0; c < 3; ++c) {   // AG = A Gf, Gf[r][c] = G[c][r]
+                            const float g0 = G[c * 3 + 0], g1 = G[c * 3 + 1], g2 = G[c * 3 + 2];
+                            AG[0 * 3 + c] = cam.a0 * g0 + cam.c0 * g2;
+                            AG[1 * 3 + c] = cam.a1 * g1 + cam.c1 * g2;
+                            AG[2 * 3 + c] = g2;
+                        }
+                        if (S.update_FL && side == 0) {
+                            // dL/dA = E A Gf^T + E^T A Gf, entries (0,0),(0,2),(1,1),(1,2); each pair once
+                            float AGt[9];   // A Gf^T, Gf^T = G
+    #pragma unroll
                             for (int c = 0; c < 3; ++c) {
-                                const float r1 = gR12[a * 3 + 0] * Ri[0 * 3 + c] + gR12[a * 3 + 1] * Ri[1 * 3 + c] +
-                                                 gR12[a * 3 + 2] * Ri[2 * 3 + c];
-                                const float r0 = gR12[0 * 3 + a] * Rj[0 * 3 + c] + gR12[1 * 3 + a] * Rj[1 * 3 + c] +
-                                                 gR12[2 * 3 + a] * Rj[2 * 3 + c];
-                                oR[a * 3 + c] = side ? r1 : r0;
+                                const float g0 = G[0 * 3 + c], g1 = G[1 * 3 + c], g2 = G[2 * 3 + c];
+                                AGt[0 * 3 + c] = cam.a0 * g0 + cam.c0 * g2;
+                                AGt[1 * 3 + c] = cam.a1 * g1 + cam.c1 * g2;
+                                AGt[2 * 3 + c] = g2;
+                            }
+    #define PD_DA(r, c)                                                                                      \
+        (f.E[(r)*3 + 0] * AGt[0 * 3 + (c)] + f.E[(r)*3 + 1] * AGt[1 * 3 + (c)] + f.E[(r)*3 + 2] * AGt[2 * 3 + (c)] + \
+         f.E[0 * 3 + (r)] * AG[0 * 3 + (c)] + f.E[1 * 3 + (r)] * AG[1 * 3 + (c)] + f.E[2 * 3 + (r)] * AG[2 * 3 + (c)])
+                            oA[0] = PD_DA(0, 0);
+                            oA[1] = PD_DA(0, 2);
+                            oA[2] = PD_DA(1, 1);
+                            oA[3] = PD_DA(1, 2);
+    #undef PD_DA
+                        }
+                        if (need_rt) {
+    #pragma unroll
+                            for (int r = 0; r < 3; ++r) {   // gE = AG A^T : gE[r][c] = sum_q AG[r][q] A[c][q]
+                                gE[r * 3 + 0] = AG[r * 3 + 0] * cam.a0 + AG[r * 3 + 2] * cam.c0;
+                                gE[r * 3 + 1] = AG[r * 3 + 1] * cam.a1 + AG[r * 3 + 2] * cam.c1;
+                                gE[r * 3 + 2] = AG[r * 3 + 2];
+                            }
+                            // E = R12 H : gR12 = gE H^T ; gH = R12^T gE
+                            const float ex = f.Et[0], ey = f.Et[1], ez = f.Et[2];
+                            float gR12[9], gH[9];
+    #pragma unroll
+                            for (int r = 0; r < 3; ++r) {   // (gE H^T)[r][c] = sum_q gE[r][q] H[c][q]
+                                const float g0 = gE[r * 3 + 0], g1 = gE[r * 3 + 1], g2 = gE[r * 3 + 2];
+                                gR12[r * 3 + 0] = -g1 * ez + g2 * ey;
+                                gR12[r * 3 + 1] = g0 * ez - g2 * ex;
+                                gR12[r * 3 + 2] = -g0 * ey + g1 * ex;
+                            }
+    #pragma unroll
+                            for (int r = 0; r < 3; ++r)
+    #pragma unroll
+                                for (int c = 0; c < 3; ++c)
+                                    gH[r * 3 + c] = f.R12[0 * 3 + r] * gE[0 * 3 + c] + f.R12[1 * 3 + r] * gE[1 * 3 + c] +
+                                                    f.R12[2 * 3 + r] * gE[2 * 3 + c];
+                            const float gEt[3] = {gH[2 * 3 + 1] - gH[1 * 3 + 2], gH[0 * 3 + 2] - gH[2 * 3 + 0],
+                                                  gH[1 * 3 + 0] - gH[0 * 3 + 1]};
+                            float gt12[3];
+    #pragma unroll
+                            for (int a = 0; a < 3; ++a)
+                                gt12[a] = -(f.R12[a * 3 + 0] * gEt[0] + f.R12[a * 3 + 1] * gEt[1] + f.R12[a * 3 + 2] * gEt[2]);
+    #pragma unroll
+                            for (int a = 0; a < 3; ++a)
+    #pragma unroll
+                                for (int c = 0; c < 3; ++c) gR12[a * 3 + c] += -f.t12[a] * gEt[c] - gt12[a] * ti[c];
+                            // side 1: frame is camera 2 (j): gtc_j = gt12 ; gRc_j = gR12 Rc_i
+                            // side 0: frame is camera 1 (i): gtc_i = -R12^T gt12 ; gRc_i = gR12^T Rc_j
+    #pragma unroll
+                            for (int a = 0; a < 3; ++a) {
+                                const float t1 = gt12[a];
+                                const float t0 = -(f.R12[0 * 3 + a] * gt12[0] + f.R12[1 * 3 + a] * gt12[1] + f.R12[2 * 3 + a] * gt12[2]);
+                                ot[a] = side ? t1 : t0;
+    #pragma unroll
+                                for (int c = 0; c < 3; ++c) {
+                                    const float r1 = gR12[a * 3 + 0] * Ri[0 * 3 + c] + gR12[a * 3 + 1] * Ri[1 * 3 + c] +
+                                                     gR12[a * 3 + 2] * Ri[2 * 3 + c];
+                                    const float r0 = gR12[0 * 3 + a] * Rj[0 * 3 + c] + gR12[1 * 3 + a] * Rj[1 * 3 + c] +
+                                                     gR12[2 * 3 + a] * Rj[2 * 3 + c];
+                                    oR[a * 3 + c] = side ? r1 : r0;
+                                }
                             }
                         }
                     }
+                    if (prof) { pq = __builtin_readcyclecounter(); pt[6] += pq - pc; }
+                    float4 *dst = (float4 *)(L.pinc + tid * 16);
+                    dst[0] = make_float4(oR[0], oR[1], oR[2], oR[3]);
+                    dst[1] = make_float4(oR[4], oR[5], oR[6], oR[7]);
+                    dst[2] = make_float4(oR[8], ot[0], ot[1], ot[2]);
+                    dst[3] = make_float4(oA[0], oA[1], oA[2], oA[3]);
                 }
-                float4 *dst = (float4 *)(L.pinc + tid * 16);
-                dst[0] = make_float4(oR[0], oR[1], oR[2], oR[3]);
-                dst[1] = make_float4(oR[4], oR[5], oR[6], oR[7]);
-                dst[2] = make_float4(oR[8], ot[0], ot[1], ot[2]);
-                dst[3] = make_float4(oA[0], oA[1], oA[2], oA[3]);
                 __syncthreads();
+                if (prof) { const long long n_ = __builtin_readcyclecounter(); pt[7] += n_ - pq; pq = n_; }
                 // ---- P3b: per-frame sums over the incidences of this chunk, fixed (ascending) order ----
                 if (small_n) {
                     if (fb_n < N) {
@@ -659,6 +784,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         }
                     }
                 }
+                if (prof) { const long long n_ = __builtin_readcyclecounter(); pt[8] += n_ - pq; pq = n_; }
                 if (c0 + PD_GGS_THREADS < n_inc) __syncthreads();   // pinc is rewritten by the next chunk
             }
             if (!spare_wave && wave == 0) {
@@ -823,7 +949,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
         if (P.eval_only) break;
     }
     if (prof && lane == 0) {
-        for (int i = 0; i < 6; ++i) P.prof[i] = pt[i];
+        for (int i = 0; i < 10; ++i) P.prof[i] = pt[i];
     }
     if (own && wg == 0 && !P.eval_only) {
 #pragma unroll
@@ -920,6 +1046,20 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
         }
     }
     inc_off[N] = (int)inc.size();
+    // per-pair table: positions of the pair's two incidences (side 0 under frame i, side 1 under frame j)
+    std::vector<int4> ptab(n_pairs);
+    {
+        std::vector<int> pos0(n_pairs, 0), pos1(n_pairs, 0);
+        int q = 0;
+        for (int n = 0; n < N; ++n)
+            for (int p = 0; p < n_pairs; ++p) {
+                if (pair_ij[p].x == n) pos0[p] = q++;
+                if (pair_ij[p].y == n) pos1[p] = q++;
+            }
+        for (int p = 0; p < n_pairs; ++p)
+            ptab[p] = make_int4(pair_ij[p].x | (pair_ij[p].y << 8), pair_item_off[p], pair_item_off[p + 1] - pair_item_off[p],
+                                pos0[p] | (pos1[p] << 16));
+    }
 
     // one blob: pts | pair_ij | pair_item_off | items | inc_off | inc   (16-byte aligned pieces)
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -929,7 +1069,8 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     const size_t o_itm = al(o_pio + sizeof(int) * pair_item_off.size());
     const size_t o_ino = al(o_itm + sizeof(int4) * items.size());
     const size_t o_inc = al(o_ino + sizeof(int) * inc_off.size());
-    const size_t total = al(o_inc + sizeof(int4) * inc.size());
+    const size_t o_ptb = al(o_inc + sizeof(int4) * inc.size());
+    const size_t total = al(o_ptb + sizeof(int4) * ptab.size());
     std::vector<char> host(total, 0);
     memcpy(host.data() + o_pts, pts.data(), sizeof(float4) * pts.size());
     memcpy(host.data() + o_pij, pair_ij.data(), sizeof(int2) * pair_ij.size());
@@ -937,6 +1078,7 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     memcpy(host.data() + o_itm, items.data(), sizeof(int4) * items.size());
     memcpy(host.data() + o_ino, inc_off.data(), sizeof(int) * inc_off.size());
     memcpy(host.data() + o_inc, inc.data(), sizeof(int4) * inc.size());
+    memcpy(host.data() + o_ptb, ptab.data(), sizeof(int4) * ptab.size());
     PdSeqHost &h = eng->seqs[seq];
     PD_HIP_CHECK(hipMalloc(&h.blob, total));
     PD_HIP_CHECK(hipMemcpy(h.blob, host.data(), total, hipMemcpyHostToDevice));
@@ -947,6 +1089,7 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     h.desc.items = (const int4 *)(base + o_itm);
     h.desc.inc_off = (const int *)(base + o_ino);
     h.desc.inc = (const int4 *)(base + o_inc);
+    h.desc.ptab = (const int4 *)(base + o_ptb);
     h.desc.M = (int)M;
     h.desc.n_pairs = n_pairs;
     h.desc.n_items = n_items;
@@ -1038,6 +1181,7 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     P.xchg_stride = (int)eng->xchg_granules;
     P.err_flag = eng->d_err;
     P.prof = eng->ggs_prof_on ? (long long *)(eng->d_err + 2) : nullptr;
+    P.prof_wave = eng->ggs_prof_on > 0 ? (eng->ggs_prof_on - 1) & 7 : 1;
     if (k > 1) {
         // tags restart at 1 every launch: zero every polled word first (guide G16 "re-initialise every call")
         const size_t n_zero = 2 * eng->xchg_granules * B;

@@ -39,6 +39,8 @@ struct PdSeqDesc {
     const int4 *items;         // [n_items] (pair, first match, match count, 0)
     const int *inc_off;        // [n_frames + 1] incidence CSR: pairs touching frame n
     const int4 *inc;           // [2 * n_pairs] (i, j, first item, n_items | side << 16); side 0: frame is i
+    const int4 *ptab;          // [n_pairs] (i | j << 8, first item, n_items, pos_side0 | pos_side1 << 16): where the
+                               //   two incidences of the pair sit in `inc` (pair-level backward writes there)
     int M, n_pairs, n_items, n_frames;
     float sc, cx, cy;          // min(h, w) / 2, w / 2, h / 2 (opencv_from_cameras_projection)
     int pad;
@@ -65,7 +67,8 @@ struct PdGgsParams {
     unsigned long long *xchg;  // [B, 2, max_items * 12] tagged granules (k > 1)
     int xchg_stride;           // granules per (sequence, slot)
     unsigned int *err_flag;    // device word: nonzero = a bounded spin gave up
-    long long *prof;           // [6] optional phase cycle counters (debug), else null
+    long long *prof;           // optional phase cycle counters (debug), else null
+    int prof_wave;             // which wave of workgroup 0 records them
 };
 
 struct PdSeqHost {

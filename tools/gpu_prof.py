@@ -16,18 +16,18 @@ for B in (8,):
         md = synth.make_matches(enc, H, W, per_pair=300, seed=2000 + b)
         eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
     x0 = torch.cat([synth.perturb_pose(synth.make_cameras(N, seed=2000 + b), seed=7 + b) for b in range(B)]).to(dev)
-    for k in (0, 16, 12):
+    for k, pw in ((0, 2), (0, 6), (12, 2), (12, 6)):
         cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=k)
-        eng.ggs_prof(True)
+        eng.ggs_prof(pw)
         eng.ggs_guide(x0, 0, cfg)
         torch.cuda.synchronize()
         t0 = time.time()
         eng.ggs_guide(x0, 0, cfg)
         torch.cuda.synchronize()
         dt = time.time() - t0
-        pr = eng.ggs_prof(True)
+        pr = eng.ggs_prof(pw)
         tot = sum(pr[k2] for k2 in ("P1", "P2", "xchg", "P3", "P4"))
-        print(f"B={B} k={k}: {dt*1e3:.2f} ms / 700 it = {dt/700*1e6:.2f} us/it; cycles/it P1 {pr['P1']:.0f} P2 {pr['P2']:.0f} xchg {pr['xchg']:.0f} P3 {pr['P3']:.0f} P4 {pr['P4']:.0f} total {tot:.0f} (iters {pr['iters']}) -> {tot/(dt/700*1e6):.0f} cycles/us", flush=True)
+        print(f"B={B} k={k} wave={pw-1}: [P3a {pr['P3a']:.0f} wait {pr['P3_wait1']:.0f} P3b {pr['P3b']:.0f}] {dt*1e3:.2f} ms / 700 it = {dt/700*1e6:.2f} us/it; cycles/it P1 {pr['P1']:.0f} P2 {pr['P2']:.0f} xchg {pr['xchg']:.0f} P3 {pr['P3']:.0f} P4 {pr['P4']:.0f} total {tot:.0f} (iters {pr['iters']}) -> {tot/(dt/700*1e6):.0f} cycles/us", flush=True)
     eng.ggs_prof(False)
 for (B, N2) in [(1, 20), (8, 20)]:
     z = synth.make_z(B, N2).to(dev)
