@@ -427,13 +427,22 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 float Fm[9];
 #pragma unroll
                 for (int c = 0; c < 9; ++c) Fm[c] = L.F[s * 9 + c];
-                float4 mb[8];
-                if (resident) {
+                // two 64-match steps per pass: lane handles matches lane + 64*(2j) and lane + 64*(2j+1) together
+                v2f acc2[PD_ITEM_VALS];
 #pragma unroll
-                    for (int st = 0; st < 8; ++st) mb[st] = mres[st];
+                for (int c = 0; c < PD_ITEM_VALS; ++c) acc2[c] = (v2f){0.0f, 0.0f};
+                const int npairs = (e.y + 127) >> 7;
+                if (resident) {   // straight from the resident registers (no copies)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j < npairs)
+                            sampson_step2(mres[2 * j], mres[2 * j + 1], (lane + 128 * j) < e.y, (lane + 128 * j + 64) < e.y, Fm,
+                                          P.sampson_max, acc2);
+                    }
                 } else {
                     // stream this item: all (<= 8) lines in flight at once, indices clamped (no
                     // predicated loads), out-of-range lanes are masked in the arithmetic instead
+                    float4 mb[8];
                     const float4 *pts = D.pts + e.x;
                     const int last = e.y - 1;
 #pragma unroll
@@ -441,17 +450,12 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         const int m = lane + 64 * st;
                         mb[st] = pts[m < e.y ? m : last];
                     }
-                }
-                // two 64-match steps per pass: lane handles matches lane + 64*(2j) and lane + 64*(2j+1) together
-                v2f acc2[PD_ITEM_VALS];
 #pragma unroll
-                for (int c = 0; c < PD_ITEM_VALS; ++c) acc2[c] = (v2f){0.0f, 0.0f};
-                const int npairs = (e.y + 127) >> 7;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j < npairs)
-                        sampson_step2(mb[2 * j], mb[2 * j + 1], (lane + 128 * j) < e.y, (lane + 128 * j + 64) < e.y, Fm,
-                                      P.sampson_max, acc2);
+                    for (int j = 0; j < 4; ++j) {
+                        if (j < npairs)
+                            sampson_step2(mb[2 * j], mb[2 * j + 1], (lane + 128 * j) < e.y, (lane + 128 * j + 64) < e.y, Fm,
+                                          P.sampson_max, acc2);
+                    }
                 }
                 float acc[PD_ITEM_VALS];
 #pragma unroll
