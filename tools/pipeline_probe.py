@@ -45,7 +45,7 @@ def run(K, depth):
     return dt, its, outs
 
 
-for kk in (16, 14, 12, 10, 8):
+for kk in (16, 12):
     cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=kk)
     for depth in (2,):
         run(2, depth)
