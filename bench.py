@@ -131,13 +131,19 @@ def cpu_baseline(budget_s: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--seqs-per-gpu", type=int, default=SEQS_PER_GPU)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--pipeline-depth", type=int, default=2,
+    ap.add_argument("--ggs-slots", type=int, default=2,
+                    help="how many of the batches in flight may be in their guided (GGS) half at once")
+    ap.add_argument("--unguided-streams", type=int, default=2,
+                    help="streams for the unguided halves (two halves side by side fill the CUs the guided kernels leave free)")
+    ap.add_argument("--ggs-wgs", type=int, default=0, help="override GGS workgroups per sequence (0 = from the slot count)")
+    ap.add_argument("--pipeline-depth", type=int, default=4,
                     help="engine contexts / HIP streams per GPU; consecutive passes (different batches) overlap: the next "
                          "batch's unguided denoiser steps run on the CUs the persistent GGS kernel leaves free. 1 = serial")
+    ap.add_argument("--trace", action="store_true", help="print the pipeline timeline (per-batch phase times) to stderr")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0, help="CPU seconds for the cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -161,29 +167,35 @@ def main():
     assert g1 - g0 == B
     diff = synth.make_diffuser(seed=0).to(dev)
     depth = max(1, args.pipeline_depth)
+    slots = min(depth, max(1, args.ggs_slots))
     from posediffusion_amd.engine import PoseEngine
     from posediffusion_amd.host import denoiser_state
+    from posediffusion_amd.pipeline import SamplingPipeline
     eng = get_engine(diff.model, diff, B, N_FRAMES)
     tables = {k: v for k, v in diff.named_buffers(recurse=False)}
     engines = [eng] + [PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=B, max_N=N_FRAMES) for _ in range(depth - 1)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+    pipe = SamplingPipeline(engines, slots, dev, unguided_streams=args.unguided_streams, trace=args.trace)
     # one resident batch per context (different sequences: seeds offset by the global batch size)
     inputs = [build_inputs(engines[j], diff, B, dev, seed0=g0 + j * total) for j in range(depth)]
     z, noise = inputs[0]
     # GGS workgroups per sequence: alone on the chip -> one work item per wave (24 WGs/sequence, lowest latency);
-    # with `depth` batches in flight each batch's persistent GGS kernel gets an equal share of 192 CUs so that
-    # the kernels of different batches run CONCURRENTLY (64 CUs stay free for the other batches' denoiser steps)
-    wgs = 0 if depth == 1 else max(1, 192 // (B * depth))
+    # pipelined -> the `slots` batches that may be in their guided half share 192 CUs so that their persistent
+    # kernels run CONCURRENTLY, and 64 CUs stay free for the unguided halves of the other batches in flight
+    wgs = args.ggs_wgs if args.ggs_wgs > 0 else pipe.wgs_per_seq(B)
     cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=wgs)
     use_graph = not args.no_graph
     torch.cuda.synchronize()
 
     def one_step(i):
-        j = i % depth
-        with torch.cuda.stream(streams[j]):
-            pose, _, stats = engines[j].sample(inputs[j][0], inputs[j][1], COND_START, cfg, use_graph=use_graph, want_process=False)
-            return shard.gather_poses(pose, total), stats
+        j = pipe.next_context()
+        pend = pipe.submit(inputs[j][0], inputs[j][1], COND_START, cfg, use_graph=use_graph, want_process=False)
+        return pend.pose, pend.stats
 
+    for j in range(depth):          # setup: every context captures its hipGraphs before anything is timed
+        with torch.cuda.stream(pipe.u_stream):
+            out = engines[j].sample(inputs[j][0], inputs[j][1], COND_START, cfg, use_graph=use_graph, want_process=False, phase=1)
+            engines[j].sample(inputs[j][0], inputs[j][1], COND_START, cfg, use_graph=use_graph, want_process=False, phase=2, out=out)
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
@@ -192,25 +204,32 @@ def main():
     t0 = time.perf_counter()
     results = [one_step(i) for i in range(args.steps)]
     torch.cuda.synchronize()
+    # the one data-path collective: every rank's poses of all K passes in ONE all_gather over xGMI (still timed)
+    gathered = shard.gather_poses(torch.stack([r[0] for r in results], dim=1).contiguous(), total)   # [total, K, N, 9]
+    torch.cuda.synchronize()
     shard.barrier()
     torch.cuda.synchronize()
     dt = shard.max_over_ranks(time.perf_counter() - t0, dev)
     for e in engines:
         e.check_async()
-    poses, stats = results[-1]
+    if args.trace and rank == 0:
+        for i, (a, b2, c, d) in enumerate(pipe.timeline()):
+            print(f"  sub {i:2d}: U {a:7.1f} -> {b2:7.1f} ({b2 - a:5.1f})   G {c:7.1f} -> {d:7.1f} ({d - c:5.1f})", file=sys.stderr)
+    assert gathered.shape[0] == total and gathered.shape[1] == args.steps
     # un-overlapped latency of one pass (outside the timed region, reported next to the throughput)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    with torch.cuda.stream(streams[0]):
-        engines[0].sample(z, noise, COND_START, cfg, use_graph=use_graph, want_process=False)
-    torch.cuda.synchronize()
-    pass_latency_ms = (time.perf_counter() - t1) * 1e3
+    for rep in range(2):        # the first call captures the whole-loop graph
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        with torch.cuda.stream(pipe.u_stream):
+            engines[0].sample(z, noise, COND_START, cfg, use_graph=use_graph, want_process=False)
+        torch.cuda.synchronize()
+        pass_latency_ms = (time.perf_counter() - t1) * 1e3
     ms_per_step = dt / args.steps * 1e3
     value = total * args.steps / dt
 
     # every guided step must have run its full 700 iterations (no data-dependent early exit skipped work)
     iters = torch.stack([r[1][:, :, :, 1].sum(dim=(0, 2)).cpu() for r in results])    # [pass, local sequence]
-    finite = all(bool(torch.isfinite(r[0]).all().item()) for r in results)
+    finite = bool(torch.isfinite(gathered).all().item())
 
     # ---- roofline of the dominant kernel + the denoiser step, timed with hipEvents on the launch stream
     ggs_ms = eng.time_kernel(1, B, N_FRAMES, cfg, reps=3)
@@ -233,7 +252,7 @@ def main():
                         "unguided model mean at t=9",
             "sequences_per_gpu": B, "frames": N_FRAMES, "matches_per_sequence": M, "diffusion_steps": 100,
             "ggs_iterations_per_sequence_run": float(iters.min().item()), "hip_graph": use_graph,
-            "pipeline_depth": depth, "pass_latency_ms_unpipelined": pass_latency_ms, "ggs_workgroups_per_sequence": wgs or 24,
+            "pipeline_depth": depth, "ggs_slots": slots, "unguided_streams": len(pipe.u_streams), "pass_latency_ms_unpipelined": pass_latency_ms, "ggs_workgroups_per_sequence": wgs or 24,
             "parallelism": f"dp{world} (independent sequences, one final all_gather)", "outputs_finite": finite,
         },
         "roofline": {

@@ -171,6 +171,23 @@ int pd_sample(pd_engine *eng, const float *z, const float *noise, int B, int N, 
               const pd_ggs_cfg *ggs, float *pose_out, float *process_out, float *stats_out,
               int use_graph, void *stream);
 
+/* The same loop in two halves, for callers that software-pipeline several batches (one engine
+ * and one stream per batch in flight): the unguided steps t = T-1 .. cond_start_step need few
+ * CUs, the guided steps t < cond_start_step hold wgs_per_seq CUs per sequence for milliseconds
+ * (persistent, co-resident workgroups), so a scheduler gates PD_PHASE_GUIDED on an event while
+ * PD_PHASE_UNGUIDED of later batches runs beside it (posediffusion_amd/pipeline.py).
+ *   PD_PHASE_ALL      = pd_sample
+ *   PD_PHASE_UNGUIDED : uploads z / noise and runs the unguided steps; pose_out is not written
+ *   PD_PHASE_GUIDED   : continues from the engine's state of the preceding PD_PHASE_UNGUIDED call
+ *                       with the same arguments, then writes pose_out / process_out / stats_out
+ * Both halves must be issued on the same stream (or ordered by the caller). */
+#define PD_PHASE_ALL 0
+#define PD_PHASE_UNGUIDED 1
+#define PD_PHASE_GUIDED 2
+int pd_sample_phase(pd_engine *eng, const float *z, const float *noise, int B, int N, int cond_start_step,
+                    const pd_ggs_cfg *ggs, int phase, float *pose_out, float *process_out, float *stats_out,
+                    int use_graph, void *stream);
+
 /* Final decode pose_encoding_to_camera (camera_transform.py:64-105): enc[B*N,9] ->
  * R[B*N,9] row-major 3x3, T[B*N,3], focal[B*N,2] (PyTorch3D NDC).  DEVICE pointers. */
 int pd_pose_to_camera(pd_engine *eng, const float *enc, int n_cameras, float *R_out, float *T_out,

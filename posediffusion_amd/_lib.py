@@ -60,6 +60,7 @@ SIGNATURES = {
     "pd_ggs_optimize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp]),
     "pd_ggs_loss_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp]),
     "pd_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp, _i, _vp]),
+    "pd_sample_phase": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _i, _vp, _vp, _vp, _i, _vp]),
     "pd_pose_to_camera": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "pd_time_kernel": (_i, [_vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _i, C.POINTER(C.c_float), _vp]),
     "pd_check_async_error": (_i, [_vp]),

@@ -245,11 +245,12 @@ extern "C" int pd_ggs_loss_grad(pd_engine *eng, const float *x, int B, int N, in
 // ---- whole sampler ------------------------------------------------------------------------------
 // Issues every launch of p_sample_loop on `s`, reading/writing only engine-owned buffers (so the
 // same code can be captured into a graph and replayed).
-static int issue_loop(pd_engine *eng, int B, int N, int cond_start, const pd_ggs_cfg *ggs, bool want_stats, hipStream_t s) {
+static int issue_loop(pd_engine *eng, int B, int N, int cond_start, const pd_ggs_cfg *ggs, bool want_stats, int step_begin,
+                      int step_end, hipStream_t s) {
     const int T = eng->timesteps;
     const size_t bn9 = (size_t)B * N * 9;
     float *proc = eng->d_process;
-    for (int step = 0; step < T; ++step) {
+    for (int step = step_begin; step < step_end; ++step) {
         const int t = T - 1 - step;                               // reversed(range(T))  :296
         const float *x = proc + (size_t)step * bn9;
         float *xn = proc + (size_t)(step + 1) * bn9;
@@ -272,12 +273,12 @@ static int issue_loop(pd_engine *eng, int B, int N, int cond_start, const pd_ggs
 
 static bool same_cfg(const pd_ggs_cfg &a, const pd_ggs_cfg &b) { return memcmp(&a, &b, sizeof(a)) == 0; }
 
-extern "C" int pd_sample(pd_engine *eng, const float *z, const float *noise, int B, int N, int cond_start_step,
-                         const pd_ggs_cfg *ggs, float *pose_out, float *process_out, float *stats_out, int use_graph,
-                         void *stream) {
+extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *noise, int B, int N, int cond_start_step,
+                               const pd_ggs_cfg *ggs, int phase, float *pose_out, float *process_out, float *stats_out,
+                               int use_graph, void *stream) {
     if (!eng || !z || !noise || !pose_out || B <= 0 || B > eng->max_B || N <= 0 || N > eng->max_N ||
-        cond_start_step < 0 || cond_start_step > eng->timesteps) {
-        pd_set_error("pd_sample: invalid arguments (B=%d N=%d cond_start_step=%d)", B, N, cond_start_step);
+        cond_start_step < 0 || cond_start_step > eng->timesteps || phase < PD_PHASE_ALL || phase > PD_PHASE_GUIDED) {
+        pd_set_error("pd_sample: invalid arguments (B=%d N=%d cond_start_step=%d phase=%d)", B, N, cond_start_step, phase);
         return PD_ERR_INVALID_ARG;
     }
     if (ggs) {
@@ -296,11 +297,19 @@ extern "C" int pd_sample(pd_engine *eng, const float *z, const float *noise, int
     const size_t bn9 = (size_t)B * N * 9;
     const bool has_ggs = ggs && cond_start_step > 0;
     const bool want_stats = has_ggs && stats_out;
-    PD_HIP_CHECK(hipMemcpyAsync(eng->d_z, z, sizeof(float) * B * N * eng->z_dim, hipMemcpyDeviceToDevice, s));
-    PD_HIP_CHECK(hipMemcpyAsync(eng->d_noise, noise, sizeof(float) * (T + 1) * bn9, hipMemcpyDeviceToDevice, s));
-    PD_HIP_CHECK(hipMemcpyAsync(eng->d_process, noise, sizeof(float) * bn9, hipMemcpyDeviceToDevice, s));   // :289
-    if (!use_graph) {
-        int rc = issue_loop(eng, B, N, cond_start_step, has_ggs ? ggs : nullptr, true, s);
+    // the unguided steps come first (t = T-1 .. cond_start), the guided ones last (t < cond_start, :270)
+    const int split = has_ggs ? T - cond_start_step : T;
+    const int step_begin = phase == PD_PHASE_GUIDED ? split : 0;
+    const int step_end = phase == PD_PHASE_UNGUIDED ? split : T;
+    if (phase != PD_PHASE_GUIDED) {
+        PD_HIP_CHECK(hipMemcpyAsync(eng->d_z, z, sizeof(float) * B * N * eng->z_dim, hipMemcpyDeviceToDevice, s));
+        PD_HIP_CHECK(hipMemcpyAsync(eng->d_noise, noise, sizeof(float) * (T + 1) * bn9, hipMemcpyDeviceToDevice, s));
+        PD_HIP_CHECK(hipMemcpyAsync(eng->d_process, noise, sizeof(float) * bn9, hipMemcpyDeviceToDevice, s));   // :289
+    }
+    if (step_begin == step_end) {
+        // nothing to run in this phase
+    } else if (!use_graph) {
+        int rc = issue_loop(eng, B, N, cond_start_step, has_ggs ? ggs : nullptr, true, step_begin, step_end, s);
         if (rc) return rc;
     } else {
         pd_engine::GraphKey key;
@@ -309,18 +318,19 @@ extern "C" int pd_sample(pd_engine *eng, const float *z, const float *noise, int
         key.N = N;
         key.cond_start = has_ggs ? cond_start_step : 0;
         key.has_ggs = has_ggs;
+        key.phase = phase;
         if (has_ggs) key.cfg = *ggs;
         hipGraphExec_t exec = nullptr;
         for (auto &g : eng->graphs)
             if (g.first.B == B && g.first.N == N && g.first.cond_start == key.cond_start && g.first.has_ggs == key.has_ggs &&
-                same_cfg(g.first.cfg, key.cfg))
+                g.first.phase == phase && same_cfg(g.first.cfg, key.cfg))
                 exec = g.second;
         if (!exec) {
             // capture on a private stream so the caller's stream state is untouched
             if (!eng->own_stream) PD_HIP_CHECK(hipStreamCreateWithFlags(&eng->own_stream, hipStreamNonBlocking));
             hipGraph_t graph = nullptr;
             PD_HIP_CHECK(hipStreamBeginCapture(eng->own_stream, hipStreamCaptureModeThreadLocal));
-            int rc = issue_loop(eng, B, N, cond_start_step, has_ggs ? ggs : nullptr, true, eng->own_stream);
+            int rc = issue_loop(eng, B, N, cond_start_step, has_ggs ? ggs : nullptr, true, step_begin, step_end, eng->own_stream);
             hipError_t ce = hipStreamEndCapture(eng->own_stream, &graph);
             if (rc) {
                 if (graph) (void)hipGraphDestroy(graph);
@@ -333,6 +343,7 @@ extern "C" int pd_sample(pd_engine *eng, const float *z, const float *noise, int
         }
         PD_HIP_CHECK(hipGraphLaunch(exec, s));
     }
+    if (phase == PD_PHASE_UNGUIDED) return PD_OK;   // results are copied out by the guided phase
     PD_HIP_CHECK(hipMemcpyAsync(pose_out, eng->d_process + (size_t)T * bn9, sizeof(float) * bn9, hipMemcpyDeviceToDevice, s));
     if (process_out)
         PD_HIP_CHECK(hipMemcpyAsync(process_out, eng->d_process, sizeof(float) * (T + 1) * bn9, hipMemcpyDeviceToDevice, s));
@@ -340,6 +351,13 @@ extern "C" int pd_sample(pd_engine *eng, const float *z, const float *noise, int
         PD_HIP_CHECK(hipMemcpyAsync(stats_out, eng->d_stats, sizeof(float) * (size_t)cond_start_step * B * 5 * 4,
                                     hipMemcpyDeviceToDevice, s));
     return PD_OK;
+}
+
+extern "C" int pd_sample(pd_engine *eng, const float *z, const float *noise, int B, int N, int cond_start_step,
+                         const pd_ggs_cfg *ggs, float *pose_out, float *process_out, float *stats_out, int use_graph,
+                         void *stream) {
+    return pd_sample_phase(eng, z, noise, B, N, cond_start_step, ggs, PD_PHASE_ALL, pose_out, process_out, stats_out, use_graph,
+                           stream);
 }
 
 // ---- measurement helper -------------------------------------------------------------------------

@@ -100,7 +100,7 @@ struct pd_engine {
     float *d_z = nullptr, *d_noise = nullptr, *d_process = nullptr, *d_mean = nullptr, *d_stats = nullptr;
     // graph cache
     struct GraphKey {
-        int B, N, cond_start, has_ggs;
+        int B, N, cond_start, has_ggs, phase;
         pd_ggs_cfg cfg;
     };
     std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;

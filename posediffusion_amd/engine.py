@@ -196,23 +196,31 @@ class PoseEngine:
 
     # ---------------------------------------------------------------- sampler
     def sample(self, z: torch.Tensor, noise: torch.Tensor, cond_start_step: int = 0, ggs_cfg=None,
-               use_graph: bool = True, want_process: bool = True):
+               use_graph: bool = True, want_process: bool = True, phase: int = 0, out=None):
         """GaussianDiffusion.sample (models/gaussian_diffuser.py:284-306).  ``noise`` is
-        [T+1,B,N,9]: noise[0] the initial randn, noise[1+k] the randn_like of step t = T-1-k."""
+        [T+1,B,N,9]: noise[0] the initial randn, noise[1+k] the randn_like of step t = T-1-k.
+
+        ``phase`` (pd_engine.h PD_PHASE_*): 0 = the whole loop; 1 = inputs + unguided steps only,
+        2 = guided steps + results.  A phase-2 call takes the ``(pose, process, stats)`` tuple the
+        phase-1 call returned as ``out`` (the buffers are written by phase 2 only)."""
         B, N, _ = z.shape
         T = self.timesteps
         z = self._f32(z, (B, N, self.z_dim))
         noise = self._f32(noise, (T + 1, B, N, 9))
-        pose = torch.empty(B, N, 9, device=self.device)
-        process = torch.empty(T + 1, B, N, 9, device=self.device) if want_process else None
         has_ggs = ggs_cfg is not None and cond_start_step > 0
         c = None
         if has_ggs:
             c = ggs_cfg if isinstance(ggs_cfg, _lib.pd_ggs_cfg) else make_ggs_cfg(ggs_cfg)
-        stats = torch.zeros(max(cond_start_step, 1), B, 5, 4, device=self.device) if has_ggs else None
-        _lib.check(self.lib.pd_sample(self._h, z.data_ptr(), noise.data_ptr(), B, N, int(cond_start_step),
-                                      C.byref(c) if c is not None else None, pose.data_ptr(), _ptr(process), _ptr(stats),
-                                      int(bool(use_graph)), self._stream()), "pd_sample")
+        if out is None:
+            pose = torch.empty(B, N, 9, device=self.device)
+            process = torch.empty(T + 1, B, N, 9, device=self.device) if want_process else None
+            stats = torch.zeros(max(cond_start_step, 1), B, 5, 4, device=self.device) if has_ggs else None
+        else:
+            pose, process, stats = out
+        _lib.check(self.lib.pd_sample_phase(self._h, z.data_ptr(), noise.data_ptr(), B, N, int(cond_start_step),
+                                            C.byref(c) if c is not None else None, int(phase), pose.data_ptr(),
+                                            _ptr(process), _ptr(stats), int(bool(use_graph)), self._stream()),
+                   "pd_sample_phase")
         return pose, process, stats
 
     def pose_to_camera(self, enc: torch.Tensor):

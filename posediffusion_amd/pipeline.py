@@ -1,0 +1,212 @@
+"""Software pipeline over independent batches of sequences on ONE GPU.
+
+The reference samples one sequence at a time (test.py:153-216, demo.py:108).  Its loop has two
+very different halves (models/gaussian_diffuser.py:284-300 with the ``t < cond_start_step``
+branch at :270):
+
+* the unguided steps t = T-1 .. cond_start_step: 43 small launches per step that need few CUs;
+* the guided steps: per step one persistent ``pd_ggs_kernel`` launch that holds
+  ``wgs_per_seq`` co-resident workgroups (= CUs) per sequence for milliseconds.
+
+Sequences never interact, so several batches can be in flight.  This scheduler is a
+two-stage pipeline with ``ggs_slots`` parallel servers in the second stage:
+
+* ONE stream runs the unguided halves back to back (a half takes less time than the guided half
+  divided by the slot count, so one server keeps up);
+* ``ggs_slots`` streams run the guided halves; submission i uses slot
+  i % ggs_slots, so at most ``ggs_slots`` persistent kernels compete for CUs and
+  ``ggs_slots * B * wgs_per_seq`` is sized to leave CUs free for the unguided stream;
+* ``contexts`` engine contexts (buffers + hipGraphs) rotate through both stages.
+
+A process gets 4 hardware queues and streams that share one serialise, so the pipeline measures
+which torch streams really overlap (`pick_concurrent_streams`) and uses at most 4 of them
+(e.g. 2 unguided + 2 guided); raising the stream priority of the guided halves starves the
+unguided ones (profiles/round1_e_pipeline_notes.md).  No host thread, no host sync: the hand-over between the
+halves is ``hipStreamWaitEvent`` (include/pd_engine.h PD_PHASE_*).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from .engine import PoseEngine, make_ggs_cfg
+
+# CUs the co-resident guided kernels may hold on a 256-CU MI355X; the rest serve the unguided halves
+GGS_CU_BUDGET = 192
+
+
+def _overlaps(a: torch.cuda.Stream, b: torch.cuda.Stream, spin_cycles: int, scratch: torch.Tensor) -> bool:
+    """True if work on `b` can overtake a busy `a`, i.e. the two streams do not share a hardware queue."""
+    ea, eb = torch.cuda.Event(), torch.cuda.Event()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(spin_cycles)
+        ea.record(a)
+    with torch.cuda.stream(b):
+        scratch.add_(1.0)
+        eb.record(b)
+    eb.synchronize()
+    overtook = not ea.query()
+    ea.synchronize()
+    return overtook
+
+
+def pick_concurrent_streams(device: torch.device, n: int, priority: int = 0, candidates: int = 16) -> List[torch.cuda.Stream]:
+    """Up to `n` torch streams that pairwise run concurrently.
+
+    HIP multiplexes streams onto a few hardware queues (4 per process by default) and two streams on
+    one queue serialise: a guided half (tens of ms of persistent kernels) then blocks whatever shares
+    its queue.  Which stream lands on which queue is not specified, so it is measured: a spinning
+    kernel on one stream, a trivial one on the other, and the question whether the second finished
+    first (both directions)."""
+    pool = [torch.cuda.Stream(device=device, priority=priority) for _ in range(candidates)]
+    if n <= 1:
+        return pool[:1]
+    scratch = torch.zeros(64, device=device)
+    torch.cuda.synchronize(device)
+    # calibrate the spin to ~2 ms
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(pool[0]):
+        torch.cuda._sleep(1000)
+        e0.record(pool[0])
+        torch.cuda._sleep(1_000_000)
+        e1.record(pool[0])
+    e1.synchronize()
+    ms = max(e0.elapsed_time(e1), 1e-3)
+    spin = max(int(2.0 / ms * 1_000_000), 10_000)
+    chosen = [pool[0]]
+    for cand in pool[1:]:
+        if len(chosen) == n:
+            break
+        if any(cand.cuda_stream == c.cuda_stream for c in chosen):
+            continue
+        if all(_overlaps(c, cand, spin, scratch) and _overlaps(cand, c, spin, scratch) for c in chosen):
+            chosen.append(cand)
+    torch.cuda.synchronize(device)
+    return chosen
+
+
+class PendingSample:
+    """Result of `SamplingPipeline.submit`: tensors are valid once `done` has completed."""
+
+    def __init__(self, pose, process, stats, done: torch.cuda.Event, context: int, stream: torch.cuda.Stream):
+        self.pose, self.process, self.stats, self.done, self.context, self.stream = pose, process, stats, done, context, stream
+
+    def wait(self):
+        self.done.synchronize()
+        return self.pose, self.process, self.stats
+
+
+class SamplingPipeline:
+    def __init__(self, engines: List[PoseEngine], ggs_slots: int, device: torch.device, trace: bool = False,
+                 unguided_streams: int = 1):
+        if not engines:
+            raise ValueError("SamplingPipeline needs at least one engine context")
+        if ggs_slots < 1 or ggs_slots > len(engines):
+            raise ValueError(f"ggs_slots must be in [1, {len(engines)}] (got {ggs_slots})")
+        self.engines = engines
+        self.device = device
+        self.ggs_slots = ggs_slots
+        if len(engines) == 1:
+            self.u_streams = [torch.cuda.Stream(device=device)]
+            self.g_streams = [self.u_streams[0]]
+        else:
+            nu = max(1, unguided_streams)
+            found = pick_concurrent_streams(device, nu + ggs_slots)
+            if len(found) < 1 + ggs_slots:
+                raise RuntimeError(f"SamplingPipeline: only {len(found)} concurrently running HIP streams found, "
+                                   f"need {1 + ggs_slots} (1 unguided + {ggs_slots} guided)")
+            # guided slots first (they must never share a queue); what is left serves the unguided halves
+            self.g_streams = found[:ggs_slots]
+            self.u_streams = found[ggs_slots:]
+        self.u_stream = self.u_streams[0]
+        self._ctx_free: List[Optional[torch.cuda.Event]] = [None] * len(engines)
+        self._submitted = 0
+        # trace=True: per submission (u_begin, u_end, g_begin, g_end) timing events, see `timeline()`
+        self._trace = [] if trace else None
+
+    @property
+    def contexts(self) -> int:
+        return len(self.engines)
+
+    @property
+    def streams(self):
+        return self.u_streams + [s for s in self.g_streams if s is not self.u_stream]
+
+    def wgs_per_seq(self, B: int) -> int:
+        """Workgroups per sequence so that `ggs_slots` guided kernels of B sequences are co-resident.
+        A lone context (nothing to overlap with) returns 0 = the engine's own choice."""
+        if self.contexts == 1:
+            return 0
+        return max(1, GGS_CU_BUDGET // (B * self.ggs_slots))
+
+    def make_cfg(self, ggs_cfg: dict, B: int):
+        return make_ggs_cfg(ggs_cfg, wgs_per_seq=self.wgs_per_seq(B))
+
+    def next_context(self) -> int:
+        """The context (engine index) the next `submit` will use; upload that batch's matches there."""
+        return self._submitted % self.contexts
+
+    def submit(self, z: torch.Tensor, noise: torch.Tensor, cond_start_step: int = 0, ggs_cfg=None,
+               use_graph: bool = True, want_process: bool = False,
+               inputs_ready: Optional[torch.cuda.Event] = None) -> PendingSample:
+        """Enqueue GaussianDiffusion.sample for one batch; returns immediately.
+
+        ``z`` / ``noise`` must be complete when the unguided stream reaches them: pass the event that
+        follows their producer as ``inputs_ready`` (or synchronise before submitting).  The pipeline
+        deliberately does not touch the caller's current stream: a marker on the default stream can
+        sit behind a guided half when the two share a hardware queue, which stalls the whole pipe."""
+        i = self._submitted
+        j = i % self.contexts
+        eng = self.engines[j]
+        guided = ggs_cfg is not None and cond_start_step > 0
+        us = self.u_streams[i % len(self.u_streams)]
+        gs = self.g_streams[i % self.ggs_slots] if guided else us
+        if inputs_ready is not None:
+            us.wait_event(inputs_ready)
+        if self._ctx_free[j] is not None:
+            us.wait_event(self._ctx_free[j])                       # the context's previous batch has left the engine
+        tr = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self._trace is not None else None
+        with torch.cuda.stream(us):
+            if tr:
+                tr[0].record(us)
+            if not guided:
+                out = eng.sample(z, noise, cond_start_step, ggs_cfg, use_graph=use_graph, want_process=want_process)
+            else:
+                out = eng.sample(z, noise, cond_start_step, ggs_cfg, use_graph=use_graph, want_process=want_process, phase=1)
+        if tr:
+            tr[1].record(us)
+        if gs is not us:
+            ev = torch.cuda.Event()
+            ev.record(us)
+            gs.wait_event(ev)
+        done = torch.cuda.Event()
+        with torch.cuda.stream(gs):
+            if tr:
+                tr[2].record(gs)
+            if guided:
+                out = eng.sample(z, noise, cond_start_step, ggs_cfg, use_graph=use_graph, want_process=want_process,
+                                 phase=2, out=out)
+            if tr:
+                tr[3].record(gs)
+                self._trace.append(tr)
+            done.record(gs)
+        self._ctx_free[j] = done
+        self._submitted += 1
+        return PendingSample(out[0], out[1], out[2], done, j, gs)
+
+    def timeline(self):
+        """[(u_begin, u_end, g_begin, g_end)] in ms relative to the first submission (trace=True; synchronises)."""
+        self.synchronize()
+        if not self._trace:
+            return []
+        t0 = self._trace[0][0]
+        return [tuple(t0.elapsed_time(e) for e in tr) for tr in self._trace]
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def check_async(self):
+        for e in self.engines:
+            e.check_async()

@@ -409,3 +409,52 @@ def test_two_engines_overlapped_on_two_streams_match_serial(seeded_diffuser):
             assert torch.equal(o, refs[j]), f"engine {j}: overlapped result differs from its serial result"
     for e in engs:
         e.close()
+
+
+def test_pipeline_gated_phases_match_whole_loop(seeded_diffuser):
+    """SamplingPipeline (3 contexts, 2 unguided streams, 2 guided slots): pd_sample_phase UNGUIDED + event gate + GUIDED must give,
+    bit for bit, what pd_sample gives for the same batch, whatever else is in flight; also without graphs and
+    for a batch without guidance."""
+    from posediffusion_amd.engine import PoseEngine
+    from posediffusion_amd.host import denoiser_state, draw_noise
+    from posediffusion_amd.pipeline import SamplingPipeline
+    dev = torch.device(DEV)
+    diff = seeded_diffuser.to(dev)
+    B, N, D = 3, 10, 3
+    tables = {k: v for k, v in diff.named_buffers(recurse=False)}
+    engs = [PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=B, max_N=N) for _ in range(D)]
+    data = []
+    for e, eng in enumerate(engs):
+        z = synth.make_z(B, N, seed=500 + 10 * e).to(dev)
+        noise = torch.stack([draw_noise((N, 9), 100, dev, 5, True, generator=torch.Generator(device=dev).manual_seed(70 + 10 * e + b))
+                             for b in range(B)], dim=1)
+        for b in range(B):
+            enc = synth.make_cameras(N, seed=80 + 10 * e + b)
+            md = synth.make_matches(enc, 224, 224, per_pair=120, seed=80 + 10 * e + b)
+            eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+        data.append((z, noise))
+    pipe = SamplingPipeline(engs, 2, dev, unguided_streams=2)
+    cfg = make_ggs_cfg(synth.GGS_CFG, iter_num=25, min_matches=0, wgs_per_seq=6)
+    torch.cuda.synchronize()
+    refs, refs_plain = [], []
+    for j in range(D):
+        pose, proc, stats = engs[j].sample(data[j][0], data[j][1], 5, cfg, use_graph=True)
+        refs.append((pose.clone(), proc.clone(), stats.clone()))
+        refs_plain.append(engs[j].sample(data[j][0], data[j][1], 0, None, use_graph=True)[0].clone())
+        torch.cuda.synchronize()
+    for use_graph in (True, False):
+        pend = []
+        for i in range(7):
+            j = pipe.next_context()
+            pend.append(pipe.submit(data[j][0], data[j][1], 5, cfg, use_graph=use_graph, want_process=True))
+        j = pipe.next_context()
+        plain = pipe.submit(data[j][0], data[j][1], 0, None, use_graph=use_graph)
+        pipe.synchronize()
+        pipe.check_async()
+        for p in pend:
+            pose, proc, stats = p.wait()
+            assert torch.equal(pose, refs[p.context][0]) and torch.equal(proc, refs[p.context][1])
+            assert torch.equal(stats, refs[p.context][2])
+        assert torch.equal(plain.wait()[0], refs_plain[plain.context])
+    for e in engs:
+        e.close()
