@@ -616,10 +616,11 @@ void pd_denoiser_destroy(pd_engine *eng) {
 // one GEMM launch; the tile width is chosen per problem: 16-wide tiles double the workgroup count (and
 // halve each wave's serial MFMA chain) whenever 32-wide tiles would leave most of the 256 CUs idle
 template <int K, int AMODE, int EPI>
-static void launch_gemm(GemmArgs &g, float *const wp[2], int MT, hipStream_t s) {
+static void launch_gemm(GemmArgs &g, float *const wp[2], int MT, int wide_min, hipStream_t s) {
     const int tiles32 = MT * (g.Nout / 32);
     g.MT = MT;
-    if (tiles32 >= 200) {
+    // the XCD-aware block mapping of pd_gemm_kernel needs a multiple of 8 N-tiles (128-wide _last.0 has only 4 of 32)
+    if (tiles32 >= wide_min && (g.Nout / 32) % 8 == 0) {
         g.Wp = wp[0];
         hipLaunchKernelGGL((pd_gemm_kernel<K, AMODE, EPI, 32>), dim3(MT * (g.Nout / 32)), dim3(256), 32 * (K + 4) * 4, s, g);
     } else {
@@ -643,24 +644,24 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     // _first with the embedding fused into the A staging
     g.bias = d->first_b; g.C = d->h; g.Nout = DM;
     g.x = x; g.z = z; g.temb = d->t_table + (size_t)t * 128; g.n_frames = N;
-    launch_gemm<KFIRST_PAD, 2, 0>(g, d->first_wp, MT, s);
+    launch_gemm<KFIRST_PAD, 2, 0>(g, d->first_wp, MT, eng->gemm_wide_min_tiles, s);
     for (int l = 0; l < d->num_layers; ++l) {
         const PdLayerDev &L = d->layers[l];
         // x += MHA(LN1(x))
         g.A = d->h; g.bias = L.qkv_b; g.C = d->qkv; g.Nout = 3 * DM;
-        launch_gemm<DM, 1, 0>(g, L.qkv_wp, MT, s);
+        launch_gemm<DM, 1, 0>(g, L.qkv_wp, MT, eng->gemm_wide_min_tiles, s);
         hipLaunchKernelGGL(pd_attn_kernel, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
         g.A = d->ctx; g.bias = L.out_b; g.C = d->h; g.Nout = DM;
-        launch_gemm<DM, 0, 2>(g, L.out_wp, MT, s);
+        launch_gemm<DM, 0, 2>(g, L.out_wp, MT, eng->gemm_wide_min_tiles, s);
         // x += W2 relu(W1 LN2(x))
         g.A = d->h; g.bias = L.ff1_b; g.C = d->ff; g.Nout = DFF;
-        launch_gemm<DM, 1, 1>(g, L.ff1_wp, MT, s);
+        launch_gemm<DM, 1, 1>(g, L.ff1_wp, MT, eng->gemm_wide_min_tiles, s);
         g.A = d->ff; g.bias = L.ff2_b; g.C = d->h; g.Nout = DM;
-        launch_gemm<DFF, 0, 2>(g, L.ff2_wp, MT, s);
+        launch_gemm<DFF, 0, 2>(g, L.ff2_wp, MT, eng->gemm_wide_min_tiles, s);
     }
     // _last.0 as a plain tile GEMM, then the fused LN/ReLU/Linear(128->9)/DDPM tail
     g.A = d->h; g.bias = d->last0_b; g.C = d->hid; g.Nout = HID;
-    launch_gemm<DM, 0, 0>(g, d->last0_wp, MT, s);
+    launch_gemm<DM, 0, 0>(g, d->last0_wp, MT, eng->gemm_wide_min_tiles, s);
     HeadArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.hid = d->hid; ha.lnw = d->last_ln_w; ha.lnb = d->last_ln_b;

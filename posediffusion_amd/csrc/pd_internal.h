@@ -95,6 +95,7 @@ struct pd_engine {
     size_t xchg_granules = 0;            // per (sequence, slot)
     unsigned int *d_err = nullptr;       // [0] async error word; [2..] debug phase counters
     int ggs_prof_on = 0;
+    int gemm_wide_min_tiles = 200;   // launch_gemm: 32-wide tiles when there are at least this many of them
     float *d_stats_scratch = nullptr;
     // sampler buffers (fixed addresses so a captured graph can be replayed)
     float *d_z = nullptr, *d_noise = nullptr, *d_process = nullptr, *d_mean = nullptr, *d_stats = nullptr;

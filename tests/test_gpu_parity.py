@@ -50,6 +50,24 @@ def test_denoiser_vs_oracle_shapes(engine, oracle_weights, B, N):
     assert rel_err(engine.denoise(x.to(DEV), z.to(DEV), t), ref) < TOL
 
 
+def test_denoiser_wide_tile_path_large_batch(seeded_diffuser, oracle_weights):
+    """M = 1 680 tokens: every GEMM has >= 200 32-wide tiles, so the 32x32x2 path is taken wherever it is legal;
+    the 128-wide `_last.0` (4 N-tiles of 32, not a multiple of the 8 XCDs) must stay on 16-wide tiles
+    (a regression here wrote past the activation buffer)."""
+    from posediffusion_amd.engine import PoseEngine
+    from posediffusion_amd.host import denoiser_state
+    dev = torch.device(DEV)
+    diff = seeded_diffuser.to(dev)
+    B, N = 84, 20
+    tables = {k: v for k, v in diff.named_buffers(recurse=False)}
+    eng = PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=B, max_N=N)
+    g = torch.Generator().manual_seed(77)
+    x, z = torch.randn(B, N, 9, generator=g), synth.make_z(B, N, seed=6)
+    ref = O.denoiser_forward(oracle_weights, x, torch.full((B,), 42, dtype=torch.long), z)
+    assert rel_err(eng.denoise(x.to(dev), z.to(dev), 42), ref) < TOL
+    eng.close()
+
+
 def test_large_pose_values_harmonic_embedding(engine, oracle_weights):
     """|x| ~ 50 puts harmonic arguments at 2.5e4 rad: range reduction of sin must hold (SURVEY 'error amplifiers')."""
     g = torch.Generator().manual_seed(9)
