@@ -135,10 +135,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--seqs-per-gpu", type=int, default=SEQS_PER_GPU)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--ggs-slots", type=int, default=2,
+    ap.add_argument("--ggs-slots", type=int, default=4,
                     help="how many of the batches in flight may be in their guided (GGS) half at once")
-    ap.add_argument("--unguided-streams", type=int, default=2,
-                    help="streams for the unguided halves (two halves side by side fill the CUs the guided kernels leave free)")
+    ap.add_argument("--unguided-streams", type=int, default=0,
+                    help="0: every stream runs whole passes; u > 0: two-stage pipeline with u streams for the unguided halves")
     ap.add_argument("--ggs-wgs", type=int, default=0, help="override GGS workgroups per sequence (0 = from the slot count)")
     ap.add_argument("--pipeline-depth", type=int, default=4,
                     help="engine contexts / HIP streams per GPU; consecutive passes (different batches) overlap: the next "
@@ -179,8 +179,8 @@ def main():
     inputs = [build_inputs(engines[j], diff, B, dev, seed0=g0 + j * total) for j in range(depth)]
     z, noise = inputs[0]
     # GGS workgroups per sequence: alone on the chip -> one work item per wave (24 WGs/sequence, lowest latency);
-    # pipelined -> the `slots` batches that may be in their guided half share 192 CUs so that their persistent
-    # kernels run CONCURRENTLY, and 64 CUs stay free for the unguided halves of the other batches in flight
+    # pipelined -> sized so that the persistent kernels of ALL batches that may be in their guided half are
+    # co-resident (4 batches x 8 sequences x 8 workgroups = 256 CUs; see posediffusion_amd/pipeline.py)
     wgs = args.ggs_wgs if args.ggs_wgs > 0 else pipe.wgs_per_seq(B)
     cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=wgs)
     use_graph = not args.no_graph
@@ -252,7 +252,7 @@ def main():
                         "unguided model mean at t=9",
             "sequences_per_gpu": B, "frames": N_FRAMES, "matches_per_sequence": M, "diffusion_steps": 100,
             "ggs_iterations_per_sequence_run": float(iters.min().item()), "hip_graph": use_graph,
-            "pipeline_depth": depth, "ggs_slots": slots, "unguided_streams": len(pipe.u_streams), "pass_latency_ms_unpipelined": pass_latency_ms, "ggs_workgroups_per_sequence": wgs or 24,
+            "pipeline_depth": depth, "ggs_slots": slots, "unguided_streams": 0 if pipe.whole_pass_streams else len(pipe.u_streams), "pass_latency_ms_unpipelined": pass_latency_ms, "ggs_workgroups_per_sequence": wgs or 24,
             "parallelism": f"dp{world} (independent sequences, one final all_gather)", "outputs_finite": finite,
         },
         "roofline": {

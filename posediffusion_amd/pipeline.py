@@ -8,21 +8,23 @@ branch at :270):
 * the guided steps: per step one persistent ``pd_ggs_kernel`` launch that holds
   ``wgs_per_seq`` co-resident workgroups (= CUs) per sequence for milliseconds.
 
-Sequences never interact, so several batches can be in flight.  This scheduler is a
-two-stage pipeline with ``ggs_slots`` parallel servers in the second stage:
+Sequences never interact, so several batches can be in flight, each on its own engine
+context (buffers + hipGraphs).  A process gets 4 hardware queues and streams that share one
+serialise, so at most 4 streams are used and the pipeline measures which torch streams really
+overlap (`pick_concurrent_streams`).  Two ways to use them:
 
-* ONE stream runs the unguided halves back to back (a half takes less time than the guided half
-  divided by the slot count, so one server keeps up);
-* ``ggs_slots`` streams run the guided halves; submission i uses slot
-  i % ggs_slots, so at most ``ggs_slots`` persistent kernels compete for CUs and
-  ``ggs_slots * B * wgs_per_seq`` is sized to leave CUs free for the unguided stream;
-* ``contexts`` engine contexts (buffers + hipGraphs) rotate through both stages.
+* ``unguided_streams = 0`` (default of bench.py): every stream runs whole passes (unguided half,
+  then guided half) of every 4th batch.  With 8 workgroups per sequence a guided kernel of 8
+  sequences holds 64 CUs, so even four guided halves at once are co-resident (4 x 64 = 256 CUs)
+  and the small denoiser launches of the other batches fill whatever is free.
+* ``unguided_streams = u > 0``: a two-stage pipeline, u streams run unguided halves back to back
+  and ``ggs_slots`` streams run guided halves (submission i uses slot i % ggs_slots);
+  ``ggs_slots * B * wgs_per_seq`` is sized to leave a quarter of the CUs to the unguided streams.
+  The hand-over between the halves is ``hipStreamWaitEvent`` (include/pd_engine.h PD_PHASE_*).
 
-A process gets 4 hardware queues and streams that share one serialise, so the pipeline measures
-which torch streams really overlap (`pick_concurrent_streams`) and uses at most 4 of them
-(e.g. 2 unguided + 2 guided); raising the stream priority of the guided halves starves the
-unguided ones (profiles/round1_e_pipeline_notes.md).  No host thread, no host sync: the hand-over between the
-halves is ``hipStreamWaitEvent`` (include/pd_engine.h PD_PHASE_*).
+No host thread and no host synchronisation in either mode.  Raising the stream priority of the
+guided halves, more than 4 hardware queues, or touching the default stream while a guided half is
+queued all cost throughput (profiles/round1_e_pipeline_notes.md).
 """
 from __future__ import annotations
 
@@ -32,8 +34,8 @@ import torch
 
 from .engine import PoseEngine, make_ggs_cfg
 
-# CUs the co-resident guided kernels may hold on a 256-CU MI355X; the rest serve the unguided halves
-GGS_CU_BUDGET = 192
+# two-stage mode: fraction of the CUs the co-resident guided kernels may hold; the rest serve the unguided streams
+GGS_CU_FRACTION = 0.75
 
 
 def _overlaps(a: torch.cuda.Stream, b: torch.cuda.Stream, spin_cycles: int, scratch: torch.Tensor) -> bool:
@@ -111,14 +113,18 @@ class SamplingPipeline:
             self.u_streams = [torch.cuda.Stream(device=device)]
             self.g_streams = [self.u_streams[0]]
         else:
-            nu = max(1, unguided_streams)
+            nu = max(0, unguided_streams)
             found = pick_concurrent_streams(device, nu + ggs_slots)
-            if len(found) < 1 + ggs_slots:
+            if len(found) < min(nu, 1) + ggs_slots:
                 raise RuntimeError(f"SamplingPipeline: only {len(found)} concurrently running HIP streams found, "
-                                   f"need {1 + ggs_slots} (1 unguided + {ggs_slots} guided)")
-            # guided slots first (they must never share a queue); what is left serves the unguided halves
+                                   f"need {min(nu, 1) + ggs_slots} ({min(nu, 1)} unguided + {ggs_slots} guided)")
+            # guided slots first (they must never share a queue); what is left serves the unguided halves.
+            # unguided_streams = 0: every slot stream runs whole passes (its unguided half, then its guided half)
             self.g_streams = found[:ggs_slots]
-            self.u_streams = found[ggs_slots:]
+            self.u_streams = found[ggs_slots:] if nu > 0 else []
+        self.whole_pass_streams = not self.u_streams
+        if self.whole_pass_streams:
+            self.u_streams = list(self.g_streams)
         self.u_stream = self.u_streams[0]
         self._ctx_free: List[Optional[torch.cuda.Event]] = [None] * len(engines)
         self._submitted = 0
@@ -131,14 +137,22 @@ class SamplingPipeline:
 
     @property
     def streams(self):
-        return self.u_streams + [s for s in self.g_streams if s is not self.u_stream]
+        seen, out = set(), []
+        for st in self.u_streams + self.g_streams:
+            if st.cuda_stream not in seen:
+                seen.add(st.cuda_stream)
+                out.append(st)
+        return out
 
     def wgs_per_seq(self, B: int) -> int:
         """Workgroups per sequence so that `ggs_slots` guided kernels of B sequences are co-resident.
         A lone context (nothing to overlap with) returns 0 = the engine's own choice."""
         if self.contexts == 1:
             return 0
-        return max(1, GGS_CU_BUDGET // (B * self.ggs_slots))
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if not self.whole_pass_streams:
+            cus = int(cus * GGS_CU_FRACTION)
+        return max(1, cus // (B * self.ggs_slots))
 
     def make_cfg(self, ggs_cfg: dict, B: int):
         return make_ggs_cfg(ggs_cfg, wgs_per_seq=self.wgs_per_seq(B))
@@ -162,6 +176,8 @@ class SamplingPipeline:
         guided = ggs_cfg is not None and cond_start_step > 0
         us = self.u_streams[i % len(self.u_streams)]
         gs = self.g_streams[i % self.ggs_slots] if guided else us
+        if self.whole_pass_streams:
+            us = gs
         if inputs_ready is not None:
             us.wait_event(inputs_ready)
         if self._ctx_free[j] is not None:

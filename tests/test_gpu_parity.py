@@ -430,7 +430,7 @@ def test_two_engines_overlapped_on_two_streams_match_serial(seeded_diffuser):
 
 
 def test_pipeline_gated_phases_match_whole_loop(seeded_diffuser):
-    """SamplingPipeline (3 contexts, 2 unguided streams, 2 guided slots): pd_sample_phase UNGUIDED + event gate + GUIDED must give,
+    """SamplingPipeline (3 contexts; two-stage 2+2 and 1+2 streams, and whole-pass streams): pd_sample_phase UNGUIDED + event gate + GUIDED must give,
     bit for bit, what pd_sample gives for the same batch, whatever else is in flight; also without graphs and
     for a batch without guidance."""
     from posediffusion_amd.engine import PoseEngine
@@ -451,7 +451,6 @@ def test_pipeline_gated_phases_match_whole_loop(seeded_diffuser):
             md = synth.make_matches(enc, 224, 224, per_pair=120, seed=80 + 10 * e + b)
             eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
         data.append((z, noise))
-    pipe = SamplingPipeline(engs, 2, dev, unguided_streams=2)
     cfg = make_ggs_cfg(synth.GGS_CFG, iter_num=25, min_matches=0, wgs_per_seq=6)
     torch.cuda.synchronize()
     refs, refs_plain = [], []
@@ -460,7 +459,8 @@ def test_pipeline_gated_phases_match_whole_loop(seeded_diffuser):
         refs.append((pose.clone(), proc.clone(), stats.clone()))
         refs_plain.append(engs[j].sample(data[j][0], data[j][1], 0, None, use_graph=True)[0].clone())
         torch.cuda.synchronize()
-    for use_graph in (True, False):
+    for use_graph, slots, ustreams in ((True, 2, 2), (False, 2, 1), (True, 3, 0)):
+        pipe = SamplingPipeline(engs, slots, dev, unguided_streams=ustreams)   # two-stage (2+2, 1+2) and whole-pass streams
         pend = []
         for i in range(7):
             j = pipe.next_context()
