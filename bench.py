@@ -45,6 +45,10 @@ FP32_PEAK_TFLOPS = 157.3             # MI355X fp32 vector ALU = dense fp32 MFMA 
 HBM_PEAK_GBS = 8000.0
 
 
+# per-XCD persistent denoiser: workgroups per XCD when [alone on the chip, several batches in flight]; 0 = per-launch kernels
+DEFAULT_DEN_WGS = {False: 0, True: 0}
+
+
 def build_inputs(eng, diff, B, dev, seed0):
     """Synthetic inputs for B local sequences (global indices seed0 .. seed0+B-1), all resident on the
     device: z, reference-order noise, and matches that are epipolar-consistent with the engine's own
@@ -143,6 +147,8 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=4,
                     help="engine contexts / HIP streams per GPU; consecutive passes (different batches) overlap: the next "
                          "batch's unguided denoiser steps run on the CUs the persistent GGS kernel leaves free. 1 = serial")
+    ap.add_argument("--denoiser-wgs-per-xcd", type=int, default=-1,
+                    help="per-XCD persistent denoiser kernel: workgroups per XCD (0 = per-launch kernels, -1 = default)")
     ap.add_argument("--trace", action="store_true", help="print the pipeline timeline (per-batch phase times) to stderr")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0, help="CPU seconds for the cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -174,6 +180,9 @@ def main():
     eng = get_engine(diff.model, diff, B, N_FRAMES)
     tables = {k: v for k, v in diff.named_buffers(recurse=False)}
     engines = [eng] + [PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=B, max_N=N_FRAMES) for _ in range(depth - 1)]
+    den_wgs = args.denoiser_wgs_per_xcd if args.denoiser_wgs_per_xcd >= 0 else DEFAULT_DEN_WGS[depth > 1]
+    for e in engines:
+        e.set_denoiser_wgs_per_xcd(den_wgs)
     pipe = SamplingPipeline(engines, slots, dev, unguided_streams=args.unguided_streams, trace=args.trace)
     # one resident batch per context (different sequences: seeds offset by the global batch size)
     inputs = [build_inputs(engines[j], diff, B, dev, seed0=g0 + j * total) for j in range(depth)]
@@ -233,7 +242,7 @@ def main():
 
     # ---- roofline of the dominant kernel + the denoiser step, timed with hipEvents on the launch stream
     ggs_ms = eng.time_kernel(1, B, N_FRAMES, cfg, reps=3)
-    den_ms = eng.time_kernel(0, B, N_FRAMES, cfg, reps=20)
+    den_ms = eng.time_kernel(2 if den_wgs > 0 else 0, B, N_FRAMES, cfg, reps=20)
     M = N_FRAMES * (N_FRAMES - 1) // 2 * PER_PAIR
     ggs_flops = B * M * FLOP_PER_MATCH_ITER * 7 * cfg.iter_num             # one pd_ggs_guide launch = 700 iterations
     ggs_tflops = ggs_flops / (ggs_ms * 1e-3) / 1e12
@@ -252,7 +261,7 @@ def main():
                         "unguided model mean at t=9",
             "sequences_per_gpu": B, "frames": N_FRAMES, "matches_per_sequence": M, "diffusion_steps": 100,
             "ggs_iterations_per_sequence_run": float(iters.min().item()), "hip_graph": use_graph,
-            "pipeline_depth": depth, "ggs_slots": slots, "unguided_streams": 0 if pipe.whole_pass_streams else len(pipe.u_streams), "pass_latency_ms_unpipelined": pass_latency_ms, "ggs_workgroups_per_sequence": wgs or 24,
+            "denoiser_wgs_per_xcd": den_wgs, "pipeline_depth": depth, "ggs_slots": slots, "unguided_streams": 0 if pipe.whole_pass_streams else len(pipe.u_streams), "pass_latency_ms_unpipelined": pass_latency_ms, "ggs_workgroups_per_sequence": wgs or 24,
             "parallelism": f"dp{world} (independent sequences, one final all_gather)", "outputs_finite": finite,
         },
         "roofline": {

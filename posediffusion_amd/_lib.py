@@ -59,6 +59,7 @@ SIGNATURES = {
     "pd_ggs_guide": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp]),
     "pd_ggs_optimize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp]),
     "pd_ggs_loss_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp]),
+    "pd_engine_set_option": (_i, [_vp, _i, _i]),
     "pd_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp, _i, _vp]),
     "pd_sample_phase": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _i, _vp, _vp, _vp, _i, _vp]),
     "pd_pose_to_camera": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -20,50 +20,11 @@
 //     Wp[n_tile][k_chunk][lane][4] so every wave-level load is one fully coalesced 1 KiB line
 //     streamed straight to VGPRs (each weight byte is read by exactly one wave per M-tile);
 //   * bias / ReLU / residual are fused into the epilogue.
-#include "pd_internal.h"
+#include "pd_denoiser_dev.h"
 
+#include <algorithm>
 #include <math.h>
 #include <string.h>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define DM 512          // d_model
-#define NH 4            // heads
-#define DH 128          // head dim
-#define DFF 1024        // feed-forward dim
-#define ZD 384          // z_dim
-#define KFIRST 702      // 189 + 128 + 384 + 1   (denoiser.py:39)
-#define KFIRST_PAD 704
-// The engine permutes the K axis of _first so the wide pieces land 16-byte aligned in LDS:
-//   engine column k' : [0,384) z | [384,512) t_emb | [512,692) harmonic | [692,701) x | 701 pivot | 702,703 pad
-//   reference column : [0,180) harmonic | [180,189) x | [189,317) t_emb | [317,701) z | 701 pivot  (denoiser.py:68)
-__host__ __device__ inline int pd_first_col(int kp) {
-    if (kp < 384) return 317 + kp;
-    if (kp < 512) return 189 + (kp - 384);
-    if (kp < 692) return kp - 512;
-    if (kp < 701) return 180 + (kp - 692);
-    return kp;   // 701 pivot; 702/703 are padding (>= KFIRST -> zero)
-}
-#define HID 128         // mlp_hidden_dim
-
-struct PdLayerDev {          // [0] = 32-wide-tile packing, [1] = 16-wide-tile packing of the same weights
-    float *qkv_wp[2], *qkv_b;  // LayerNorm-1 gamma folded into the columns, beta into the bias
-    float *out_wp[2], *out_b;
-    float *ff1_wp[2], *ff1_b;  // LayerNorm-2 folded likewise
-    float *ff2_wp[2], *ff2_b;
-};
-
-struct PdDenoiserDev {
-    int num_layers = 0, timesteps = 0, m_cap = 0;
-    float *t_table = nullptr;          // [T,128] time embeddings
-    float *first_wp[2] = {nullptr, nullptr}, *first_b = nullptr;
-    PdLayerDev layers[PD_MAX_LAYERS];
-    float *last0_wp[2] = {nullptr, nullptr}, *last0_b = nullptr, *last_ln_w = nullptr, *last_ln_b = nullptr;
-    float *last3_w = nullptr, *last3_b = nullptr;   // [9,128] plain
-    float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ff = nullptr, *hid = nullptr;   // activations [m_cap, .]
-    std::vector<void *> allocs;
-};
 
 // --------------------------------------------------------------------------------------------
 // weight repack: W[Nout][K] row-major -> MFMA-fragment order (zero padded), optionally with a
@@ -143,17 +104,6 @@ struct GemmArgs {
     int M, Nout;
     int MT;                // number of 32-row M tiles (XCD-aware block mapping)
 };
-
-// 8-lane (one activation row) sum on the DPP network: xor-1, xor-2 quad permutes + half-row mirror
-template <int CTRL>
-__device__ __forceinline__ float pd_dpp_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float pd_sum8(float v) {
-    v = pd_dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
-    v = pd_dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
-    return pd_dpp_add<0x141>(v);   // row_half_mirror
-}
 
 template <int K, int AMODE, int EPI, int NT>
 __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
@@ -363,17 +313,6 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
 // workgroup stages K and V of its (sequence, head) and each of its 4 waves owns ONE query row:
 // lane j scores key j, softmax is a wave reduction, lanes then own 2 of the 128 output dims.
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ float pd_wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
-}
-__device__ __forceinline__ float pd_wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 __global__ __launch_bounds__(256) void pd_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int N) {
     constexpr int LD = DH + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -584,11 +523,31 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(dev_copy(d, &d->last_ln_b, w->last_ln_b, HID));
     PD_TRY(dev_copy(d, &d->last3_w, w->last3_w, 9 * HID));
     PD_TRY(dev_copy(d, &d->last3_b, w->last3_b, 9));
-    PD_TRY(dev_alloc(d, &d->h, (size_t)d->m_cap * DM));
-    PD_TRY(dev_alloc(d, &d->qkv, (size_t)d->m_cap * 3 * DM));
-    PD_TRY(dev_alloc(d, &d->ctx, (size_t)d->m_cap * DM));
-    PD_TRY(dev_alloc(d, &d->ff, (size_t)d->m_cap * DFF));
-    PD_TRY(dev_alloc(d, &d->hid, (size_t)d->m_cap * HID));
+    // the per-XCD kernel partitions the activation rows by XCD (sequence s -> XCD s % 8)
+    d->cap_x = (((eng->max_B + 7) / 8) * eng->max_N + 31) / 32 * 32;
+    const size_t rows = (size_t)std::max(d->m_cap, 8 * d->cap_x);
+    PD_TRY(dev_alloc(d, &d->h, rows * DM));
+    PD_TRY(dev_alloc(d, &d->qkv, rows * 3 * DM));
+    PD_TRY(dev_alloc(d, &d->ctx, rows * DM));
+    PD_TRY(dev_alloc(d, &d->ff, rows * DFF));
+    PD_TRY(dev_alloc(d, &d->hid, rows * HID));
+    {
+        std::vector<float> sc((size_t)w->timesteps * 8, 0.0f);
+        for (int t = 0; t < w->timesteps; ++t) {
+            sc[t * 8 + 0] = eng->c_recip[t];
+            sc[t * 8 + 1] = eng->c_recipm1[t];
+            sc[t * 8 + 2] = eng->coef1[t];
+            sc[t * 8 + 3] = eng->coef2[t];
+            sc[t * 8 + 4] = expf(0.5f * eng->logvar[t]);
+        }
+        PD_TRY(dev_alloc(d, &d->sched, sc.size()));
+        PD_HIP_CHECK(hipMemcpy(d->sched, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
+        float *bar = nullptr;
+        PD_TRY(dev_alloc(d, &bar, 8 * 32));
+        PD_HIP_CHECK(hipMemset(bar, 0, 8 * 32 * sizeof(float)));
+        d->xcd_bar = (unsigned *)bar;
+        PD_TRY(pd_denoiser_xcd_init());
+    }
     PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0, 32>, 32 * (KFIRST_PAD + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0, 16>, 32 * (KFIRST_PAD + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 0, 32>, 32 * (DM + 4) * 4));

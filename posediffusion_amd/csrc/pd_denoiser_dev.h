@@ -1,0 +1,73 @@
+// pd_denoiser_dev.h -- shapes, device-side weight tables and small wave helpers shared by the
+// per-launch denoiser kernels (pd_denoiser.hip) and the per-XCD persistent kernel (pd_denoiser_xcd.hip).
+#pragma once
+#include "pd_internal.h"
+
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DM 512          // d_model
+#define NH 4            // heads
+#define DH 128          // head dim
+#define DFF 1024        // feed-forward dim
+#define ZD 384          // z_dim
+#define KFIRST 702      // 189 + 128 + 384 + 1   (denoiser.py:39)
+#define KFIRST_PAD 704
+// The engine permutes the K axis of _first so the wide pieces land 16-byte aligned in LDS:
+//   engine column k' : [0,384) z | [384,512) t_emb | [512,692) harmonic | [692,701) x | 701 pivot | 702,703 pad
+//   reference column : [0,180) harmonic | [180,189) x | [189,317) t_emb | [317,701) z | 701 pivot  (denoiser.py:68)
+__host__ __device__ inline int pd_first_col(int kp) {
+    if (kp < 384) return 317 + kp;
+    if (kp < 512) return 189 + (kp - 384);
+    if (kp < 692) return kp - 512;
+    if (kp < 701) return 180 + (kp - 692);
+    return kp;   // 701 pivot; 702/703 are padding (>= KFIRST -> zero)
+}
+#define HID 128         // mlp_hidden_dim
+
+struct PdLayerDev {          // [0] = 32-wide-tile packing, [1] = 16-wide-tile packing of the same weights
+    float *qkv_wp[2], *qkv_b;  // LayerNorm-1 gamma folded into the columns, beta into the bias
+    float *out_wp[2], *out_b;
+    float *ff1_wp[2], *ff1_b;  // LayerNorm-2 folded likewise
+    float *ff2_wp[2], *ff2_b;
+};
+
+struct PdDenoiserDev {
+    int num_layers = 0, timesteps = 0, m_cap = 0;
+    float *t_table = nullptr;          // [T,128] time embeddings
+    float *first_wp[2] = {nullptr, nullptr}, *first_b = nullptr;
+    PdLayerDev layers[PD_MAX_LAYERS];
+    float *last0_wp[2] = {nullptr, nullptr}, *last0_b = nullptr, *last_ln_w = nullptr, *last_ln_b = nullptr;
+    float *last3_w = nullptr, *last3_b = nullptr;   // [9,128] plain
+    float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ff = nullptr, *hid = nullptr;   // activations [rows, .]
+    // per-XCD persistent kernel (pd_denoiser_xcd.hip): XCD x owns activation rows [x * cap_x, (x + 1) * cap_x)
+    int cap_x = 0;
+    float *sched = nullptr;            // [T,8]: c_recip, c_recipm1, coef1, coef2, sigma per step
+    unsigned *xcd_bar = nullptr;       // [8][32] words: per-XCD arrival counter + its value at launch start
+    std::vector<void *> allocs;
+};
+
+// 8-lane (one activation row) sum on the DPP network: xor-1, xor-2 quad permutes + half-row mirror
+template <int CTRL>
+__device__ __forceinline__ float pd_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float pd_sum8(float v) {
+    v = pd_dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = pd_dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    return pd_dpp_add<0x141>(v);   // row_half_mirror
+}
+
+__device__ __forceinline__ float pd_wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float pd_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
