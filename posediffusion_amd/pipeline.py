@@ -28,6 +28,7 @@ queued all cost throughput (profiles/round1_e_pipeline_notes.md).
 """
 from __future__ import annotations
 
+import warnings
 from typing import List, Optional
 
 import torch
@@ -115,9 +116,11 @@ class SamplingPipeline:
         else:
             nu = max(0, unguided_streams)
             found = pick_concurrent_streams(device, nu + ggs_slots)
-            if len(found) < min(nu, 1) + ggs_slots:
-                raise RuntimeError(f"SamplingPipeline: only {len(found)} concurrently running HIP streams found, "
-                                   f"need {min(nu, 1) + ggs_slots} ({min(nu, 1)} unguided + {ggs_slots} guided)")
+            if len(found) < nu + ggs_slots:
+                # e.g. under a profiler that serialises dispatches: same results, less overlap
+                warnings.warn(f"SamplingPipeline: only {len(found)} of the {nu + ggs_slots} requested HIP streams run "
+                              "concurrently; batches will share streams", RuntimeWarning)
+                found = [found[i % len(found)] for i in range(nu + ggs_slots)]
             # guided slots first (they must never share a queue); what is left serves the unguided halves.
             # unguided_streams = 0: every slot stream runs whole passes (its unguided half, then its guided half)
             self.g_streams = found[:ggs_slots]

@@ -1,0 +1,70 @@
+"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into per-kernel traffic per dispatch.
+usage: python tools/pmc_summary.py <dir FETCH_SIZE pass> <dir WRITE_SIZE pass> "<profiled command>"  > summary.json
+
+Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (section HBM): rocprofv3 reports the two derived
+counters in KB per dispatch; on gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane) coalesced read stream,
+so it is doubled in the *_corrected figures; the counters sit on the fabric side of the L2, i.e. Infinity-Cache hits are
+included: this is L2-miss traffic, an upper bound on HBM bytes."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def read(d, counter):
+    per = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") == counter:
+                    per[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return per
+
+
+def main():
+    fdir, wdir, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
+    fetch, write = read(fdir, "FETCH_SIZE"), read(wdir, "WRITE_SIZE")
+    kernels = {}
+    for name in sorted(set(fetch) | set(write)):
+        if not name.startswith("pd_") and "pd_" not in name:
+            continue
+        f, w = fetch.get(name, []), write.get(name, [])
+        fa = sum(f) / len(f) if f else 0.0
+        wa = sum(w) / len(w) if w else 0.0
+        kernels[name] = {
+            "FETCH_SIZE": {"dispatches": len(f), "avg_KB": fa, "min_KB": min(f) if f else 0.0, "max_KB": max(f) if f else 0.0},
+            "WRITE_SIZE": {"dispatches": len(w), "avg_KB": wa, "min_KB": min(w) if w else 0.0, "max_KB": max(w) if w else 0.0},
+            "traffic_bytes_per_dispatch_raw": (fa + wa) * 1024.0,
+            "traffic_bytes_per_dispatch_corrected": (2.0 * fa + wa) * 1024.0,
+        }
+
+    def corrected(prefix):
+        return sum(v["traffic_bytes_per_dispatch_corrected"] for k, v in kernels.items() if k.startswith(prefix))
+
+    # one denoiser step = 34 GEMM launches of 7 kinds + 8 attention + 1 tail; weight per kind by its launches per step
+    per_step = {"pd_gemm_kernel<704": 1, "pd_gemm_kernel<512, 1, 0": 8, "pd_gemm_kernel<512, 0, 2": 8,
+                "pd_gemm_kernel<512, 1, 1": 8, "pd_gemm_kernel<1024, 0, 2": 8, "pd_gemm_kernel<512, 0, 0": 1,
+                "pd_attn_kernel": 8, "pd_tail_kernel": 1}
+    den = 0.0
+    for k, v in kernels.items():
+        for pre, n in per_step.items():
+            if k.replace("void ", "").startswith(pre):
+                den += n * v["traffic_bytes_per_dispatch_corrected"]
+    out = {
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `{cmd}` "
+                  "(8 sequences, N=20, GGS on, 8 GGS workgroups per sequence as in the default 4-batch pipeline), 1x MI355X; tools/collect_pmc.sh + tools/pmc_summary.py",
+        "units": "KB per dispatch as reported by rocprofv3 (FETCH_SIZE / WRITE_SIZE); bytes = KB * 1024",
+        "gfx950_correction": "MI355X_MICROARCH.md section HBM: FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) "
+                             "coalesced read stream on gfx950 -> doubled in *_corrected; Infinity-Cache hits are counted "
+                             "(fabric-side counter), so this is L2-miss traffic, an upper bound on HBM bytes",
+        "kernels": kernels,
+        "ggs_launch_B8": {"traffic_bytes_corrected": corrected("pd_ggs_kernel")},
+        "denoiser_step_B8": {"traffic_bytes_corrected": den},
+    }
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
