@@ -139,3 +139,24 @@ def test_synthetic_matches_are_consistent():
     pm2 = O.prepare_matches(md2["kp1"], md2["kp2"], md2["i12"], md2["img_shape"])
     v2, _ = O.compute_sampson_distance(torch.from_numpy(wild[None]), pm2)
     assert len(v2) == 750 and v2.max().item() < 1e-12
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|importlib\.import_module\(\s*[\"']oracle", re.M)
+    offenders = []
+    for base, _, files in os.walk(os.path.join(root, "posediffusion_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(base, f), errors="replace").read()
+                if pat.search(txt) or "oracle/_ref" in txt or "sys.path" in txt and "oracle" in txt:
+                    offenders.append(os.path.join(base, f))
+    assert not offenders, offenders
+    bench = open(os.path.join(root, "bench.py")).read()
+    uses = [m.start() for m in pat.finditer(bench)]
+    body = bench[bench.index("def cpu_baseline"):bench.index("def main")]
+    assert uses and all(bench.index("def cpu_baseline") < u < bench.index("def main") for u in uses), \
+        "bench.py may import the oracle only inside cpu_baseline()"
+    assert "oracle" in body
