@@ -174,22 +174,25 @@ __device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, 
     const v2f clamped = __builtin_elementwise_min(sam, pd_splat(smax));
     acc[11] += (v2f){ina ? clamped.x : 0.0f, inb ? clamped.y : 0.0f};   // :169
     const bool va = ina && (sam.x < smax), vb = inb && (sam.y < smax);   // :170 (false for NaN)
-    const v2f valid = {va ? 1.0f : 0.0f, vb ? 1.0f : 0.0f};
-    const v2f two_inv = {va ? inv.x + inv.x : 0.0f, vb ? inv.y + inv.y : 0.0f};   // selects, not products: inv may be inf
-    const v2f ca = {va ? ee.x * two_inv.x : 0.0f, vb ? ee.y * two_inv.y : 0.0f};
-    const v2f cb = {va ? sam.x * two_inv.x : 0.0f, vb ? sam.y * two_inv.y : 0.0f};
-    acc[9] += (v2f){va ? sam.x : 0.0f, vb ? sam.y : 0.0f};
-    acc[10] += valid;
-    // d sam / dF[r][c] = ca x1[r] x2[c] - cb (l_c x1[r] [c<2] + r_r x2[c] [r<2])
-    const v2f a1 = ca * u1, a2 = ca * v1, bl0 = cb * l0, bl1 = cb * l1, br0 = cb * r0, br1 = cb * r1;
-    acc[0] += a1 * u2 - (bl0 * u1 + br0 * u2);
-    acc[1] += a1 * v2 - (bl1 * u1 + br0 * v2);
-    acc[2] += a1 - br0;
-    acc[3] += a2 * u2 - (bl0 * v1 + br1 * u2);
-    acc[4] += a2 * v2 - (bl1 * v1 + br1 * v2);
-    acc[5] += a2 - br1;
-    acc[6] += ca * u2 - bl0;
-    acc[7] += ca * v2 - bl1;
+    // everything below is scaled by inv_v = valid ? 1/bottom : 0 (a select, not a product: 1/bottom may be inf),
+    // so invalid / out-of-range matches contribute exact zeros without further masking
+    const v2f inv_v = {va ? inv.x : 0.0f, vb ? inv.y : 0.0f};
+    const v2f ca = (ee + ee) * inv_v;                 // 2 ee / bottom
+    const v2f sam_v = (ee * ee) * inv_v;              // = sam where valid, else 0
+    const v2f cb = (sam_v + sam_v) * inv_v;           // 2 sam / bottom
+    acc[9] += sam_v;
+    acc[10] += (v2f){va ? 1.0f : 0.0f, vb ? 1.0f : 0.0f};
+    // d sam / dF[r][c] = x1[r] g_c - cb r_r x2[c] [r<2],  g_c = ca x2[c] - cb l_c [c<2]   (x1[2] = x2[2] = 1)
+    const v2f g0 = pd_fma2(ca, u2, -(cb * l0)), g1 = pd_fma2(ca, v2, -(cb * l1));
+    const v2f nbr0 = -(cb * r0), nbr1 = -(cb * r1);
+    acc[0] = pd_fma2(nbr0, u2, pd_fma2(u1, g0, acc[0]));
+    acc[1] = pd_fma2(nbr0, v2, pd_fma2(u1, g1, acc[1]));
+    acc[2] = pd_fma2(u1, ca, acc[2]) + nbr0;
+    acc[3] = pd_fma2(nbr1, u2, pd_fma2(v1, g0, acc[3]));
+    acc[4] = pd_fma2(nbr1, v2, pd_fma2(v1, g1, acc[4]));
+    acc[5] = pd_fma2(v1, ca, acc[5]) + nbr1;
+    acc[6] += g0;
+    acc[7] += g1;
     acc[8] += ca;
 }
 
