@@ -161,7 +161,8 @@ int pd_ggs_loss_grad(pd_engine *eng, const float *x, int B, int N, int update_R,
  *        (posediffusion_amd/csrc/pd_denoiser_xcd.hip) with w workgroups (= CUs) on each of the 8 XCDs: one launch per
  *        run of unguided steps, no kernel boundaries inside.  32 = lowest latency for one batch alone; 8 leaves
  *        room for three more batches in flight.  Shapes the kernel does not cover (more than 64 token rows per
- *        XCD) silently keep the per-launch path; results agree to rounding order. */
+ *        XCD) silently keep the per-launch path; results agree to rounding order.
+ * Changing an option drops the engine's captured hipGraphs. */
 #define PD_OPT_DENOISER_WGS_PER_XCD 1
 int pd_engine_set_option(pd_engine *eng, int option, int value);
 

@@ -382,11 +382,15 @@ extern "C" int pd_engine_set_option(pd_engine *eng, int option, int value) {
             return PD_ERR_INVALID_ARG;
         }
         eng->den_wgs_per_xcd = value;
-        return PD_OK;
+        break;
     default:
         pd_set_error("pd_engine_set_option: unknown option %d", option);
         return PD_ERR_INVALID_ARG;
     }
+    // captured graphs bake the launch shapes in: drop them, the next pd_sample call captures again
+    for (auto &g : eng->graphs) (void)hipGraphExecDestroy(g.second);
+    eng->graphs.clear();
+    return PD_OK;
 }
 
 // ---- measurement helper -------------------------------------------------------------------------
