@@ -105,12 +105,36 @@ struct GemmArgs {
     int MT;                // number of 32-row M tiles (XCD-aware block mapping)
 };
 
-// stage the 32 activation rows [m0, m0 + 32) into LDS (row stride K + 4) with the fused LayerNorm / embedding
-// build; no predicated loads (rows past M load a valid row and are zeroed)
-template <int K, int AMODE>
-__device__ __forceinline__ void pd_stage_rows(const GemmArgs &g, int m0, float *As) {
-    constexpr int LDA = K + 4;
-    const int tid = threadIdx.x;
+template <int K, int AMODE, int EPI, int NT>
+__global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
+    constexpr int LDA = K + 4;            // padded row stride (floats): conflict-free ds_read_b128
+    constexpr int CW = (NT == 32) ? 8 : 16;   // k-chunk width per float4 fragment load
+    constexpr int KC = K / CW;
+    constexpr int CPW = KC / 4;           // chunks per wave (split-K over the 4 waves)
+    constexpr int NB = (CPW > 16) ? 2 : 1;   // weight batches held in registers
+    constexpr int BATCH = CPW / NB;
+    constexpr int NACC = (NT == 32) ? 16 : 8;
+    static_assert(KC % 4 == 0 && CPW % NB == 0, "chunk batching");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;                      // [32][LDA]; later aliased by the cross-wave reduction
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware tile mapping (guide T1): the dispatcher places block id on XCD id % 8; all M-tiles that share
+    // an N-tile are given ids with the same id % 8, so each weight tile is fetched into ONE L2 once and the
+    // other M-tile workgroups hit it there (the naive (m + MT*n) order spread them over MT different XCDs
+    // and re-fetched every weight byte MT times).  Needs (Nout / NT) % 8 == 0 -- true for every layer here.
+    const int bid = blockIdx.x, slot = bid >> 3;
+    const int ntile = (bid & 7) + 8 * (slot / g.MT), mtile = slot % g.MT;
+    const int m0 = mtile * 32, n0 = ntile * NT;
+    const float4 *wp = (const float4 *)g.Wp + ((size_t)ntile * KC + (size_t)wave * CPW) * 64 + lane;
+
+    // ---- weights first: the whole first batch of this wave's fragments goes in flight before the
+    // activation staging, so the HBM/MALL latency of the weight stream hides under it --------------
+    float4 w0[BATCH];
+#pragma unroll
+    for (int c = 0; c < BATCH; ++c) w0[c] = wp[(size_t)c * 64];
+
+    // ---- stage the 32 activation rows (fused LN / embedding); no predicated loads ---------------
+    {
         const int r = tid >> 3, sub = tid & 7;
         const int m = m0 + r;
         const bool live = m < g.M;
@@ -202,37 +226,7 @@ __device__ __forceinline__ void pd_stage_rows(const GemmArgs &g, int m0, float *
                 }
             }
         }
-}
-
-template <int K, int AMODE, int EPI, int NT>
-__global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
-    constexpr int LDA = K + 4;            // padded row stride (floats): conflict-free ds_read_b128
-    constexpr int CW = (NT == 32) ? 8 : 16;   // k-chunk width per float4 fragment load
-    constexpr int KC = K / CW;
-    constexpr int CPW = KC / 4;           // chunks per wave (split-K over the 4 waves)
-    constexpr int NB = (CPW > 16) ? 2 : 1;   // weight batches held in registers
-    constexpr int BATCH = CPW / NB;
-    constexpr int NACC = (NT == 32) ? 16 : 8;
-    static_assert(KC % 4 == 0 && CPW % NB == 0, "chunk batching");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *As = lds;                      // [32][LDA]; later aliased by the cross-wave reduction
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware tile mapping (guide T1): the dispatcher places block id on XCD id % 8; all M-tiles that share
-    // an N-tile are given ids with the same id % 8, so each weight tile is fetched into ONE L2 once and the
-    // other M-tile workgroups hit it there (the naive (m + MT*n) order spread them over MT different XCDs
-    // and re-fetched every weight byte MT times).  Needs (Nout / NT) % 8 == 0 -- true for every layer here.
-    const int bid = blockIdx.x, slot = bid >> 3;
-    const int ntile = (bid & 7) + 8 * (slot / g.MT), mtile = slot % g.MT;
-    const int m0 = mtile * 32, n0 = ntile * NT;
-    const float4 *wp = (const float4 *)g.Wp + ((size_t)ntile * KC + (size_t)wave * CPW) * 64 + lane;
-
-    // ---- weights first: the whole first batch of this wave's fragments goes in flight before the
-    // activation staging, so the HBM/MALL latency of the weight stream hides under it --------------
-    float4 w0[BATCH];
-#pragma unroll
-    for (int c = 0; c < BATCH; ++c) w0[c] = wp[(size_t)c * 64];
-
-    pd_stage_rows<K, AMODE>(g, m0, As);
+    }
     __syncthreads();
 
     // ---- split-K MFMA loop: wave w owns k-chunks [w*CPW, (w+1)*CPW) --------------------------
@@ -581,11 +575,11 @@ void pd_denoiser_destroy(pd_engine *eng) {
 // one GEMM launch; the tile width is chosen per problem: 16-wide tiles double the workgroup count (and
 // halve each wave's serial MFMA chain) whenever 32-wide tiles would leave most of the 256 CUs idle
 template <int K, int AMODE, int EPI>
-static void launch_gemm(GemmArgs &g, float *const wp[2], int MT, const pd_engine *eng, hipStream_t s) {
+static void launch_gemm(GemmArgs &g, float *const wp[2], int MT, int wide_min, hipStream_t s) {
     const int tiles32 = MT * (g.Nout / 32);
     g.MT = MT;
-    // the XCD-aware block mapping needs a multiple of 8 N-tiles (the 128-wide _last.0 has only 4 tiles of 32)
-    if (tiles32 >= eng->gemm_wide_min_tiles && (g.Nout / 32) % 8 == 0) {
+    // the XCD-aware block mapping of pd_gemm_kernel needs a multiple of 8 N-tiles (128-wide _last.0 has only 4 of 32)
+    if (tiles32 >= wide_min && (g.Nout / 32) % 8 == 0) {
         g.Wp = wp[0];
         hipLaunchKernelGGL((pd_gemm_kernel<K, AMODE, EPI, 32>), dim3(MT * (g.Nout / 32)), dim3(256), 32 * (K + 4) * 4, s, g);
     } else {
@@ -609,24 +603,24 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     // _first with the embedding fused into the A staging
     g.bias = d->first_b; g.C = d->h; g.Nout = DM;
     g.x = x; g.z = z; g.temb = d->t_table + (size_t)t * 128; g.n_frames = N;
-    launch_gemm<KFIRST_PAD, 2, 0>(g, d->first_wp, MT, eng, s);
+    launch_gemm<KFIRST_PAD, 2, 0>(g, d->first_wp, MT, eng->gemm_wide_min_tiles, s);
     for (int l = 0; l < d->num_layers; ++l) {
         const PdLayerDev &L = d->layers[l];
         // x += MHA(LN1(x))
         g.A = d->h; g.bias = L.qkv_b; g.C = d->qkv; g.Nout = 3 * DM;
-        launch_gemm<DM, 1, 0>(g, L.qkv_wp, MT, eng, s);
+        launch_gemm<DM, 1, 0>(g, L.qkv_wp, MT, eng->gemm_wide_min_tiles, s);
         hipLaunchKernelGGL(pd_attn_kernel, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
         g.A = d->ctx; g.bias = L.out_b; g.C = d->h; g.Nout = DM;
-        launch_gemm<DM, 0, 2>(g, L.out_wp, MT, eng, s);
+        launch_gemm<DM, 0, 2>(g, L.out_wp, MT, eng->gemm_wide_min_tiles, s);
         // x += W2 relu(W1 LN2(x))
         g.A = d->h; g.bias = L.ff1_b; g.C = d->ff; g.Nout = DFF;
-        launch_gemm<DM, 1, 1>(g, L.ff1_wp, MT, eng, s);
+        launch_gemm<DM, 1, 1>(g, L.ff1_wp, MT, eng->gemm_wide_min_tiles, s);
         g.A = d->ff; g.bias = L.ff2_b; g.C = d->h; g.Nout = DM;
-        launch_gemm<DFF, 0, 2>(g, L.ff2_wp, MT, eng, s);
+        launch_gemm<DFF, 0, 2>(g, L.ff2_wp, MT, eng->gemm_wide_min_tiles, s);
     }
     // _last.0 as a plain tile GEMM, then the fused LN/ReLU/Linear(128->9)/DDPM tail
     g.A = d->h; g.bias = d->last0_b; g.C = d->hid; g.Nout = HID;
-    launch_gemm<DM, 0, 0>(g, d->last0_wp, MT, eng, s);
+    launch_gemm<DM, 0, 0>(g, d->last0_wp, MT, eng->gemm_wide_min_tiles, s);
     HeadArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.hid = d->hid; ha.lnw = d->last_ln_w; ha.lnb = d->last_ln_b;
