@@ -197,7 +197,7 @@ __device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, 
 }
 
 // LDS carve (floats).  Everything lives in the one dynamic region (guide G17).
-#define PD_GGS_LDS_FIXED (64 * 9 + 64 * 3 + 64 * 2 + 64 * 2 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8 + PD_GGS_THREADS * 16 + 64 * 16)
+#define PD_GGS_LDS_FIXED (64 * 9 + 64 * 3 + 64 * 2 + 64 * 2 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8 + PD_GGS_PINC_ROWS * 16 + 64 * 16)
 struct Lds {
     float *Rc;     // [64*9]  R_cv per frame  (opencv_from_cameras_projection)
     float *tc;     // [64*3]
@@ -208,11 +208,11 @@ struct Lds {
     float *gR;     // [64*9]  per-frame dL/dR  (PyTorch3D R, un-normalised)
     float *gA;     // [64*4]  per-frame partial dL/dA {00,02,11,12}
     float *ctl;    // [8]     ctl[0] = stage done flag, ctl[1] = abort
-    float *pinc;   // [512*16] per-incidence backward results of the current chunk (16-byte aligned)
+    float *pinc;   // [1024*16] backward results of the current chunk of pairs, one row per (pair, side), frame-sorted
     float *psum;   // [64*16]  per-frame partial sums across chunks (N > 32 only)
     int4 *itab;    // [n_slots] (first match, count, i, j) of the local items
     int4 *inc;     // [n_inc] incidence entries (only when they fit; else read from global)
-    int *incoff;   // [68] incidence CSR offsets per frame
+    int *incoff;   // [PD_GGS_MAX_PCHUNKS][68] per chunk of pairs: CSR offsets of its incidences per frame
     float *F;      // [n_slots*9]
     float *item;   // [n_items*12]
 };
@@ -229,18 +229,18 @@ __device__ __forceinline__ Lds carve(float *base, int n_slots, int n_inc_lds) {
     L.gA = L.gR + 64 * 9;
     L.ctl = L.gA + 64 * 4;
     L.pinc = L.ctl + 8;
-    L.psum = L.pinc + PD_GGS_THREADS * 16;
+    L.psum = L.pinc + PD_GGS_PINC_ROWS * 16;
     L.itab = (int4 *)(L.psum + 64 * 16);
     L.inc = L.itab + n_slots;
     L.incoff = (int *)(L.inc + n_inc_lds);
-    L.F = (float *)(L.incoff + 68);
+    L.F = (float *)(L.incoff + PD_GGS_MAX_PCHUNKS * 68);
     L.item = L.F + n_slots * 9 + ((4 - ((n_slots * 9) & 3)) & 3);
     return L;
 }
 static size_t ggs_lds_bytes(int n_slots, int n_items, int n_inc_lds) {
     size_t f9 = (size_t)n_slots * 9;
     f9 += (4 - (f9 & 3)) & 3;
-    return ((size_t)PD_GGS_LDS_FIXED + 68 + f9 + (size_t)n_items * PD_ITEM_VALS) * 4 + (size_t)(n_slots + n_inc_lds) * 16;
+    return ((size_t)PD_GGS_LDS_FIXED + PD_GGS_MAX_PCHUNKS * 68 + f9 + (size_t)n_items * PD_ITEM_VALS) * 4 + (size_t)(n_slots + n_inc_lds) * 16;
 }
 
 // decode one frame's 9-vector into R_cv, t_cv, focal (camera_transform.py:80-97 + pytorch3d
@@ -332,9 +332,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
         }
         L.itab[s] = e;
     }
-    for (int q = tid; q <= N; q += PD_GGS_THREADS) L.incoff[q] = D.inc_off[q];
-    for (int q = tid; q < n_inc_lds; q += PD_GGS_THREADS) L.inc[q] = D.inc[q];
-    const bool inc_lds = n_inc_lds > 0;
+    for (int q = tid; q < D.n_pchunks * (N + 1); q += PD_GGS_THREADS) L.incoff[(q / (N + 1)) * 68 + q % (N + 1)] = D.pchunk_off[q];
     if (tid == 0) {
         L.ctl[0] = 0.0f;
         L.ctl[1] = 0.0f;
@@ -375,12 +373,8 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
     }
     const bool small_n = N <= PD_GGS_THREADS / 16;              // every frame has its own thread group
     const bool spare_wave = N * 16 <= (PD_GGS_WAVES - 1) * 64;   // the last wave is entirely idle in P3b
-    const int n_inc = L.incoff[N];
-    // pair-level backward is possible when every incidence slot fits the LDS result buffer at once
-    const bool pair_path = n_inc <= PD_GGS_THREADS;
-    const int4 my_pair = (pair_path && tid < D.n_pairs) ? D.ptab[tid] : make_int4(0, 0, 0, 0);
-    // this thread's incidence of chunk 0 (constant for the launch)
-    const int4 my_inc = (tid < n_inc) ? (inc_lds ? L.inc[tid] : D.inc[tid]) : make_int4(0, 0, 0, 0);
+    // pair-level backward in chunks of PD_GGS_THREADS pairs (one chunk up to N = 32); chunk 0's table entry is hoisted
+    const int4 my_pair = (tid < D.n_pairs) ? D.ptab[tid] : make_int4(0, 0, 0, 0);
     unsigned epoch = 0;
     int trace_row = 0;
     const bool prof = P.prof != nullptr && blockIdx.x == 0 && wave == P.prof_wave;   // one wave of WG 0
@@ -537,20 +531,23 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
             // 9 dL/dRc_side + 3 dL/dtc_side + 4 dL/dA partials, then P3b sums them per frame in fixed order
             const bool need_rt = S.update_R || S.update_T;
             float fsum = 0.0f;                       // P3b accumulator of thread (frame, component)
-            for (int c0 = 0; c0 < n_inc; c0 += PD_GGS_THREADS) {
-                if (pair_path) {
+            for (int ck = 0; ck < D.n_pchunks; ++ck) {
+                const int *coff = L.incoff + ck * 68;   // this chunk's incidences by frame (positions within L.pinc)
+                {
                     // ---- P3a (pair level): ONE thread per frame pair runs the shared backward chain once and
                     // writes both sides' results straight into their incidence slots.  190 threads = 3 waves, one
                     // per SIMD: cost is per wave-instruction, so this halves the critical path of the per-incidence
                     // form (6 waves, two SIMDs carrying two waves each).
-                    if (tid < D.n_pairs) {
-                        const int pi = my_pair.x & 0xff, pj = my_pair.x >> 8, nit = my_pair.z;
+                    const int pair = ck * PD_GGS_THREADS + tid;
+                    if (pair < D.n_pairs) {
+                        const int4 mp = (ck == 0) ? my_pair : D.ptab[pair];
+                        const int pi = mp.x & 0xff, pj = mp.x >> 8, nit = mp.z;
                         float G[9];
 #pragma unroll
                         for (int c = 0; c < 9; ++c) G[c] = 0.0f;
                         for (int u = 0; u < nit; ++u)
 #pragma unroll
-                            for (int c = 0; c < 9; ++c) G[c] += L.item[(my_pair.y + u) * PD_ITEM_VALS + c];
+                            for (int c = 0; c < 9; ++c) G[c] += L.item[(mp.y + u) * PD_ITEM_VALS + c];
                         float Ri[9], Rj[9], ti[3], tj[3];
 #pragma unroll
                         for (int c = 0; c < 9; ++c) {
@@ -592,7 +589,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
 #undef PD_DA
                         }
                         // side 1 = frame j (camera 2), side 0 = frame i (camera 1); one side at a time (register pressure)
-                        float4 *d0 = (float4 *)(L.pinc + (my_pair.w & 0xffff) * 16), *d1 = (float4 *)(L.pinc + (my_pair.w >> 16) * 16);
+                        float4 *d0 = (float4 *)(L.pinc + (mp.w & 0xffff) * 16), *d1 = (float4 *)(L.pinc + (mp.w >> 16) * 16);
                         if (need_rt) {
                             float gE[9];
 #pragma unroll
@@ -656,139 +653,23 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         }
                         d0[3] = make_float4(oA[0], oA[1], oA[2], oA[3]);
                     }
-                } else {
-                    const int q = c0 + tid;
-                    float oR[9], ot[3], oA[4];
-    #pragma unroll
-                    for (int c = 0; c < 9; ++c) oR[c] = 0.0f;
-                    ot[0] = ot[1] = ot[2] = 0.0f;
-                    oA[0] = oA[1] = oA[2] = oA[3] = 0.0f;
-                    if (q < n_inc) {
-                        const int4 ie = (c0 == 0) ? my_inc : (inc_lds ? L.inc[q] : D.inc[q]);   // (i, j, first item, n_items | side << 16)
-                        const int pi = ie.x, pj = ie.y, side = ie.w >> 16, nit = ie.w & 0xffff;
-                        float G[9];
-    #pragma unroll
-                        for (int c = 0; c < 9; ++c) G[c] = 0.0f;
-                        for (int u = 0; u < nit; ++u)
-    #pragma unroll
-                            for (int c = 0; c < 9; ++c) G[c] += L.item[(ie.z + u) * PD_ITEM_VALS + c];
-                        float Ri[9], Rj[9], ti[3];
-    #pragma unroll
-                        for (int c = 0; c < 9; ++c) {
-                            Ri[c] = L.Rc[pi * 9 + c];
-                            Rj[c] = L.Rc[pj * 9 + c];
-                        }
-    #pragma unroll
-                        for (int c = 0; c < 3; ++c) ti[c] = L.tc[pi * 3 + c];
-                        PairFwd f;
-                        {
-                            float tj[3];
-    #pragma unroll
-                            for (int c = 0; c < 3; ++c) tj[c] = L.tc[pj * 3 + c];
-                            pair_forward(Ri, ti, Rj, tj, f);
-                        }
-                        // Gf = dL/dFo = G^T ; gE = A Gf A^T  (A = [[a0,0,c0],[0,a1,c1],[0,0,1]])
-                        float AG[9], gE[9];
-    #pragma unroll
-                        for (int c = 0; c < 3; ++c) {   // AG = A Gf, Gf[r][c] = G[c][r]
-                            const float g0 = G[c * 3 + 0], g1 = G[c * 3 + 1], g2 = G[c * 3 + 2];
-                            AG[0 * 3 + c] = cam.a0 * g0 + cam.c0 * g2;
-                            AG[1 * 3 + c] = cam.a1 * g1 + cam.c1 * g2;
-                            AG[2 * 3 + c] = g2;
-                        }
-                        if (S.update_FL && side == 0) {
-                            // dL/dA = E A Gf^T + E^T A Gf, entries (0,0),(0,2),(1,1),(1,2); each pair once
-                            float AGt[9];   // A Gf^T, Gf^T = G
-    #pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                const float g0 = G[0 * 3 + c], g1 = G[1 * 3 + c], g2 = G[2 * 3 + c];
-                                AGt[0 * 3 + c] = cam.a0 * g0 + cam.c0 * g2;
-                                AGt[1 * 3 + c] = cam.a1 * g1 + cam.c1 * g2;
-                                AGt[2 * 3 + c] = g2;
-                            }
-    #define PD_DA(r, c)                                                                                      \
-        (f.E[(r)*3 + 0] * AGt[0 * 3 + (c)] + f.E[(r)*3 + 1] * AGt[1 * 3 + (c)] + f.E[(r)*3 + 2] * AGt[2 * 3 + (c)] + \
-         f.E[0 * 3 + (r)] * AG[0 * 3 + (c)] + f.E[1 * 3 + (r)] * AG[1 * 3 + (c)] + f.E[2 * 3 + (r)] * AG[2 * 3 + (c)])
-                            oA[0] = PD_DA(0, 0);
-                            oA[1] = PD_DA(0, 2);
-                            oA[2] = PD_DA(1, 1);
-                            oA[3] = PD_DA(1, 2);
-    #undef PD_DA
-                        }
-                        if (need_rt) {
-    #pragma unroll
-                            for (int r = 0; r < 3; ++r) {   // gE = AG A^T : gE[r][c] = sum_q AG[r][q] A[c][q]
-                                gE[r * 3 + 0] = AG[r * 3 + 0] * cam.a0 + AG[r * 3 + 2] * cam.c0;
-                                gE[r * 3 + 1] = AG[r * 3 + 1] * cam.a1 + AG[r * 3 + 2] * cam.c1;
-                                gE[r * 3 + 2] = AG[r * 3 + 2];
-                            }
-                            // E = R12 H : gR12 = gE H^T ; gH = R12^T gE
-                            const float ex = f.Et[0], ey = f.Et[1], ez = f.Et[2];
-                            float gR12[9], gH[9];
-    #pragma unroll
-                            for (int r = 0; r < 3; ++r) {   // (gE H^T)[r][c] = sum_q gE[r][q] H[c][q]
-                                const float g0 = gE[r * 3 + 0], g1 = gE[r * 3 + 1], g2 = gE[r * 3 + 2];
-                                gR12[r * 3 + 0] = -g1 * ez + g2 * ey;
-                                gR12[r * 3 + 1] = g0 * ez - g2 * ex;
-                                gR12[r * 3 + 2] = -g0 * ey + g1 * ex;
-                            }
-    #pragma unroll
-                            for (int r = 0; r < 3; ++r)
-    #pragma unroll
-                                for (int c = 0; c < 3; ++c)
-                                    gH[r * 3 + c] = f.R12[0 * 3 + r] * gE[0 * 3 + c] + f.R12[1 * 3 + r] * gE[1 * 3 + c] +
-                                                    f.R12[2 * 3 + r] * gE[2 * 3 + c];
-                            const float gEt[3] = {gH[2 * 3 + 1] - gH[1 * 3 + 2], gH[0 * 3 + 2] - gH[2 * 3 + 0],
-                                                  gH[1 * 3 + 0] - gH[0 * 3 + 1]};
-                            float gt12[3];
-    #pragma unroll
-                            for (int a = 0; a < 3; ++a)
-                                gt12[a] = -(f.R12[a * 3 + 0] * gEt[0] + f.R12[a * 3 + 1] * gEt[1] + f.R12[a * 3 + 2] * gEt[2]);
-    #pragma unroll
-                            for (int a = 0; a < 3; ++a)
-    #pragma unroll
-                                for (int c = 0; c < 3; ++c) gR12[a * 3 + c] += -f.t12[a] * gEt[c] - gt12[a] * ti[c];
-                            // side 1: frame is camera 2 (j): gtc_j = gt12 ; gRc_j = gR12 Rc_i
-                            // side 0: frame is camera 1 (i): gtc_i = -R12^T gt12 ; gRc_i = gR12^T Rc_j
-    #pragma unroll
-                            for (int a = 0; a < 3; ++a) {
-                                const float t1 = gt12[a];
-                                const float t0 = -(f.R12[0 * 3 + a] * gt12[0] + f.R12[1 * 3 + a] * gt12[1] + f.R12[2 * 3 + a] * gt12[2]);
-                                ot[a] = side ? t1 : t0;
-    #pragma unroll
-                                for (int c = 0; c < 3; ++c) {
-                                    const float r1 = gR12[a * 3 + 0] * Ri[0 * 3 + c] + gR12[a * 3 + 1] * Ri[1 * 3 + c] +
-                                                     gR12[a * 3 + 2] * Ri[2 * 3 + c];
-                                    const float r0 = gR12[0 * 3 + a] * Rj[0 * 3 + c] + gR12[1 * 3 + a] * Rj[1 * 3 + c] +
-                                                     gR12[2 * 3 + a] * Rj[2 * 3 + c];
-                                    oR[a * 3 + c] = side ? r1 : r0;
-                                }
-                            }
-                        }
-                    }
-                    if (prof) { pq = __builtin_readcyclecounter(); pt[6] += pq - pc; }
-                    float4 *dst = (float4 *)(L.pinc + tid * 16);
-                    dst[0] = make_float4(oR[0], oR[1], oR[2], oR[3]);
-                    dst[1] = make_float4(oR[4], oR[5], oR[6], oR[7]);
-                    dst[2] = make_float4(oR[8], ot[0], ot[1], ot[2]);
-                    dst[3] = make_float4(oA[0], oA[1], oA[2], oA[3]);
                 }
+                if (prof) { pq = __builtin_readcyclecounter(); pt[6] += pq - pc; }
                 __syncthreads();
                 if (prof) { const long long n_ = __builtin_readcyclecounter(); pt[7] += n_ - pq; pq = n_; }
                 // ---- P3b: per-frame sums over the incidences of this chunk, fixed (ascending) order ----
-                if (small_n) {
+                if (small_n) {   // N <= 32: one chunk holds every pair, thread (fb_n, fb_c) owns its sum for the whole launch
                     if (fb_n < N) {
-                        const int lo = max(fb_lo, c0), hi = min(fb_hi, c0 + PD_GGS_THREADS);
-                        float acc2 = (c0 == 0) ? 0.0f : fsum;
-                        for (int e = lo; e < hi; e += 24) {   // 24 LDS loads in flight, summed in order
+                        float acc2 = 0.0f;
+                        for (int e = fb_lo; e < fb_hi; e += 24) {   // 24 LDS loads in flight, summed in order
                             float t24[24];
 #pragma unroll
-                            for (int u = 0; u < 24; ++u) t24[u] = L.pinc[(min(e + u, hi - 1) - c0) * 16 + fb_c];
+                            for (int u = 0; u < 24; ++u) t24[u] = L.pinc[min(e + u, fb_hi - 1) * 16 + fb_c];
 #pragma unroll
-                            for (int u = 0; u < 24; ++u) acc2 += (e + u < hi) ? t24[u] : 0.0f;
+                            for (int u = 0; u < 24; ++u) acc2 += (e + u < fb_hi) ? t24[u] : 0.0f;
                         }
                         fsum = acc2;
-                    } else if (spare_wave && wave == PD_GGS_WAVES - 1 && c0 == 0) {
+                    } else if (spare_wave && wave == PD_GGS_WAVES - 1) {
                         // totals over all items by an otherwise idle wave: one 16-byte read per item gets
                         // {dF22, sum(s valid), n_valid, sum(min(s, max))}
                         float s_sum = 0.0f, s_cnt = 0.0f, s_cl = 0.0f;
@@ -807,19 +688,25 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                             L.ctl[2] = s_cl;
                         }
                     }
-                } else {
+                } else {         // several passes over the frames, partial sums carried across chunks in LDS
                     for (int n0 = 0; n0 < N; n0 += PD_GGS_THREADS / 16) {
                         const int n = n0 + fb_n;
                         if (n < N) {
-                            const int lo = max(L.incoff[n], c0), hi = min(L.incoff[n + 1], c0 + PD_GGS_THREADS);
-                            float acc2 = (c0 == 0) ? 0.0f : L.psum[n * 16 + fb_c];
-                            for (int e = lo; e < hi; ++e) acc2 += L.pinc[(e - c0) * 16 + fb_c];
+                            const int lo = coff[n], hi = coff[n + 1];
+                            float acc2 = (ck == 0) ? 0.0f : L.psum[n * 16 + fb_c];
+                            for (int e = lo; e < hi; e += 16) {   // 16 LDS loads in flight, summed in order
+                                float t16[16];
+#pragma unroll
+                                for (int u = 0; u < 16; ++u) t16[u] = L.pinc[min(e + u, hi - 1) * 16 + fb_c];
+#pragma unroll
+                                for (int u = 0; u < 16; ++u) acc2 += (e + u < hi) ? t16[u] : 0.0f;
+                            }
                             L.psum[n * 16 + fb_c] = acc2;
                         }
                     }
                 }
                 if (prof) { const long long n_ = __builtin_readcyclecounter(); pt[8] += n_ - pq; pq = n_; }
-                if (c0 + PD_GGS_THREADS < n_inc) __syncthreads();   // pinc is rewritten by the next chunk
+                if (ck + 1 < D.n_pchunks) __syncthreads();   // pinc is rewritten by the next chunk
             }
             if (!spare_wave && wave == 0) {
                 float s_sum = 0.0f, s_cnt = 0.0f, s_cl = 0.0f;
@@ -1080,16 +967,29 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
         }
     }
     inc_off[N] = (int)inc.size();
-    // per-pair table: positions of the pair's two incidences (side 0 under frame i, side 1 under frame j)
+    // per-pair table: positions of the pair's two incidences (side 0 under frame i, side 1 under frame j) among the
+    // incidences of its CHUNK of PD_GGS_THREADS pairs, sorted by frame; pchunk_off[chunk][n] = first position of frame n
+    const int n_pchunks = (n_pairs + PD_GGS_THREADS - 1) / PD_GGS_THREADS;
+    if (n_pchunks > PD_GGS_MAX_PCHUNKS) {
+        pd_set_error("pd_ggs_set_matches: %d frame pairs with matches (max %d)", n_pairs, PD_GGS_MAX_PCHUNKS * PD_GGS_THREADS);
+        return PD_ERR_UNSUPPORTED;
+    }
     std::vector<int4> ptab(n_pairs);
+    std::vector<int> pchunk_off((size_t)n_pchunks * (N + 1), 0);
     {
         std::vector<int> pos0(n_pairs, 0), pos1(n_pairs, 0);
-        int q = 0;
-        for (int n = 0; n < N; ++n)
-            for (int p = 0; p < n_pairs; ++p) {
-                if (pair_ij[p].x == n) pos0[p] = q++;
-                if (pair_ij[p].y == n) pos1[p] = q++;
+        for (int ck = 0; ck < n_pchunks; ++ck) {
+            const int p_lo = ck * PD_GGS_THREADS, p_hi = std::min(n_pairs, p_lo + PD_GGS_THREADS);
+            int q = 0;
+            for (int n = 0; n < N; ++n) {
+                pchunk_off[(size_t)ck * (N + 1) + n] = q;
+                for (int p = p_lo; p < p_hi; ++p) {
+                    if (pair_ij[p].x == n) pos0[p] = q++;
+                    if (pair_ij[p].y == n) pos1[p] = q++;
+                }
             }
+            pchunk_off[(size_t)ck * (N + 1) + N] = q;
+        }
         for (int p = 0; p < n_pairs; ++p)
             ptab[p] = make_int4(pair_ij[p].x | (pair_ij[p].y << 8), pair_item_off[p], pair_item_off[p + 1] - pair_item_off[p],
                                 pos0[p] | (pos1[p] << 16));
@@ -1104,7 +1004,8 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     const size_t o_ino = al(o_itm + sizeof(int4) * items.size());
     const size_t o_inc = al(o_ino + sizeof(int) * inc_off.size());
     const size_t o_ptb = al(o_inc + sizeof(int4) * inc.size());
-    const size_t total = al(o_ptb + sizeof(int4) * ptab.size());
+    const size_t o_pco = al(o_ptb + sizeof(int4) * ptab.size());
+    const size_t total = al(o_pco + sizeof(int) * pchunk_off.size());
     std::vector<char> host(total, 0);
     memcpy(host.data() + o_pts, pts.data(), sizeof(float4) * pts.size());
     memcpy(host.data() + o_pij, pair_ij.data(), sizeof(int2) * pair_ij.size());
@@ -1113,6 +1014,7 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     memcpy(host.data() + o_ino, inc_off.data(), sizeof(int) * inc_off.size());
     memcpy(host.data() + o_inc, inc.data(), sizeof(int4) * inc.size());
     memcpy(host.data() + o_ptb, ptab.data(), sizeof(int4) * ptab.size());
+    memcpy(host.data() + o_pco, pchunk_off.data(), sizeof(int) * pchunk_off.size());
     PdSeqHost &h = eng->seqs[seq];
     PD_HIP_CHECK(hipMalloc(&h.blob, total));
     PD_HIP_CHECK(hipMemcpy(h.blob, host.data(), total, hipMemcpyHostToDevice));
@@ -1124,6 +1026,8 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     h.desc.inc_off = (const int *)(base + o_ino);
     h.desc.inc = (const int4 *)(base + o_inc);
     h.desc.ptab = (const int4 *)(base + o_ptb);
+    h.desc.pchunk_off = (const int *)(base + o_pco);
+    h.desc.n_pchunks = n_pchunks;
     h.desc.M = (int)M;
     h.desc.n_pairs = n_pairs;
     h.desc.n_items = n_items;
@@ -1173,18 +1077,13 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     int k = cfg->wgs_per_seq > 0 ? cfg->wgs_per_seq : (max_items + PD_GGS_WAVES - 1) / PD_GGS_WAVES;
     k = std::max(1, std::min(k, device_cus / B));
     if ((size_t)max_items * PD_XCHG_LINE > eng->xchg_granules) k = 1;
-    int n_slots = 0, n_inc_lds = 0, max_inc = 0;
-    for (int b = 0; b < B; ++b) max_inc = std::max(max_inc, 2 * eng->seqs[b].desc.n_pairs);
+    int n_slots = 0;
+    const int n_inc_lds = 0;   // (the per-incidence table is not used by the kernel any more)
     size_t lds = 0;
     for (;;) {
         const int rounds = (max_items + k * PD_GGS_WAVES - 1) / (k * PD_GGS_WAVES);
         n_slots = rounds * PD_GGS_WAVES;
-        n_inc_lds = max_inc;
         lds = ggs_lds_bytes(n_slots, max_items, n_inc_lds);
-        if (lds > 160 * 1024) {   // incidence table stays in global memory if LDS is short
-            n_inc_lds = 0;
-            lds = ggs_lds_bytes(n_slots, max_items, 0);
-        }
         if (lds <= 160 * 1024 || k >= device_cus / B) break;
         ++k;
     }

@@ -14,6 +14,8 @@
 #define PD_MAX_FRAMES 64          // one wavefront lane per frame in the GGS update phase
 #define PD_GGS_THREADS 512        // 8 waves per GGS workgroup
 #define PD_GGS_WAVES (PD_GGS_THREADS / PD_WAVE)
+#define PD_GGS_PINC_ROWS (2 * PD_GGS_THREADS)   // pair backward results in LDS: both sides of one chunk of PD_GGS_THREADS pairs
+#define PD_GGS_MAX_PCHUNKS 4                   // 64 frames -> 2016 pairs -> 4 chunks
 #define PD_GGS_MAX_STAGES 5
 #define PD_ITEM_MAX_MATCHES 512   // one work item = <= 512 matches of one frame pair (8 per lane)
 #define PD_ITEM_VALS 12           // 9 dL/dF sums + sum(s valid) + n_valid + sum(min(s, max))
@@ -41,6 +43,8 @@ struct PdSeqDesc {
     const int4 *inc;           // [2 * n_pairs] (i, j, first item, n_items | side << 16); side 0: frame is i
     const int4 *ptab;          // [n_pairs] (i | j << 8, first item, n_items, pos_side0 | pos_side1 << 16): where the
                                //   two incidences of the pair sit in `inc` (pair-level backward writes there)
+    const int *pchunk_off;     // [n_pchunks][n_frames + 1] per chunk of PD_GGS_THREADS pairs: CSR of the chunk's incidences by frame
+    int n_pchunks;             // (ptab positions are chunk-local; one chunk <=> n_pairs <= PD_GGS_THREADS: then == inc_off)
     int M, n_pairs, n_items, n_frames;
     float sc, cx, cy;          // min(h, w) / 2, w / 2, h / 2 (opencv_from_cameras_projection)
     int pad;
