@@ -211,13 +211,12 @@ struct Lds {
     float *pinc;   // [1024*16] backward results of the current chunk of pairs, one row per (pair, side), frame-sorted
     float *psum;   // [64*16]  per-frame partial sums across chunks (N > 32 only)
     int4 *itab;    // [n_slots] (first match, count, i, j) of the local items
-    int4 *inc;     // [n_inc] incidence entries (only when they fit; else read from global)
     int *incoff;   // [PD_GGS_MAX_PCHUNKS][68] per chunk of pairs: CSR offsets of its incidences per frame
     float *F;      // [n_slots*9]
     float *item;   // [n_items*12]
 };
 
-__device__ __forceinline__ Lds carve(float *base, int n_slots, int n_inc_lds) {
+__device__ __forceinline__ Lds carve(float *base, int n_slots) {
     Lds L;
     L.Rc = base;
     L.tc = L.Rc + 64 * 9;
@@ -231,16 +230,15 @@ __device__ __forceinline__ Lds carve(float *base, int n_slots, int n_inc_lds) {
     L.pinc = L.ctl + 8;
     L.psum = L.pinc + PD_GGS_PINC_ROWS * 16;
     L.itab = (int4 *)(L.psum + 64 * 16);
-    L.inc = L.itab + n_slots;
-    L.incoff = (int *)(L.inc + n_inc_lds);
+    L.incoff = (int *)(L.itab + n_slots);
     L.F = (float *)(L.incoff + PD_GGS_MAX_PCHUNKS * 68);
     L.item = L.F + n_slots * 9 + ((4 - ((n_slots * 9) & 3)) & 3);
     return L;
 }
-static size_t ggs_lds_bytes(int n_slots, int n_items, int n_inc_lds) {
+static size_t ggs_lds_bytes(int n_slots, int n_items) {
     size_t f9 = (size_t)n_slots * 9;
     f9 += (4 - (f9 & 3)) & 3;
-    return ((size_t)PD_GGS_LDS_FIXED + PD_GGS_MAX_PCHUNKS * 68 + f9 + (size_t)n_items * PD_ITEM_VALS) * 4 + (size_t)(n_slots + n_inc_lds) * 16;
+    return ((size_t)PD_GGS_LDS_FIXED + PD_GGS_MAX_PCHUNKS * 68 + f9 + (size_t)n_items * PD_ITEM_VALS) * 4 + (size_t)n_slots * 16;
 }
 
 // decode one frame's 9-vector into R_cv, t_cv, focal (camera_transform.py:80-97 + pytorch3d
@@ -301,7 +299,7 @@ __device__ __forceinline__ void decode_all(const Lds &L, const float *xr, int la
 // --------------------------------------------------------------------------------------------
 // the kernel
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, int B, int n_slots, int n_inc_lds) {
+__global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, int B, int n_slots) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x % B, wg = blockIdx.x / B;   // XCD-aware: see header comment
@@ -309,7 +307,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
     const int N = P.N, k = P.k;
     const int nW = k * PD_GGS_WAVES;
     const int n_items = D.n_items;
-    const Lds L = carve(smem, n_slots, n_inc_lds);
+    const Lds L = carve(smem, n_slots);
     float *xg = P.x + (size_t)b * N * PD_POSE_DIM;
     u64 *xchg = P.xchg ? P.xchg + (size_t)b * 2 * P.xchg_stride : nullptr;
 
@@ -952,21 +950,11 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     }
     pair_item_off.push_back((int)items.size());
     const int n_pairs = (int)pair_ij.size(), n_items = (int)items.size();
-    std::vector<int> inc_off(N + 1, 0);
-    std::vector<int4> inc;
-    for (int n = 0; n < N; ++n) {
-        inc_off[n] = (int)inc.size();
-        for (int p = 0; p < n_pairs; ++p) {
-            const int nit = pair_item_off[p + 1] - pair_item_off[p];
-            if (nit > 0xffff) {
-                pd_set_error("pd_ggs_set_matches: a frame pair holds too many matches");
-                return PD_ERR_UNSUPPORTED;
-            }
-            if (pair_ij[p].x == n) inc.push_back(make_int4(pair_ij[p].x, pair_ij[p].y, pair_item_off[p], nit | (0 << 16)));
-            if (pair_ij[p].y == n) inc.push_back(make_int4(pair_ij[p].x, pair_ij[p].y, pair_item_off[p], nit | (1 << 16)));
+    for (int p = 0; p < n_pairs; ++p)
+        if (pair_item_off[p + 1] - pair_item_off[p] > 0xffff) {
+            pd_set_error("pd_ggs_set_matches: a frame pair holds too many matches");
+            return PD_ERR_UNSUPPORTED;
         }
-    }
-    inc_off[N] = (int)inc.size();
     // per-pair table: positions of the pair's two incidences (side 0 under frame i, side 1 under frame j) among the
     // incidences of its CHUNK of PD_GGS_THREADS pairs, sorted by frame; pchunk_off[chunk][n] = first position of frame n
     const int n_pchunks = (n_pairs + PD_GGS_THREADS - 1) / PD_GGS_THREADS;
@@ -995,15 +983,13 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
                                 pos0[p] | (pos1[p] << 16));
     }
 
-    // one blob: pts | pair_ij | pair_item_off | items | inc_off | inc   (16-byte aligned pieces)
+    // one blob: pts | pair_ij | pair_item_off | items | ptab | pchunk_off   (aligned pieces)
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_pts = 0;
     const size_t o_pij = al(o_pts + sizeof(float4) * pts.size());
     const size_t o_pio = al(o_pij + sizeof(int2) * pair_ij.size());
     const size_t o_itm = al(o_pio + sizeof(int) * pair_item_off.size());
-    const size_t o_ino = al(o_itm + sizeof(int4) * items.size());
-    const size_t o_inc = al(o_ino + sizeof(int) * inc_off.size());
-    const size_t o_ptb = al(o_inc + sizeof(int4) * inc.size());
+    const size_t o_ptb = al(o_itm + sizeof(int4) * items.size());
     const size_t o_pco = al(o_ptb + sizeof(int4) * ptab.size());
     const size_t total = al(o_pco + sizeof(int) * pchunk_off.size());
     std::vector<char> host(total, 0);
@@ -1011,8 +997,6 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     memcpy(host.data() + o_pij, pair_ij.data(), sizeof(int2) * pair_ij.size());
     memcpy(host.data() + o_pio, pair_item_off.data(), sizeof(int) * pair_item_off.size());
     memcpy(host.data() + o_itm, items.data(), sizeof(int4) * items.size());
-    memcpy(host.data() + o_ino, inc_off.data(), sizeof(int) * inc_off.size());
-    memcpy(host.data() + o_inc, inc.data(), sizeof(int4) * inc.size());
     memcpy(host.data() + o_ptb, ptab.data(), sizeof(int4) * ptab.size());
     memcpy(host.data() + o_pco, pchunk_off.data(), sizeof(int) * pchunk_off.size());
     PdSeqHost &h = eng->seqs[seq];
@@ -1023,8 +1007,6 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     h.desc.pair_ij = (const int2 *)(base + o_pij);
     h.desc.pair_item_off = (const int *)(base + o_pio);
     h.desc.items = (const int4 *)(base + o_itm);
-    h.desc.inc_off = (const int *)(base + o_ino);
-    h.desc.inc = (const int4 *)(base + o_inc);
     h.desc.ptab = (const int4 *)(base + o_ptb);
     h.desc.pchunk_off = (const int *)(base + o_pco);
     h.desc.n_pchunks = n_pchunks;
@@ -1078,12 +1060,11 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     k = std::max(1, std::min(k, device_cus / B));
     if ((size_t)max_items * PD_XCHG_LINE > eng->xchg_granules) k = 1;
     int n_slots = 0;
-    const int n_inc_lds = 0;   // (the per-incidence table is not used by the kernel any more)
     size_t lds = 0;
     for (;;) {
         const int rounds = (max_items + k * PD_GGS_WAVES - 1) / (k * PD_GGS_WAVES);
         n_slots = rounds * PD_GGS_WAVES;
-        lds = ggs_lds_bytes(n_slots, max_items, n_inc_lds);
+        lds = ggs_lds_bytes(n_slots, max_items);
         if (lds <= 160 * 1024 || k >= device_cus / B) break;
         ++k;
     }
@@ -1120,7 +1101,7 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
         const size_t n_zero = 2 * eng->xchg_granules * B;
         hipLaunchKernelGGL(pd_ggs_zero_kernel, dim3(256), dim3(256), 0, s, eng->d_xchg, n_zero);
     }
-    hipLaunchKernelGGL(pd_ggs_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots, n_inc_lds);
+    hipLaunchKernelGGL(pd_ggs_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }

@@ -39,12 +39,10 @@ struct PdSeqDesc {
     const int2 *pair_ij;       // [n_pairs] (i, j) frame indices, p2^T F p1 = 0 with 1 = i, 2 = j
     const int *pair_item_off;  // [n_pairs + 1] items of pair p are items[off[p] .. off[p+1])
     const int4 *items;         // [n_items] (pair, first match, match count, 0)
-    const int *inc_off;        // [n_frames + 1] incidence CSR: pairs touching frame n
-    const int4 *inc;           // [2 * n_pairs] (i, j, first item, n_items | side << 16); side 0: frame is i
-    const int4 *ptab;          // [n_pairs] (i | j << 8, first item, n_items, pos_side0 | pos_side1 << 16): where the
-                               //   two incidences of the pair sit in `inc` (pair-level backward writes there)
+    const int4 *ptab;          // [n_pairs] (i | j << 8, first item, n_items, pos_side0 | pos_side1 << 16): rows of the pair's two
+                               //   results (side 0 -> frame i, side 1 -> frame j) among its chunk's frame-sorted incidences
     const int *pchunk_off;     // [n_pchunks][n_frames + 1] per chunk of PD_GGS_THREADS pairs: CSR of the chunk's incidences by frame
-    int n_pchunks;             // (ptab positions are chunk-local; one chunk <=> n_pairs <= PD_GGS_THREADS: then == inc_off)
+    int n_pchunks;             // (ptab positions are chunk-local)
     int M, n_pairs, n_items, n_frames;
     float sc, cx, cy;          // min(h, w) / 2, w / 2, h / 2 (opencv_from_cameras_projection)
     int pad;
