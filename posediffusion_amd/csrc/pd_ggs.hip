@@ -296,6 +296,22 @@ __device__ __forceinline__ void decode_all(const Lds &L, const float *xr, int la
     }
 }
 
+// the (<= 4) two-match steps of an item as straight-line code per step count: without the per-step branch the
+// scheduler interleaves the independent steps, which hides the VALU dependency latency two waves per SIMD cannot
+#define PD_P2_STEP(M, j) sampson_step2(M[2 * (j)], M[2 * (j) + 1], (lane + 128 * (j)) < e.y, (lane + 128 * (j) + 64) < e.y, Fm, P.sampson_max, acc2)
+#define PD_P2_STEPS(M)                                                        \
+    do {                                                                      \
+        if (npairs >= 4) {                                                    \
+            PD_P2_STEP(M, 0); PD_P2_STEP(M, 1); PD_P2_STEP(M, 2); PD_P2_STEP(M, 3); \
+        } else if (npairs == 3) {                                             \
+            PD_P2_STEP(M, 0); PD_P2_STEP(M, 1); PD_P2_STEP(M, 2);             \
+        } else if (npairs == 2) {                                             \
+            PD_P2_STEP(M, 0); PD_P2_STEP(M, 1);                               \
+        } else if (npairs == 1) {                                             \
+            PD_P2_STEP(M, 0);                                                 \
+        }                                                                     \
+    } while (0)
+
 // --------------------------------------------------------------------------------------------
 // the kernel
 // --------------------------------------------------------------------------------------------
@@ -428,12 +444,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 for (int c = 0; c < PD_ITEM_VALS; ++c) acc2[c] = (v2f){0.0f, 0.0f};
                 const int npairs = (e.y + 127) >> 7;
                 if (resident) {   // straight from the resident registers (no copies)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (j < npairs)
-                            sampson_step2(mres[2 * j], mres[2 * j + 1], (lane + 128 * j) < e.y, (lane + 128 * j + 64) < e.y, Fm,
-                                          P.sampson_max, acc2);
-                    }
+                    PD_P2_STEPS(mres);
                 } else {
                     // stream this item: all (<= 8) lines in flight at once, indices clamped (no
                     // predicated loads), out-of-range lanes are masked in the arithmetic instead
@@ -445,12 +456,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         const int m = lane + 64 * st;
                         mb[st] = pts[m < e.y ? m : last];
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (j < npairs)
-                            sampson_step2(mb[2 * j], mb[2 * j + 1], (lane + 128 * j) < e.y, (lane + 128 * j + 64) < e.y, Fm,
-                                          P.sampson_max, acc2);
-                    }
+                    PD_P2_STEPS(mb);
                 }
                 float acc[PD_ITEM_VALS];
 #pragma unroll

@@ -16,7 +16,7 @@ for B in (8,):
         md = synth.make_matches(enc, H, W, per_pair=300, seed=2000 + b)
         eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
     x0 = torch.cat([synth.perturb_pose(synth.make_cameras(N, seed=2000 + b), seed=7 + b) for b in range(B)]).to(dev)
-    for k, pw in ((0, 2), (0, 6), (12, 2), (12, 6)):
+    for k, pw in ((0, 1), (0, 6), (8, 1), (8, 6)):
         cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=k)
         eng.ggs_prof(pw)
         eng.ggs_guide(x0, 0, cfg)
