@@ -89,8 +89,11 @@ typedef struct pd_ggs_cfg {
     int32_t min_matches;    /* 10    */
     float momentum;         /* 0.9 (torch.optim.SGD at :89) */
     int32_t wgs_per_seq;    /* 0 = engine picks; >0 = workgroups cooperating on one sequence */
-    int32_t reserved;
+    int32_t reserved;       /* flags; 0 by default.  PD_GGS_CFG_FORCE_ONE_HOP: for sequences with more than 32 frames keep
+                             * the single-exchange kernel (every workgroup back-propagates all pairs) instead of the
+                             * two-hop kernel that distributes the backward (testing / comparison) */
 } pd_ggs_cfg;
+#define PD_GGS_CFG_FORCE_ONE_HOP 1
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
 

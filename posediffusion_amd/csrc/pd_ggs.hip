@@ -552,110 +552,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         for (int u = 0; u < nit; ++u)
 #pragma unroll
                             for (int c = 0; c < 9; ++c) G[c] += L.item[(mp.y + u) * PD_ITEM_VALS + c];
-                        float Ri[9], Rj[9], ti[3], tj[3];
-#pragma unroll
-                        for (int c = 0; c < 9; ++c) {
-                            Ri[c] = L.Rc[pi * 9 + c];
-                            Rj[c] = L.Rc[pj * 9 + c];
-                        }
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            ti[c] = L.tc[pi * 3 + c];
-                            tj[c] = L.tc[pj * 3 + c];
-                        }
-                        PairFwd f;
-                        pair_forward(Ri, ti, Rj, tj, f);
-                        float AG[9];
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {   // AG = A Gf, Gf[r][c] = G[c][r]
-                            const float g0 = G[c * 3 + 0], g1 = G[c * 3 + 1], g2 = G[c * 3 + 2];
-                            AG[0 * 3 + c] = cam.a0 * g0 + cam.c0 * g2;
-                            AG[1 * 3 + c] = cam.a1 * g1 + cam.c1 * g2;
-                            AG[2 * 3 + c] = g2;
-                        }
-                        float oA[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                        if (S.update_FL) {   // dL/dA = E A Gf^T + E^T A Gf, entries (0,0),(0,2),(1,1),(1,2)
-                            float AGt[9];
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                const float g0 = G[0 * 3 + c], g1 = G[1 * 3 + c], g2 = G[2 * 3 + c];
-                                AGt[0 * 3 + c] = cam.a0 * g0 + cam.c0 * g2;
-                                AGt[1 * 3 + c] = cam.a1 * g1 + cam.c1 * g2;
-                                AGt[2 * 3 + c] = g2;
-                            }
-#define PD_DA(r, c)                                                                                      \
-    (f.E[(r)*3 + 0] * AGt[0 * 3 + (c)] + f.E[(r)*3 + 1] * AGt[1 * 3 + (c)] + f.E[(r)*3 + 2] * AGt[2 * 3 + (c)] + \
-     f.E[0 * 3 + (r)] * AG[0 * 3 + (c)] + f.E[1 * 3 + (r)] * AG[1 * 3 + (c)] + f.E[2 * 3 + (r)] * AG[2 * 3 + (c)])
-                            oA[0] = PD_DA(0, 0);
-                            oA[1] = PD_DA(0, 2);
-                            oA[2] = PD_DA(1, 1);
-                            oA[3] = PD_DA(1, 2);
-#undef PD_DA
-                        }
-                        // side 1 = frame j (camera 2), side 0 = frame i (camera 1); one side at a time (register pressure)
-                        float4 *d0 = (float4 *)(L.pinc + (mp.w & 0xffff) * 16), *d1 = (float4 *)(L.pinc + (mp.w >> 16) * 16);
-                        if (need_rt) {
-                            float gE[9];
-#pragma unroll
-                            for (int r = 0; r < 3; ++r) {   // gE = AG A^T
-                                gE[r * 3 + 0] = AG[r * 3 + 0] * cam.a0 + AG[r * 3 + 2] * cam.c0;
-                                gE[r * 3 + 1] = AG[r * 3 + 1] * cam.a1 + AG[r * 3 + 2] * cam.c1;
-                                gE[r * 3 + 2] = AG[r * 3 + 2];
-                            }
-                            const float ex = f.Et[0], ey = f.Et[1], ez = f.Et[2];
-                            float gR12[9], gH[9];
-#pragma unroll
-                            for (int r = 0; r < 3; ++r) {   // gR12 = gE H^T
-                                const float g0 = gE[r * 3 + 0], g1 = gE[r * 3 + 1], g2 = gE[r * 3 + 2];
-                                gR12[r * 3 + 0] = -g1 * ez + g2 * ey;
-                                gR12[r * 3 + 1] = g0 * ez - g2 * ex;
-                                gR12[r * 3 + 2] = -g0 * ey + g1 * ex;
-                            }
-#pragma unroll
-                            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                                for (int c = 0; c < 3; ++c)   // gH = R12^T gE
-                                    gH[r * 3 + c] = f.R12[0 * 3 + r] * gE[0 * 3 + c] + f.R12[1 * 3 + r] * gE[1 * 3 + c] +
-                                                    f.R12[2 * 3 + r] * gE[2 * 3 + c];
-                            const float gEt[3] = {gH[2 * 3 + 1] - gH[1 * 3 + 2], gH[0 * 3 + 2] - gH[2 * 3 + 0],
-                                                  gH[1 * 3 + 0] - gH[0 * 3 + 1]};
-                            float gt12[3];
-#pragma unroll
-                            for (int a = 0; a < 3; ++a)
-                                gt12[a] = -(f.R12[a * 3 + 0] * gEt[0] + f.R12[a * 3 + 1] * gEt[1] + f.R12[a * 3 + 2] * gEt[2]);
-#pragma unroll
-                            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                                for (int c = 0; c < 3; ++c) gR12[a * 3 + c] += -f.t12[a] * gEt[c] - gt12[a] * ti[c];
-                            float oR[9];
-#pragma unroll
-                            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                                for (int c = 0; c < 3; ++c)   // gRc_j = gR12 Rc_i
-                                    oR[a * 3 + c] = gR12[a * 3 + 0] * Ri[0 * 3 + c] + gR12[a * 3 + 1] * Ri[1 * 3 + c] +
-                                                    gR12[a * 3 + 2] * Ri[2 * 3 + c];
-                            d1[0] = make_float4(oR[0], oR[1], oR[2], oR[3]);
-                            d1[1] = make_float4(oR[4], oR[5], oR[6], oR[7]);
-                            d1[2] = make_float4(oR[8], gt12[0], gt12[1], gt12[2]);          // gtc_j = gt12
-                            d1[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                            float ot[3];
-#pragma unroll
-                            for (int a = 0; a < 3; ++a) {
-                                ot[a] = -(f.R12[0 * 3 + a] * gt12[0] + f.R12[1 * 3 + a] * gt12[1] + f.R12[2 * 3 + a] * gt12[2]);   // -R12^T gt12
-#pragma unroll
-                                for (int c = 0; c < 3; ++c)   // gRc_i = gR12^T Rc_j
-                                    oR[a * 3 + c] = gR12[0 * 3 + a] * Rj[0 * 3 + c] + gR12[1 * 3 + a] * Rj[1 * 3 + c] +
-                                                    gR12[2 * 3 + a] * Rj[2 * 3 + c];
-                            }
-                            d0[0] = make_float4(oR[0], oR[1], oR[2], oR[3]);
-                            d0[1] = make_float4(oR[4], oR[5], oR[6], oR[7]);
-                            d0[2] = make_float4(oR[8], ot[0], ot[1], ot[2]);
-                        } else {
-                            const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                            d1[0] = z4; d1[1] = z4; d1[2] = z4; d1[3] = z4;
-                            d0[0] = z4; d0[1] = z4; d0[2] = z4;
-                        }
-                        d0[3] = make_float4(oA[0], oA[1], oA[2], oA[3]);
+#include "pd_ggs_pairbwd.inc"
                     }
                 }
                 if (prof) { pq = __builtin_readcyclecounter(); pt[6] += pq - pc; }
@@ -751,114 +648,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
             __syncthreads();
             PD_PROF(3);
 
-            // ---- P4 (wave 0): totals, early exit, quaternion/focal chain, clip, momentum SGD ----
-            if (wave == 0) {
-                const float s_sum = L.cam[6], s_cnt = L.cam[7], s_cl = L.ctl[2];
-                float ga[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) ga[c] = wave_allsum(lane < N ? L.gA[lane * 4 + c] : 0.0f);
-                last_print = s_cl * inv_M;
-                last_cnt = s_cnt;
-                // len(valid) / n_frames < min_matches -> break   (geometry_guided_sampling.py:104-108)
-                const bool done = (!P.eval_only) && P.min_matches > 0 && (s_cnt < (float)P.min_matches * (float)N);
-                if (!done) {
-                    const float inv_cnt = pd_rcp(s_cnt);
-                    const float loss = s_sum * inv_cnt;                   // valid.mean()  :110
-                    last_loss = loss;
-                    float g[9];
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) g[c] = 0.0f;
-                    if (lane < N) {
-                        if (S.update_T) {
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) g[c] = L.gT[lane * 3 + c] * inv_cnt;
-                        }
-                        if (S.update_R) {
-                            // R = I + two_s * Pm(q): chain rule to the (unnormalised) quaternion
-                            const float r = xr[3], i = xr[4], j = xr[5], kq = xr[6];
-                            const float n2 = r * r + i * i + j * j + kq * kq;
-                            const float rn2 = pd_rcp(n2);
-                            const float ts = 2.0f * rn2;
-                            float gR[9];
-#pragma unroll
-                            for (int c = 0; c < 9; ++c) gR[c] = L.gR[lane * 9 + c];
-                            const float gts = gR[0] * -(j * j + kq * kq) + gR[1] * (i * j - kq * r) + gR[2] * (i * kq + j * r) +
-                                              gR[3] * (i * j + kq * r) + gR[4] * -(i * i + kq * kq) + gR[5] * (j * kq - i * r) +
-                                              gR[6] * (i * kq - j * r) + gR[7] * (j * kq + i * r) + gR[8] * -(i * i + j * j);
-                            float h[9];
-#pragma unroll
-                            for (int c = 0; c < 9; ++c) h[c] = ts * gR[c];
-                            const float qs = gts * (-4.0f * rn2 * rn2);
-                            const float gq_r = -kq * h[1] + j * h[2] + kq * h[3] - i * h[5] - j * h[6] + i * h[7] + qs * r;
-                            const float gq_i = j * h[1] + kq * h[2] + j * h[3] - 2.0f * i * h[4] - r * h[5] + kq * h[6] +
-                                               r * h[7] - 2.0f * i * h[8] + qs * i;
-                            const float gq_j = -2.0f * j * h[0] + i * h[1] + r * h[2] + i * h[3] + kq * h[5] - r * h[6] +
-                                               kq * h[7] - 2.0f * j * h[8] + qs * j;
-                            const float gq_k = -2.0f * kq * h[0] - r * h[1] + i * h[2] + r * h[3] - 2.0f * kq * h[4] +
-                                               j * h[5] + i * h[6] + j * h[7] + qs * kq;
-                            g[3] = gq_r * inv_cnt;
-                            g[4] = gq_i * inv_cnt;
-                            g[5] = gq_j * inv_cnt;
-                            g[6] = gq_k * inv_cnt;
-                        }
-                        if (S.update_FL) {
-                            // A00 = 1/(f sc), A02 = -cx/(f sc): dA/df ; mean over frames ; exp ; clamp mask
-                            const float fbx = L.cam[4], fby = L.cam[5];
-                            const float kx = pd_rcp(fbx * fbx * D.sc), ky = pd_rcp(fby * fby * D.sc), rNn = pd_rcp((float)N);
-                            const float gfx = (ga[1] * D.cx - ga[0]) * kx;
-                            const float gfy = (ga[3] * D.cy - ga[2]) * ky;
-                            g[7] = gfx * rNn * L.fl[lane * 2 + 0] * L.flp[lane * 2 + 0] * inv_cnt;
-                            g[8] = gfy * rNn * L.fl[lane * 2 + 1] * L.flp[lane * 2 + 1] * inv_cnt;
-                        }
-                    }
-                    if (P.eval_only) {
-                        if (lane < N) {
-#pragma unroll
-                            for (int c = 0; c < 9; ++c) P.grad_out[((size_t)b * N + lane) * 9 + c] = g[c];
-                        }
-                        if (lane == 0 && wg == 0) {
-                            P.loss_out[b * 4 + 0] = loss;
-                            P.loss_out[b * 4 + 1] = s_cnt;
-                            P.loss_out[b * 4 + 2] = last_print;
-                            P.loss_out[b * 4 + 3] = 0.0f;
-                        }
-                    } else {
-                        // masked-norm clip (:114-121) + SGD momentum step (:122)
-                        float gn2 = 0.0f, xn2 = 0.0f;
-#pragma unroll
-                        for (int c = 0; c < 9; ++c) {
-                            gn2 += g[c] * g[c];
-                            xn2 += (fabsf(g[c]) > 0.0f) ? xr[c] * xr[c] : 0.0f;
-                        }
-                        const float gnorm = pd_sqrt(wave_allsum(gn2));
-                        const float xnorm = pd_sqrt(wave_allsum(xn2));
-                        const float max_norm = P.alpha * xnorm * pd_rcp(P.lr);
-                        const float coef = fminf(max_norm * pd_rcp(gnorm + 1e-6f), 1.0f);
-#pragma unroll
-                        for (int c = 0; c < 9; ++c) {
-                            const float gc = g[c] * coef;
-                            mom[c] = (stepped == 0) ? gc : P.momentum * mom[c] + gc;
-                            xr[c] = xr[c] - P.lr * mom[c];
-                        }
-                        ++stepped;
-                        if (P.trace && wg == 0 && trace_row < P.trace_iters) {
-                            float *tr = P.trace + ((size_t)b * P.trace_iters + trace_row) * (N * 9 + 3);
-                            if (lane < N) {
-#pragma unroll
-                                for (int c = 0; c < 9; ++c) tr[lane * 9 + c] = xr[c];
-                            }
-                            if (lane == 0) {
-                                tr[N * 9 + 0] = loss;
-                                tr[N * 9 + 1] = s_cnt;
-                                tr[N * 9 + 2] = gnorm;
-                            }
-                        }
-                        ++trace_row;
-                        decode_all(L, xr, lane, N, D);
-                    }
-                }
-                if (lane == 0) L.ctl[0] = (done || P.eval_only) ? 1.0f : 0.0f;
-            }
+#include "pd_ggs_p4.inc"
             __syncthreads();
             PD_PROF(4);
             if (prof) pt[5] += 1;
@@ -875,6 +665,294 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
     }
     if (prof && lane == 0) {
         for (int i = 0; i < 10; ++i) P.prof[i] = pt[i];
+    }
+    if (own && wg == 0 && !P.eval_only) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) xg[lane * 9 + c] = xr[c];
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// the two-hop kernel for many frames (N > 32: several chunks of pairs)
+//
+// pd_ggs_kernel lets EVERY workgroup of a sequence gather all item sums and back-propagate all pairs;
+// that replication is cheap at N = 20 (190 pairs) and dominates at N = 50 (1 225 pairs: 18 MB of
+// exchange reads and 3 chunks of pair backward per iteration and workgroup).  Here the backward is
+// distributed instead -- same arithmetic per pair and per frame, two small exchanges per iteration:
+//   P1/P2  as before, but a workgroup keeps its items' sums to itself (needs one item per pair);
+//   P3a    it back-propagates only ITS pairs and publishes the two 16-float results of each pair as
+//          one exchange line per (pair, side), at the row the frame-sorted order gives it   (hop 1)
+//   P3b    the owner of frame n (workgroup n % k) gathers that frame's rows, sums them in row order and
+//          publishes the frame's 16 gradient sums; every workgroup also publishes its loss totals   (hop 2)
+//   P4     every workgroup gathers the N frame lines + k total lines (a few KB) and runs the update.
+// Exchange lines live in the sequence's slot of the same tagged-granule buffer:
+//   [0, n_inc) (pair, side) rows | [n_inc, n_inc + k) per-workgroup totals | [n_inc + k, + N) per-frame sums.
+// --------------------------------------------------------------------------------------------
+template <int U>
+__device__ __forceinline__ bool ggs2_gather(const u64 *src_lines, int piece0, int n_piece, int pieces_per_line, unsigned epoch,
+                                            float *dst, int dst_stride, unsigned *err_flag) {
+    // piece p = (line p / pieces_per_line, 16-byte part p % pieces_per_line) -> dst[line * dst_stride + 2 * part .. + 1]
+    bool fail = false;
+    for (int p0 = piece0; p0 < n_piece; p0 += U * PD_GGS_THREADS) {
+        unsigned spins = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + u * PD_GGS_THREADS;
+            if (p < n_piece) {
+                const int line = p / pieces_per_line, part = p - line * pieces_per_line;
+                const u64 *a = src_lines + (size_t)line * PD_XCHG_LINE + part * 2;
+                u32x4 v;
+                for (;;) {
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+                    if (v[1] == epoch && v[3] == epoch) break;
+                    if (++spins > (1u << 20) ||
+                        ((spins & 255u) == 0 && __hip_atomic_load(err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        fail = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                dst[line * dst_stride + part * 2] = __uint_as_float(v[0]);
+                dst[line * dst_stride + part * 2 + 1] = __uint_as_float(v[2]);
+            }
+        }
+    }
+    return !fail;
+}
+
+__global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, int B, int n_slots) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x % B, wg = blockIdx.x / B;
+    const PdSeqDesc D = P.seqs[b];
+    const int N = P.N, k = P.k;
+    const int nW = k * PD_GGS_WAVES;
+    const int n_items = D.n_items;          // == D.n_pairs (one item per pair)
+    const int n_inc = 2 * D.n_pairs;
+    const Lds L = carve(smem, n_slots);
+    float *xg = P.x + (size_t)b * N * PD_POSE_DIM;
+    u64 *xbase = P.xchg + (size_t)b * 2 * P.xchg_stride;
+    // LDS reuse: L.item holds this workgroup's item sums [n_slots][12]; L.pinc rows [0, 2 n_slots <= 512) the results of
+    // its pairs, rows [512, 576) the gathered rows of an owned frame, rows [640, 704) the gathered totals [k <= 256][4],
+    // rows [768, 800) the exchange row of each local (pair, side); L.psum the gathered frame sums [N][16]
+    float *own_rows = L.pinc;
+    float *frame_rows = L.pinc + 512 * 16;
+    float *tot_rows = L.pinc + 640 * 16;
+    int *grow = (int *)(L.pinc + 768 * 16);
+
+    float xr[9], mom[9];
+    const bool own = (wave == 0 && lane < N);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        xr[c] = own ? xg[lane * 9 + c] : 0.0f;
+        mom[c] = 0.0f;
+    }
+    for (int s = tid; s < n_slots; s += PD_GGS_THREADS) {
+        const int item = wg * PD_GGS_WAVES + (s & 7) + (s >> 3) * nW;
+        int4 e = make_int4(0, 0, 0, 0);
+        int2 gp = make_int2(0, 0);
+        if (item < n_items) {
+            const int4 it = D.items[item];
+            const int2 ij = D.pair_ij[it.x];
+            e = make_int4(it.y, it.z, ij.x, ij.y);
+            gp = D.gpos[it.x];
+        }
+        L.itab[s] = e;
+        grow[2 * s] = gp.x;
+        grow[2 * s + 1] = gp.y;
+    }
+    for (int q = tid; q <= N; q += PD_GGS_THREADS) L.incoff[q] = D.ginc_off[q];
+    if (tid == 0) {
+        L.ctl[0] = 0.0f;
+        L.ctl[1] = 0.0f;
+    }
+    if (wave == 0) decode_all(L, xr, lane, N, D);
+    __syncthreads();
+    // one item per wave (the usual case here: k = ceil(pairs / 8)): its matches stay in registers for the whole launch
+    const bool resident = (n_slots == PD_GGS_WAVES);
+    float4 mres[8];
+    {
+        const int4 e = L.itab[wave];
+        const int last = e.y > 0 ? e.y - 1 : 0;
+        const float4 *pts = D.pts + e.x;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = lane + 64 * q;
+            mres[q] = (resident && e.y > 0) ? pts[m < e.y ? m : last] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    unsigned epoch = 0;
+    int trace_row = 0;
+    const float inv_M = 1.0f / (float)D.M;
+    for (int st = 0; st < P.n_stages; ++st) {
+        const PdGgsStage S = P.stages[st];
+        int stepped = 0;
+        float last_print = __int_as_float(0x7fc00000), last_cnt = 0.0f, last_loss = __int_as_float(0x7fc00000);
+        const bool need_rt = S.update_R || S.update_T;
+        for (int it = 0; it < S.iters; ++it) {
+            // ---- P1: F for the pairs of this workgroup's items
+            const Cam cam = {L.cam[0], L.cam[1], L.cam[2], L.cam[3]};
+            for (int s = tid; s < n_slots; s += PD_GGS_THREADS) {
+                const int4 e = L.itab[s];
+                if (e.y > 0) {
+                    float Ri[9], Rj[9], ti[3], tj[3];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) {
+                        Ri[c] = L.Rc[e.z * 9 + c];
+                        Rj[c] = L.Rc[e.w * 9 + c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        ti[c] = L.tc[e.z * 3 + c];
+                        tj[c] = L.tc[e.w * 3 + c];
+                    }
+                    PairFwd f;
+                    pair_forward(Ri, ti, Rj, tj, f);
+                    float F[9];
+                    fundamental_from_E(f.E, cam, F);
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) L.F[s * 9 + c] = F[c];
+                }
+            }
+            __syncthreads();
+            // ---- P2: per-match Sampson residual + dL/dF, a wave per item; the 12 sums stay in this workgroup's LDS
+            ++epoch;
+            u64 *xs = xbase + (size_t)(epoch & 1) * P.xchg_stride;
+            for (int r = 0; r * PD_GGS_WAVES < n_slots; ++r) {
+                const int s = wave + PD_GGS_WAVES * r;
+                const int4 e = L.itab[s];
+                if (e.y > 0) {
+                    float Fm[9];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) Fm[c] = L.F[s * 9 + c];
+                    v2f acc2[PD_ITEM_VALS];
+#pragma unroll
+                    for (int c = 0; c < PD_ITEM_VALS; ++c) acc2[c] = (v2f){0.0f, 0.0f};
+                    const int npairs = (e.y + 127) >> 7;
+                    if (resident) {
+                        PD_P2_STEPS(mres);
+                    } else {
+                        float4 mb[8];
+                        const float4 *pts = D.pts + e.x;
+                        const int last = e.y - 1;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int m = lane + 64 * q;
+                            mb[q] = pts[m < e.y ? m : last];
+                        }
+                        PD_P2_STEPS(mb);
+                    }
+                    float acc[PD_ITEM_VALS];
+#pragma unroll
+                    for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = acc2[c].x + acc2[c].y;
+                    int slot;
+                    const float tot = wave_reduce12_transpose(acc, lane, slot);
+                    if (lane < 16 && slot < PD_ITEM_VALS) L.item[s * PD_ITEM_VALS + slot] = tot;
+                }
+            }
+            __syncthreads();
+            // ---- P3a: backward of this workgroup's pairs (thread per local item), rows 2s (side 0), 2s + 1 (side 1)
+            if (tid < n_slots && L.itab[tid].y > 0) {
+                const int4 e = L.itab[tid];
+                const int pi = e.z, pj = e.w;
+                const int4 mp = make_int4(0, 0, 1, (2 * tid) | ((2 * tid + 1) << 16));
+                float G[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) G[c] = L.item[tid * PD_ITEM_VALS + c];
+#include "pd_ggs_pairbwd.inc"
+            }
+            __syncthreads();
+            // ---- hop 1: publish the (pair, side) rows; thread (row = tid / 16, component = tid % 16), 32 rows per pass
+            for (int r0 = 0; r0 < 2 * n_slots; r0 += PD_GGS_THREADS / 16) {
+                const int row = r0 + (tid >> 4);
+                if (row < 2 * n_slots && L.itab[row >> 1].y > 0) {
+                    u64 *g = xs + (size_t)grow[row] * PD_XCHG_LINE + (tid & 15);
+                    __hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(own_rows[row * 16 + (tid & 15)]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // this workgroup's loss totals {sum s valid, n valid, sum min(s, max)} -> its totals line
+            if (wave == PD_GGS_WAVES - 1) {
+                float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+                for (int s = lane; s < n_slots; s += 64) {
+                    if (L.itab[s].y > 0) {
+                        t0 += L.item[s * PD_ITEM_VALS + 9];
+                        t1 += L.item[s * PD_ITEM_VALS + 10];
+                        t2 += L.item[s * PD_ITEM_VALS + 11];
+                    }
+                }
+                t0 = wave_allsum(t0);
+                t1 = wave_allsum(t1);
+                t2 = wave_allsum(t2);
+                if (lane < 4) {
+                    const float v = lane == 0 ? t0 : (lane == 1 ? t1 : (lane == 2 ? t2 : 0.0f));
+                    __hip_atomic_store(xs + (size_t)(n_inc + wg) * PD_XCHG_LINE + lane, ((u64)epoch << 32) | (u64)__float_as_uint(v),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // ---- P3b: the owner of frame n sums that frame's rows in row order and publishes the frame line
+            bool ok = true;
+            for (int n = wg; n < N; n += k) {
+                const int lo = L.incoff[n], cn = L.incoff[n + 1] - lo;   // <= 63 rows
+                ok = ggs2_gather<1>(xs + (size_t)lo * PD_XCHG_LINE, tid, cn * 8, 8, epoch, frame_rows, 16, P.err_flag) && ok;
+                __syncthreads();
+                if (tid < 16) {
+                    float a = 0.0f;
+                    for (int e2 = 0; e2 < cn; ++e2) a += frame_rows[e2 * 16 + tid];
+                    __hip_atomic_store(xs + (size_t)(n_inc + k + n) * PD_XCHG_LINE + tid, ((u64)epoch << 32) | (u64)__float_as_uint(a),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+            }
+            // ---- hop 2: everybody gathers the N frame lines and the k totals lines
+            ok = ggs2_gather<2>(xs + (size_t)(n_inc + k) * PD_XCHG_LINE, tid, N * 8, 8, epoch, L.psum, 16, P.err_flag) && ok;
+            ok = ggs2_gather<1>(xs + (size_t)n_inc * PD_XCHG_LINE, tid, k * 2, 2, epoch, tot_rows, 4, P.err_flag) && ok;
+            if (!ok) {
+                atomicOr(P.err_flag, 1u);
+                L.ctl[1] = 1.0f;
+            }
+            __syncthreads();
+            if (L.ctl[1] != 0.0f) return;
+            // per-frame gradients back through tc = D T and Rc[a][b] = D[a] R[b][a]; totals in workgroup order
+            for (int q = tid; q < N * 16; q += PD_GGS_THREADS) {
+                const int n = q >> 4, c = q & 15;
+                const float v = L.psum[n * 16 + c];
+                if (c < 9) {
+                    const int aa = c / 3, bb = c % 3;
+                    L.gR[n * 9 + bb * 3 + aa] = (aa < 2 ? -v : v);
+                } else if (c < 12) {
+                    L.gT[n * 3 + (c - 9)] = (c - 9 < 2 ? -v : v);
+                } else {
+                    L.gA[n * 4 + (c - 12)] = v;
+                }
+            }
+            if (wave == PD_GGS_WAVES - 1) {
+                float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+                for (int w0 = 0; w0 < k; w0 += 64) {      // fixed order: 64 workgroups at a time, tree inside
+                    const int w = w0 + lane;
+                    t0 += wave_allsum(w < k ? tot_rows[w * 4 + 0] : 0.0f);
+                    t1 += wave_allsum(w < k ? tot_rows[w * 4 + 1] : 0.0f);
+                    t2 += wave_allsum(w < k ? tot_rows[w * 4 + 2] : 0.0f);
+                }
+                if (lane == 0) {
+                    L.cam[6] = t0;
+                    L.cam[7] = t1;
+                    L.ctl[2] = t2;
+                }
+            }
+            __syncthreads();
+#include "pd_ggs_p4.inc"
+            __syncthreads();
+            if (L.ctl[0] != 0.0f) break;
+        }
+        if (wave == 0 && lane == 0 && wg == 0 && P.stats) {
+            float *so = P.stats + ((size_t)b * P.n_stages + st) * 4;
+            so[0] = last_print;
+            so[1] = (float)stepped;
+            so[2] = last_cnt;
+            so[3] = last_loss;
+        }
+        if (P.eval_only) break;
     }
     if (own && wg == 0 && !P.eval_only) {
 #pragma unroll
@@ -988,6 +1066,23 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
             ptab[p] = make_int4(pair_ij[p].x | (pair_ij[p].y << 8), pair_item_off[p], pair_item_off[p + 1] - pair_item_off[p],
                                 pos0[p] | (pos1[p] << 16));
     }
+    // the same positions among ALL incidences (two-hop kernel: one exchange line per (pair, side), grouped by frame)
+    std::vector<int2> gpos(n_pairs);
+    std::vector<int> ginc_off(N + 1, 0);
+    int single_item_pairs = 1;
+    {
+        int q = 0;
+        for (int n = 0; n < N; ++n) {
+            ginc_off[n] = q;
+            for (int p = 0; p < n_pairs; ++p) {
+                if (pair_ij[p].x == n) gpos[p].x = q++;
+                if (pair_ij[p].y == n) gpos[p].y = q++;
+            }
+        }
+        ginc_off[N] = q;
+        for (int p = 0; p < n_pairs; ++p)
+            if (pair_item_off[p + 1] - pair_item_off[p] != 1) single_item_pairs = 0;
+    }
 
     // one blob: pts | pair_ij | pair_item_off | items | ptab | pchunk_off   (aligned pieces)
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -997,7 +1092,9 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     const size_t o_itm = al(o_pio + sizeof(int) * pair_item_off.size());
     const size_t o_ptb = al(o_itm + sizeof(int4) * items.size());
     const size_t o_pco = al(o_ptb + sizeof(int4) * ptab.size());
-    const size_t total = al(o_pco + sizeof(int) * pchunk_off.size());
+    const size_t o_gps = al(o_pco + sizeof(int) * pchunk_off.size());
+    const size_t o_gio = al(o_gps + sizeof(int2) * gpos.size());
+    const size_t total = al(o_gio + sizeof(int) * ginc_off.size());
     std::vector<char> host(total, 0);
     memcpy(host.data() + o_pts, pts.data(), sizeof(float4) * pts.size());
     memcpy(host.data() + o_pij, pair_ij.data(), sizeof(int2) * pair_ij.size());
@@ -1005,6 +1102,8 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     memcpy(host.data() + o_itm, items.data(), sizeof(int4) * items.size());
     memcpy(host.data() + o_ptb, ptab.data(), sizeof(int4) * ptab.size());
     memcpy(host.data() + o_pco, pchunk_off.data(), sizeof(int) * pchunk_off.size());
+    memcpy(host.data() + o_gps, gpos.data(), sizeof(int2) * gpos.size());
+    memcpy(host.data() + o_gio, ginc_off.data(), sizeof(int) * ginc_off.size());
     PdSeqHost &h = eng->seqs[seq];
     PD_HIP_CHECK(hipMalloc(&h.blob, total));
     PD_HIP_CHECK(hipMemcpy(h.blob, host.data(), total, hipMemcpyHostToDevice));
@@ -1016,6 +1115,9 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     h.desc.ptab = (const int4 *)(base + o_ptb);
     h.desc.pchunk_off = (const int *)(base + o_pco);
     h.desc.n_pchunks = n_pchunks;
+    h.desc.gpos = (const int2 *)(base + o_gps);
+    h.desc.ginc_off = (const int *)(base + o_gio);
+    h.desc.single_item_pairs = single_item_pairs;
     h.desc.M = (int)M;
     h.desc.n_pairs = n_pairs;
     h.desc.n_items = n_items;
@@ -1036,6 +1138,7 @@ __global__ void pd_ggs_zero_kernel(unsigned long long *p, size_t n) {
 
 int pd_ggs_init() {
     PD_HIP_CHECK(hipFuncSetAttribute((const void *)pd_ggs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PD_HIP_CHECK(hipFuncSetAttribute((const void *)pd_ggs2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return PD_OK;
 }
 
@@ -1107,7 +1210,17 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
         const size_t n_zero = 2 * eng->xchg_granules * B;
         hipLaunchKernelGGL(pd_ggs_zero_kernel, dim3(256), dim3(256), 0, s, eng->d_xchg, n_zero);
     }
-    hipLaunchKernelGGL(pd_ggs_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots);
+    // many frames (several chunks of pairs): distribute the backward over the workgroups (two small exchanges per
+    // iteration) instead of replicating it -- needs one work item per pair and room for its exchange lines
+    bool two_hop = k > 1 && !(cfg->reserved & PD_GGS_CFG_FORCE_ONE_HOP) && 2 * n_slots <= 512 && k <= 256;
+    for (int b = 0; b < B && two_hop; ++b) {
+        const PdSeqDesc &d = eng->seqs[b].desc;
+        two_hop = d.n_pchunks > 1 && d.single_item_pairs && (size_t)(2 * d.n_pairs + k + N) * PD_XCHG_LINE <= eng->xchg_granules;
+    }
+    if (two_hop)
+        hipLaunchKernelGGL(pd_ggs2_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots);
+    else
+        hipLaunchKernelGGL(pd_ggs_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }

@@ -43,6 +43,9 @@ struct PdSeqDesc {
                                //   results (side 0 -> frame i, side 1 -> frame j) among its chunk's frame-sorted incidences
     const int *pchunk_off;     // [n_pchunks][n_frames + 1] per chunk of PD_GGS_THREADS pairs: CSR of the chunk's incidences by frame
     int n_pchunks;             // (ptab positions are chunk-local)
+    const int2 *gpos;          // [n_pairs] rows of the pair's (side 0, side 1) results among ALL incidences, frame-sorted
+    const int *ginc_off;       // [n_frames + 1] CSR of those rows by frame (two-hop kernel for many frames)
+    int single_item_pairs;     // 1: every pair is one work item (<= PD_ITEM_MAX_MATCHES matches)
     int M, n_pairs, n_items, n_frames;
     float sc, cx, cy;          // min(h, w) / 2, w / 2, h / 2 (opencv_from_cameras_projection)
     int pad;

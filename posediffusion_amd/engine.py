@@ -15,7 +15,7 @@ import torch
 from . import _lib
 
 GGS_DEFAULTS = dict(alpha=1e-4, learning_rate=1e-2, iter_num=100, sampson_max=10.0, min_matches=10,
-                    momentum=0.9, wgs_per_seq=0)   # cfgs/default.yaml:6-13 (+ SGD momentum of :89)
+                    momentum=0.9, wgs_per_seq=0, reserved=0)   # cfgs/default.yaml:6-13 (+ SGD momentum of :89; engine knobs)
 
 _TABLES = ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
            "posterior_mean_coef2", "posterior_log_variance_clipped")
@@ -28,7 +28,7 @@ def make_ggs_cfg(cfg: Optional[Dict] = None, **over) -> _lib.pd_ggs_cfg:
             if k in d:
                 d[k] = v
     return _lib.pd_ggs_cfg(float(d["alpha"]), float(d["learning_rate"]), int(d["iter_num"]), float(d["sampson_max"]),
-                           int(d["min_matches"]), float(d["momentum"]), int(d["wgs_per_seq"]), 0)
+                           int(d["min_matches"]), float(d["momentum"]), int(d["wgs_per_seq"]), int(d.get("reserved", 0)))
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
