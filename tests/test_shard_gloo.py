@@ -73,6 +73,7 @@ def test_two_rank_sharding_matches_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert full.shape == (total, 4, 9)
-    # same arithmetic per sequence on every rank; only BLAS threading may differ between processes
-    assert torch.allclose(full, ref, rtol=1e-5, atol=1e-6), "sharded result differs from the single-process result"
+    # same arithmetic per sequence on every rank; only BLAS threading may differ between processes (this test is about
+    # the partition / gather order, so the tolerance is generous; a wrong order is off by O(1))
+    assert torch.allclose(full, ref, rtol=1e-4, atol=1e-5), "sharded result differs from the single-process result"
     assert tmax == 2.0
