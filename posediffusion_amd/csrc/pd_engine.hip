@@ -69,6 +69,7 @@ extern "C" void pd_engine_destroy(pd_engine *eng) {
     (void)hipSetDevice(eng->device);
     (void)hipDeviceSynchronize();
     for (auto &g : eng->graphs) (void)hipGraphExecDestroy(g.second);
+    if (eng->last_use) (void)hipEventDestroy(eng->last_use);
     for (auto &s : eng->seqs) pd_ggs_free_seq(s);
     pd_denoiser_destroy(eng);
     void *ptrs[] = {eng->d_seqs, eng->d_xchg, eng->d_err, eng->d_z, eng->d_noise, eng->d_process, eng->d_mean, eng->d_stats};
@@ -353,6 +354,10 @@ extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *nois
             eng->graphs.push_back({key, exec});
         }
         PD_HIP_CHECK(hipGraphLaunch(exec, s));
+        if (has_ggs) {   // (eager launches mark their use themselves; a replay does not pass through pd_ggs_launch)
+            int rc = pd_mark_use(eng, s);
+            if (rc) return rc;
+        }
     }
     if (phase == PD_PHASE_UNGUIDED) return PD_OK;   // results are copied out by the guided phase
     PD_HIP_CHECK(hipMemcpyAsync(pose_out, eng->d_process + (size_t)T * bn9, sizeof(float) * bn9, hipMemcpyDeviceToDevice, s));

@@ -966,7 +966,18 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
 void pd_ggs_free_seq(PdSeqHost &h) {
     if (h.blob) (void)hipFree(h.blob);
     h.blob = nullptr;
+    h.blob_bytes = 0;
     memset(&h.desc, 0, sizeof(h.desc));
+}
+
+// remember the point on `s` after which this engine's match tables are no longer read
+int pd_mark_use(pd_engine *eng, hipStream_t s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return PD_OK;   // inside a graph capture: pd_sample_phase marks the replay instead
+    if (!eng->last_use) PD_HIP_CHECK(hipEventCreateWithFlags(&eng->last_use, hipEventDisableTiming));
+    PD_HIP_CHECK(hipEventRecord(eng->last_use, s));
+    return PD_OK;
 }
 
 static int upload_seq_table(pd_engine *eng) {
@@ -983,9 +994,13 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
         return PD_ERR_INVALID_ARG;
     }
     PD_HIP_CHECK(hipSetDevice(eng->device));
-    PD_HIP_CHECK(hipDeviceSynchronize());   // nothing in flight may still read the old tables
-    pd_ggs_free_seq(eng->seqs[seq]);
-    if (M == 0) return upload_seq_table(eng);
+    // nothing of THIS engine in flight may still read the old tables; other engines (other batches of a pipeline) keep
+    // running: no device-wide synchronisation here, and the blob is re-used when the new tables fit
+    if (eng->last_use) PD_HIP_CHECK(hipEventSynchronize(eng->last_use));
+    if (M == 0) {
+        pd_ggs_free_seq(eng->seqs[seq]);
+        return upload_seq_table(eng);
+    }
     if (!kp1 || !kp2 || !i12 || M < 0 || n_frames <= 0 || n_frames > PD_MAX_FRAMES || n_frames > eng->max_N ||
         height <= 0 || width <= 0) {
         pd_set_error("pd_ggs_set_matches: invalid arguments (M=%lld n_frames=%d h=%d w=%d; n_frames <= %d)",
@@ -1105,7 +1120,12 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     memcpy(host.data() + o_gps, gpos.data(), sizeof(int2) * gpos.size());
     memcpy(host.data() + o_gio, ginc_off.data(), sizeof(int) * ginc_off.size());
     PdSeqHost &h = eng->seqs[seq];
-    PD_HIP_CHECK(hipMalloc(&h.blob, total));
+    if (h.blob_bytes < total) {
+        pd_ggs_free_seq(h);
+        PD_HIP_CHECK(hipMalloc(&h.blob, total));
+        h.blob_bytes = total;
+    }
+    memset(&h.desc, 0, sizeof(h.desc));
     PD_HIP_CHECK(hipMemcpy(h.blob, host.data(), total, hipMemcpyHostToDevice));
     char *base = (char *)h.blob;
     h.desc.pts = (const float4 *)(base + o_pts);
@@ -1222,5 +1242,5 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     else
         hipLaunchKernelGGL(pd_ggs_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots);
     PD_HIP_CHECK(hipGetLastError());
-    return PD_OK;
+    return pd_mark_use(eng, s);
 }

@@ -78,6 +78,7 @@ struct PdGgsParams {
 
 struct PdSeqHost {
     void *blob = nullptr;      // one hipMalloc holding every array of the PdSeqDesc
+    size_t blob_bytes = 0;     // its capacity (re-used by later uploads that fit)
     PdSeqDesc desc{};
     int n_local_max_k1 = 0;
 };
@@ -112,6 +113,8 @@ struct pd_engine {
     };
     std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
     hipStream_t own_stream = nullptr;
+    // recorded after every enqueue that reads the match tables: pd_ggs_set_matches waits for THIS engine's work only
+    hipEvent_t last_use = nullptr;
 };
 
 // pd_denoiser.hip
@@ -132,3 +135,4 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
                   const pd_ggs_cfg *cfg, int eval_only, float *stats, float *trace, int trace_iters,
                   float *loss_out, float *grad_out, hipStream_t s);
 void pd_ggs_free_seq(PdSeqHost &h);
+int pd_mark_use(pd_engine *eng, hipStream_t s);

@@ -587,3 +587,47 @@ def test_xcd_denoiser_guided_end_to_end_vs_reference_fixture(engine, golden):
     assert rel_err(process[20], ref[20]) < 1e-4
     # the whole guided trajectory stays as close to the per-launch engine path as that path is to the reference
     assert rel_err(process[-1].cpu(), base[-1]) <= max(2.0 * rel_err(base[-1], ref[-1]), 1e-4)
+
+
+def test_pipeline_with_fresh_matches_per_batch(seeded_diffuser):
+    """Streaming use: every submission uploads its own matches into its context first.  pd_ggs_set_matches waits
+    for that engine's own work only (no device-wide synchronisation) and re-uses the slot's device blob; results are
+    those of the same batch run alone."""
+    from posediffusion_amd.engine import PoseEngine
+    from posediffusion_amd.host import denoiser_state, draw_noise
+    from posediffusion_amd.pipeline import SamplingPipeline
+    dev = torch.device(DEV)
+    diff = seeded_diffuser.to(dev)
+    B, N, D, n_sub = 2, 9, 3, 7
+    tables = {k: v for k, v in diff.named_buffers(recurse=False)}
+    engs = [PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=B, max_N=N) for _ in range(D)]
+    cfg = make_ggs_cfg(synth.GGS_CFG, iter_num=15, min_matches=0, wgs_per_seq=5)
+    subs = []
+    for i in range(n_sub):
+        z = synth.make_z(B, N, seed=700 + i).to(dev)
+        noise = torch.stack([draw_noise((N, 9), 100, dev, 4, True, generator=torch.Generator(device=dev).manual_seed(90 + 10 * i + b))
+                             for b in range(B)], dim=1)
+        mds = []
+        for b in range(B):
+            enc = synth.make_cameras(N, seed=100 + 10 * i + b)
+            mds.append(synth.make_matches(enc, 224, 224, per_pair=100 + 17 * ((i + b) % 3), seed=100 + 10 * i + b))
+        subs.append((z, noise, mds))
+    refs = []
+    for z, noise, mds in subs:                      # each batch alone on engine 0
+        for b, md in enumerate(mds):
+            engs[0].set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+        refs.append(engs[0].sample(z, noise, 4, cfg, use_graph=True)[0].clone())
+        torch.cuda.synchronize()
+    pipe = SamplingPipeline(engs, 3, dev, unguided_streams=0)
+    pend = []
+    for z, noise, mds in subs:
+        j = pipe.next_context()
+        for b, md in enumerate(mds):
+            engs[j].set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+        pend.append(pipe.submit(z, noise, 4, cfg, use_graph=True))
+    pipe.synchronize()
+    pipe.check_async()
+    for p, ref in zip(pend, refs):
+        assert torch.equal(p.wait()[0], ref)
+    for e in engs:
+        e.close()
