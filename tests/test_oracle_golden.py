@@ -164,3 +164,58 @@ def test_oracle_against_live_reference(seeded_diffuser):
     with contextlib.redirect_stdout(io.StringIO()):
         xr = ref.geometry_guided_sampling(x0.clone(), 1, md, cfg)
     assert rel_err(O.geometry_guided_sampling(x0.clone(), 1, md, cfg), xr) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------- third-party helpers
+# pytorch3d is neither under /root/reference nor installed, so its five helpers are restated in the oracle (parity
+# against pytorch3d's source is unpinned).  These checks pin the restatements against INDEPENDENT
+# definitions: scipy's rotation class, the cross product, and the documented PyTorch3D NDC projection convention.
+def test_quaternion_to_matrix_against_scipy():
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(0)
+    q = rng.normal(size=(64, 4)) * rng.uniform(0.2, 5.0, size=(64, 1))            # real-first, NOT normalised
+    ours = O.quaternion_to_matrix(torch.from_numpy(q)).numpy()
+    ref = Rotation.from_quat(q[:, [1, 2, 3, 0]]).as_matrix()                       # scipy: scalar-last, normalises
+    assert np.abs(ours - ref).max() < 1e-12
+    assert np.abs(ours @ ours.transpose(0, 2, 1) - np.eye(3)).max() < 1e-12      # the 2/|q|^2 scaling keeps R orthonormal
+
+
+def test_hat_is_the_cross_product_matrix():
+    rng = np.random.default_rng(1)
+    v, w = rng.normal(size=(32, 3)), rng.normal(size=(32, 3))
+    hv = O.hat(torch.from_numpy(v)).numpy()
+    assert np.abs(np.einsum("bij,bj->bi", hv, w) - np.cross(v, w)).max() < 1e-14
+
+
+def test_opencv_conversion_reproduces_the_ndc_projection():
+    """PyTorch3D convention (documented): X_cam = X_world R + T (row vectors), x_ndc = f X/Z, +x left / +y up, so
+    pixel u = W/2 - x_ndc s, v = H/2 - y_ndc s with s = min(H, W)/2.  The restated opencv_from_cameras_projection
+    must give the same pixels through K (R_cv X + t_cv)."""
+    rng = np.random.default_rng(2)
+    n, H, W = 16, 224, 336
+    q = rng.normal(size=(n, 4))
+    R = O.quaternion_to_matrix(torch.from_numpy(q))
+    T = torch.from_numpy(rng.normal(size=(n, 3)) * 0.3 + np.array([0.0, 0.0, 6.0]))
+    f = torch.from_numpy(rng.uniform(1.0, 4.0, size=(n, 2)))
+    X = torch.from_numpy(rng.normal(size=(n, 50, 3)))
+    Xc = X @ R + T[:, None, :]
+    s = min(H, W) / 2.0
+    u = W / 2.0 - f[:, None, 0] * Xc[..., 0] / Xc[..., 2] * s
+    v = H / 2.0 - f[:, None, 1] * Xc[..., 1] / Xc[..., 2] * s
+    Rcv, tcv, K = O.opencv_from_cameras_projection(R, T, f, H, W)
+    P = (K[:, None] @ ((Rcv[:, None] @ X[..., None]) + tcv[:, None, :, None]))[..., 0]
+    assert (P[..., 2] > 0).all()
+    assert torch.abs(P[..., 0] / P[..., 2] - u).max() < 1e-9 and torch.abs(P[..., 1] / P[..., 2] - v).max() < 1e-9
+
+
+def test_harmonic_embedding_layout():
+    """HarmonicEmbedding(n_harmonic_functions=10, append_input=True): [sin(x f) | cos(x f) | x], f = 2^k, dim-major."""
+    x = torch.tensor([[0.3, -1.7, 2.0]], dtype=torch.float64)
+    e = O.harmonic_embedding(x, 10)
+    assert e.shape == (1, 3 * 10 * 2 + 3)
+    fr = 2.0 ** np.arange(10)
+    arg = (x.numpy()[0][:, None] * fr[None, :]).reshape(-1)
+    assert np.abs(e[0, :30].numpy() - np.sin(arg)).max() < 1e-12
+    # 0.7.x computes cos as sin(. + pi/2) with pi/2 held in float32 (4.4e-8 off): the restatement keeps that
+    assert np.abs(e[0, 30:60].numpy() - np.cos(arg)).max() < 1e-7
+    assert torch.equal(e[0, 60:], x[0])
