@@ -116,9 +116,9 @@ extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_en
         const size_t bn9 = (size_t)max_B * max_N * 9;
         // all-pairs upper bound on work items for the exchange buffer: N*(N-1) ordered pairs, 1 item each,
         // plus slack for pairs split into several items
-        // one 128-byte line (16 granules) per item; the two-hop kernel lays out (pair, side) lines + one line per
-        // workgroup + one per frame in the same buffer: < N^2 + 256 + 64 lines
-        eng->xchg_granules = (size_t)(max_N * max_N + 512) * 16;
+        // one 128-byte line (16 granules) per item; the two-hop kernel lays out (pair, side) lines (both orders of every
+        // pair: < 2 N^2) + one line per workgroup + one per frame in the same buffer
+        eng->xchg_granules = (size_t)(2 * max_N * max_N + 512) * 16;
 #define PD_ALLOC(ptr, bytes)                                             \
     if (hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) {             \
         pd_set_error("pd_engine_create: hipMalloc of %zu B failed", (size_t)(bytes)); \

@@ -1188,14 +1188,36 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     int k = cfg->wgs_per_seq > 0 ? cfg->wgs_per_seq : (max_items + PD_GGS_WAVES - 1) / PD_GGS_WAVES;
     k = std::max(1, std::min(k, device_cus / B));
     if ((size_t)max_items * PD_XCHG_LINE > eng->xchg_granules) k = 1;
+    // many frames (several chunks of pairs): the two-hop kernel distributes the backward over the workgroups instead of
+    // replicating it -- needs one work item per pair and room for its exchange lines; it keeps only a workgroup's own
+    // item sums in LDS, so it also covers item counts whose full table would not fit
+    bool two_hop = k > 1 && !(cfg->reserved & PD_GGS_CFG_FORCE_ONE_HOP);
+    for (int b = 0; b < B && two_hop; ++b) {
+        const PdSeqDesc &d = eng->seqs[b].desc;
+        two_hop = d.n_pchunks > 1 && d.single_item_pairs;
+    }
     int n_slots = 0;
     size_t lds = 0;
-    for (;;) {
-        const int rounds = (max_items + k * PD_GGS_WAVES - 1) / (k * PD_GGS_WAVES);
-        n_slots = rounds * PD_GGS_WAVES;
-        lds = ggs_lds_bytes(n_slots, max_items);
-        if (lds <= 160 * 1024 || k >= device_cus / B) break;
-        ++k;
+    for (int pass = 0; pass < 2; ++pass) {
+        int kk = k;
+        for (;;) {
+            const int rounds = (max_items + kk * PD_GGS_WAVES - 1) / (kk * PD_GGS_WAVES);
+            n_slots = rounds * PD_GGS_WAVES;
+            lds = ggs_lds_bytes(n_slots, two_hop ? n_slots : max_items);
+            if (lds <= 160 * 1024 || kk >= device_cus / B) break;
+            ++kk;
+        }
+        if (two_hop) {
+            bool fits = lds <= 160 * 1024 && 2 * n_slots <= 512 && kk <= 256;
+            for (int b = 0; b < B && fits; ++b)
+                fits = (size_t)(2 * eng->seqs[b].desc.n_pairs + kk + N) * PD_XCHG_LINE <= eng->xchg_granules;
+            if (!fits) {
+                two_hop = false;   // size again for the single-exchange kernel
+                continue;
+            }
+        }
+        k = kk;
+        break;
     }
     if (lds > 160 * 1024) {
         pd_set_error("pd_ggs: %d work items need %zu B of LDS per workgroup (> 160 KiB) at B=%d", max_items, lds, B);
@@ -1229,13 +1251,6 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
         // tags restart at 1 every launch: zero every polled word first (guide G16 "re-initialise every call")
         const size_t n_zero = 2 * eng->xchg_granules * B;
         hipLaunchKernelGGL(pd_ggs_zero_kernel, dim3(256), dim3(256), 0, s, eng->d_xchg, n_zero);
-    }
-    // many frames (several chunks of pairs): distribute the backward over the workgroups (two small exchanges per
-    // iteration) instead of replicating it -- needs one work item per pair and room for its exchange lines
-    bool two_hop = k > 1 && !(cfg->reserved & PD_GGS_CFG_FORCE_ONE_HOP) && 2 * n_slots <= 512 && k <= 256;
-    for (int b = 0; b < B && two_hop; ++b) {
-        const PdSeqDesc &d = eng->seqs[b].desc;
-        two_hop = d.n_pchunks > 1 && d.single_item_pairs && (size_t)(2 * d.n_pairs + k + N) * PD_XCHG_LINE <= eng->xchg_granules;
     }
     if (two_hop)
         hipLaunchKernelGGL(pd_ggs2_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots);

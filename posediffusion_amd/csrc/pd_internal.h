@@ -15,7 +15,7 @@
 #define PD_GGS_THREADS 512        // 8 waves per GGS workgroup
 #define PD_GGS_WAVES (PD_GGS_THREADS / PD_WAVE)
 #define PD_GGS_PINC_ROWS (2 * PD_GGS_THREADS)   // pair backward results in LDS: both sides of one chunk of PD_GGS_THREADS pairs
-#define PD_GGS_MAX_PCHUNKS 4                   // 64 frames -> 2016 pairs -> 4 chunks
+#define PD_GGS_MAX_PCHUNKS 8                   // 64 frames, both orders of every pair: 4032 pairs -> 8 chunks
 #define PD_GGS_MAX_STAGES 5
 #define PD_ITEM_MAX_MATCHES 512   // one work item = <= 512 matches of one frame pair (8 per lane)
 #define PD_ITEM_VALS 12           // 9 dL/dF sums + sum(s valid) + n_valid + sum(min(s, max))

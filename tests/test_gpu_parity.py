@@ -631,3 +631,56 @@ def test_pipeline_with_fresh_matches_per_batch(seeded_diffuser):
         assert torch.equal(p.wait()[0], ref)
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_ggs_random_match_structures(engine, case):
+    """Randomised match structure against the oracle's autograd: frame counts on both sides of the 32-frame / 512-pair
+    boundaries, random subsets of ordered and reversed pairs, per-pair counts from 1 to 900 (several work items per
+    pair -> the two-hop kernel must step aside), isolated frames, shuffled input; every workgroup count in play."""
+    rng = np.random.default_rng(1000 + case)
+    N = [5, 12, 33, 34, 40, 47, 50, 21][case]
+    dense = case in (2, 4, 6)
+    enc = synth.make_cameras(N, seed=300 + case)
+    full = synth.make_matches(enc, 224, 224, per_pair=4, seed=300 + case, ordered_pairs=True)
+    i12 = full["i12"]
+    pair_key = i12[:, 0] * N + i12[:, 1]
+    keys = np.unique(pair_key)
+    keep_pairs = keys if dense else keys[rng.random(len(keys)) < 0.6]
+    if case == 7:                                                 # frame 20 isolated
+        keep_pairs = keep_pairs[(keep_pairs // N != 20) & (keep_pairs % N != 20)]
+    kp1, kp2, ii = [], [], []
+    big = set(rng.choice(keep_pairs, size=min(2, len(keep_pairs)), replace=False).tolist()) if case % 2 == 1 else set()
+    for key in keep_pairs:
+        a, b2 = int(key // N), int(key % N)
+        cnt = int(rng.integers(600, 900)) if key in big else int(rng.integers(1, 12))
+        md = synth.make_matches(enc[[a, b2]], 224, 224, per_pair=cnt, seed=int(key) + 7 * case)
+        sel = md["i12"][:, 0] == 0                                # pair (0, 1) of the two-camera scene = (a, b2)
+        kp1.append(md["kp1"][sel]); kp2.append(md["kp2"][sel])
+        ii.append(np.tile(np.array([[a, b2]], dtype=np.int64), (int(sel.sum()), 1)))
+    kp1, kp2, ii = np.concatenate(kp1), np.concatenate(kp2), np.concatenate(ii)
+    perm = rng.permutation(len(kp1))
+    kp1, kp2, ii = kp1[perm], kp2[perm], ii[perm]
+    shape = (N, 3, 224, 224)
+    engine.set_matches(0, kp1, kp2, ii, shape)
+    pm = O.prepare_matches(kp1, kp2, ii, shape)
+    x0 = synth.perturb_pose(enc, seed=400 + case)
+    xo = x0.clone().requires_grad_(True)
+    v, _ = O.compute_sampson_distance(xo, pm)
+    (go,) = torch.autograd.grad(v.mean(), xo)
+    ref, _, _ = O.ggs_optimize(x0.clone(), pm, iter_num=2, min_matches=0)
+    configs = ((0, 0), (0, 1), (1, 0), (3, 0), (17, 0))
+    if case == 6:
+        # 2 450 work items: only the two-hop kernel (own items in LDS) can hold them; the single-exchange kernel says so
+        with pytest.raises(RuntimeError, match="LDS per workgroup"):
+            engine.ggs_loss_grad(x0.to(DEV), cfg=make_ggs_cfg(wgs_per_seq=0, reserved=1, min_matches=0))
+        configs = ((0, 0), (17, 0))
+    for wgs, flags in configs:
+        cfg = make_ggs_cfg(wgs_per_seq=wgs, reserved=flags, min_matches=0)
+        loss, grad = engine.ggs_loss_grad(x0.to(DEV), cfg=cfg)
+        engine.check_async()
+        assert int(loss[0, 1].item()) == len(v), (wgs, flags)
+        assert rel_err(grad, go) < 1e-4, (wgs, flags, rel_err(grad, go))
+        out, _, _ = engine.ggs_optimize(x0.to(DEV), cfg=make_ggs_cfg(iter_num=2, wgs_per_seq=wgs, reserved=flags, min_matches=0))
+        engine.check_async()
+        assert rel_err(out, ref) < 5e-5, (wgs, flags, rel_err(out, ref))
