@@ -207,6 +207,28 @@ int pd_sample_phase(pd_engine *eng, const float *z, const float *noise, int B, i
 int pd_pose_to_camera(pd_engine *eng, const float *enc, int n_cameras, float *R_out, float *T_out,
                       float *focal_out, void *stream);
 
+/* ---- evaluation metrics (stateless, all pointers DEVICE fp32) ------- */
+
+/* camera_to_rel_deg (util/metric.py:14-47): R_*[B*N,9] row-major 3x3, T_*[B*N,3] in the PyTorch3D convention
+ * (X_view = X_world R + T); for every sequence b and every pair i < j in torch.combinations order (:106-111) the angle
+ * in degrees between the ground-truth and the predicted relative rotation (so3_relative_angle, :143-151) and between the
+ * relative translation directions (:154-172; nan/inf -> 1e6).  Outputs [B * N(N-1)/2] each. */
+int pd_metrics_rel_pose_errors(const float *R_pred, const float *T_pred, const float *R_gt, const float *T_gt, int B, int N,
+                               float *rel_r_deg, float *rel_t_deg, void *stream);
+
+/* out7 = {Auc_max_threshold (calculate_auc_np, util/metric.py:50-78), Racc_5, Racc_15, Racc_30, Tacc_5, Tacc_15,
+ * Tacc_30 (test.py:113-119, percent)} over n error pairs. */
+int pd_metrics_summary(const float *rel_r_deg, const float *rel_t_deg, int n, int max_threshold, float *out7, void *stream);
+
+/* compute_ARE (util/metric.py:174-185): absolute rotation error in degrees of n rotation pairs [n,9]. */
+int pd_metrics_are(const float *R_a, const float *R_b, int n, float *err_deg, void *stream);
+
+/* pytorch3d.ops.corresponding_cameras_alignment(cameras_src, cameras_tgt, estimate_scale, mode="extrinsics", eps) as
+ * demo.py:127-129 calls it: similarity (s, R_A, T_A) that best maps the n source cameras onto the target cameras;
+ * R_out[n,9] = R_A R_src, T_out[n,3] = T_A R_src + s T_src; s_R_T_out (may be NULL) receives {s, R_A[9], T_A[3]}. */
+int pd_align_cameras(const float *R_src, const float *T_src, const float *R_tgt, const float *T_tgt, int n, int estimate_scale,
+                     float eps, float *R_out, float *T_out, float *s_R_T_out, void *stream);
+
 /* ---- measurement helpers ------------------------------------------------------------------ */
 
 /* Times `reps` launches of the dominant kernels with hipEvents on `stream` (the stream the

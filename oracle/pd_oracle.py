@@ -501,3 +501,105 @@ def sampson_loss_grad_analytic(x: np.ndarray, kp1: np.ndarray, kp2: np.ndarray, 
         grad[:, 8] = gfy / N * fl[:, 1] * fl_pass[:, 1]
     loss = tot / cnt if cnt > 0 else float("nan")
     return loss, cnt, grad, tot_clamp / len(kp1)
+
+
+# --------------------------------------------------------------------------------------
+# N3  evaluation metrics              util/metric.py, demo.py:120-133, test.py:113-121
+# --------------------------------------------------------------------------------------
+
+def world_to_view_matrix(R: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
+    """pytorch3d ``cameras.get_world_to_view_transform().get_matrix()``: 4x4, row-vector convention
+    X_view = X_world R + T  ->  [[R, 0], [T, 1]]   (restated; pytorch3d absent)."""
+    n = R.shape[0]
+    M = torch.zeros(n, 4, 4, dtype=R.dtype)
+    M[:, :3, :3] = R
+    M[:, 3, :3] = T
+    M[:, 3, 3] = 1.0
+    return M
+
+
+def _acos_linear_extrapolation(x: torch.Tensor, bound: float) -> torch.Tensor:
+    """pytorch3d.transforms.math.acos_linear_extrapolation with bounds (-bound, bound): acos inside, first-order
+    Taylor expansion of acos around the bound outside (restated from the published 0.7.x algorithm)."""
+    import math
+    out = torch.empty_like(x)
+    up, lo = x >= bound, x <= -bound
+    mid = ~up & ~lo
+    out[mid] = torch.acos(x[mid])
+    for mask, x0 in ((up, bound), (lo, -bound)):
+        out[mask] = (x[mask] - x0) * (-1.0 / math.sqrt(1.0 - x0 * x0)) + math.acos(x0)
+    return out
+
+
+def so3_relative_angle(R1: torch.Tensor, R2: torch.Tensor, cos_bound: float = 1e-4, eps: float = 1e-4) -> torch.Tensor:
+    """pytorch3d.transforms.so3_relative_angle(R1, R2, eps=1e-4) as metric.py:147 calls it: angle of R1 R2^T from
+    its trace, acos linearly extrapolated beyond |cos| > 1 - cos_bound (restated; raises like pytorch3d when the
+    trace is outside [-1 - eps, 3 + eps])."""
+    R12 = R1 @ R2.transpose(1, 2)
+    tr = R12[:, 0, 0] + R12[:, 1, 1] + R12[:, 2, 2]
+    if ((tr < -1.0 - eps) | (tr > 3.0 + eps)).any():
+        raise ValueError("A matrix has trace outside valid range [-1-eps,3+eps].")
+    return _acos_linear_extrapolation((tr - 1.0) * 0.5, 1.0 - cos_bound)
+
+
+def camera_to_rel_deg(R_pred, T_pred, R_gt, T_gt, batch_size: int):
+    """util/metric.py:14-47 on (R, T) arrays: pairwise relative poses of all i < j within each sequence, rotation angle
+    (:143-151) and translation direction angle (:154-172) between ground truth and prediction, in degrees."""
+    gt, pr = world_to_view_matrix(R_gt, T_gt), world_to_view_matrix(R_pred, T_pred)
+    n = gt.shape[0] // batch_size
+    i1_, i2_ = torch.combinations(torch.arange(n), 2, with_replacement=False).unbind(-1)               # :106-111
+    i1, i2 = [(i[None] + torch.arange(batch_size)[:, None] * n).reshape(-1) for i in (i1_, i2_)]
+
+    def inv(se3):                                                                                       # :114-140
+        Rt = se3[:, :3, :3].transpose(1, 2)
+        out = se3.clone()
+        out[:, :3, :3] = Rt
+        out[:, 3:, :3] = -se3[:, 3:, :3] @ Rt
+        return out
+
+    rel_gt, rel_pr = inv(gt[i1]) @ gt[i2], inv(pr[i1]) @ pr[i2]
+    r = so3_relative_angle(rel_gt[:, :3, :3], rel_pr[:, :3, :3]) * 180.0 / np.pi
+    t_gt, t = rel_gt[:, 3, :3], rel_pr[:, 3, :3]
+    eps = 1e-15
+    t = t / (t.norm(dim=1, keepdim=True) + eps)
+    t_gt = t_gt / (t_gt.norm(dim=1, keepdim=True) + eps)
+    loss_t = torch.clamp_min(1.0 - (t * t_gt).sum(1) ** 2, eps)
+    err_t = torch.acos(torch.sqrt(1 - loss_t))
+    err_t[torch.isnan(err_t) | torch.isinf(err_t)] = 1e6
+    return r, err_t * 180.0 / np.pi
+
+
+def calculate_auc_np(r_error: np.ndarray, t_error: np.ndarray, max_threshold: int = 30) -> float:
+    """util/metric.py:50-78."""
+    max_errors = np.max(np.concatenate((r_error[:, None], t_error[:, None]), axis=1), axis=1)
+    histogram, _ = np.histogram(max_errors, bins=np.arange(max_threshold + 1))
+    return float(np.mean(np.cumsum(histogram.astype(float) / float(len(max_errors)))))
+
+
+def compute_ARE(R1: np.ndarray, R2: np.ndarray) -> np.ndarray:
+    """util/metric.py:174-185: absolute rotation error in degrees."""
+    R_rel = np.einsum("Bij,Bjk ->Bik", R1.transpose(0, 2, 1), R2)
+    t = (np.trace(R_rel, axis1=1, axis2=2) - 1) / 2
+    return np.arccos(np.clip(t, -1, 1)) * 180 / np.pi
+
+
+def corresponding_cameras_alignment(R_src, T_src, R_tgt, T_tgt, estimate_scale: bool = True, eps: float = 1e-9):
+    """pytorch3d.ops.corresponding_cameras_alignment(mode="extrinsics") as demo.py:127-129 calls it (restated from the
+    published 0.7.x algorithm; it is the least-squares similarity of the derivation in DESIGN section 3.4):
+    R_A = V U^T from the SVD of mean_i R_src_i R_tgt_i^T; with A_i = T_src_i R_src_i^T and B_i = T_tgt_i R_src_i^T,
+    s = <Ac, Bc> / <Ac, Ac>, T_A = mean B - s mean A;  aligned R_i = R_A R_src_i, T_i = T_A R_src_i + s T_src_i."""
+    RRcov = (R_src @ R_tgt.transpose(1, 2)).mean(0)
+    U, _, Vh = torch.linalg.svd(RRcov)
+    RA = Vh.transpose(0, 1) @ U.transpose(0, 1)
+    A = (R_src @ T_src[:, :, None])[:, :, 0]
+    B = (R_src @ T_tgt[:, :, None])[:, :, 0]
+    Amu, Bmu = A.mean(0, keepdim=True), B.mean(0, keepdim=True)
+    if estimate_scale and A.shape[0] > 1:
+        Ac, Bc = A - Amu, B - Bmu
+        s = (Ac * Bc).mean() / (Ac ** 2).mean().clamp(eps)
+    else:
+        s = torch.tensor(1.0, dtype=R_src.dtype)
+    TA = Bmu - s * Amu
+    R_al = RA[None] @ R_src
+    T_al = (TA[None].expand(R_src.shape[0], 1, 3) @ R_src)[:, 0] + T_src * s
+    return R_al, T_al, (RA, TA[0], s)

@@ -172,6 +172,44 @@ def load_reference():
     return ns
 
 
+class _MetricCameras(_PerspectiveCameras):
+    """What util/metric.py:30-31 asks of a pytorch3d camera object."""
+
+    def get_world_to_view_transform(self):
+        M = O.world_to_view_matrix(self.R, self.T)
+        return types.SimpleNamespace(get_matrix=lambda: M)
+
+
+_loaded_metric = None
+
+
+def load_reference_metric():
+    """The reference's util/metric.py executed in place (stub: pytorch3d.transforms.so3_relative_angle, restated in
+    the oracle).  -> namespace with camera_to_rel_deg, calculate_auc_np, compute_ARE and a Cameras class for it."""
+    global _loaded_metric
+    if _loaded_metric is not None:
+        return _loaded_metric
+    if not available():
+        raise RuntimeError(f"reference not found under {REF_ROOT}")
+    names = ("pytorch3d", "pytorch3d.transforms")
+    saved = {k: sys.modules.get(k) for k in names}
+    _mod("pytorch3d")
+    _mod("pytorch3d.transforms", so3_relative_angle=lambda R1, R2, eps=1e-4, **kw: O.so3_relative_angle(R1, R2, eps=eps))
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_metric", os.path.join(REF_PKG, "util", "metric.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    _loaded_metric = types.SimpleNamespace(camera_to_rel_deg=m.camera_to_rel_deg, calculate_auc_np=m.calculate_auc_np,
+                                           compute_ARE=m.compute_ARE, Cameras=_MetricCameras)
+    return _loaded_metric
+
+
 TRANSFORMER_CFG = {  # cfgs/default.yaml:27-35
     "_target_": "models.TransformerEncoderWrapper",
     "d_model": 512,

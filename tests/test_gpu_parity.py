@@ -684,3 +684,82 @@ def test_ggs_random_match_structures(engine, case):
         out, _, _ = engine.ggs_optimize(x0.to(DEV), cfg=make_ggs_cfg(iter_num=2, wgs_per_seq=wgs, reserved=flags, min_matches=0))
         engine.check_async()
         assert rel_err(out, ref) < 5e-5, (wgs, flags, rel_err(out, ref))
+
+
+# ------------------------------------------------------------------------------------------------ N3: evaluation metrics
+def _metric_module():
+    import importlib
+    import sys
+    import posediffusion_amd
+    if posediffusion_amd.DROPIN_PATH not in sys.path:
+        sys.path.insert(0, posediffusion_amd.DROPIN_PATH)
+    return importlib.import_module("util.metric")
+
+
+def test_metrics_vs_reference_fixture(golden):
+    """camera_to_rel_deg / AUC / accuracies / ARE kernels against util/metric.py executed in place (tests/golden)."""
+    M = _metric_module()
+    from posediffusion_amd.compat import PerspectiveCameras
+    g = golden["metrics"]
+    B = int(g["B"])
+    pred = PerspectiveCameras(focal_length=torch.ones(len(g["R_pred"]), 2), R=torch.from_numpy(g["R_pred"]), T=torch.from_numpy(g["T_pred"]))
+    gt = PerspectiveCameras(focal_length=torch.ones(len(g["R_gt"]), 2), R=torch.from_numpy(g["R_gt"]), T=torch.from_numpy(g["T_gt"]))
+    r, t = M.camera_to_rel_deg(pred, gt, torch.device(DEV), B)
+    # degrees from fp32 traces: acos amplifies rounding near 0 / 180 degrees (d angle = d cos / sin angle)
+    assert np.abs(r.cpu().numpy() - g["rel_r_deg"]).max() < 2e-2 and np.abs(t.cpu().numpy() - g["rel_t_deg"]).max() < 2e-2
+    big = g["rel_r_deg"] > 2.0
+    assert np.abs(r.cpu().numpy()[big] - g["rel_r_deg"][big]).max() < 2e-3
+    s = M.metrics_summary(torch.from_numpy(g["rel_r_deg"]).to(DEV), torch.from_numpy(g["rel_t_deg"]).to(DEV), 30)
+    assert abs(s["Auc_30"] - float(g["auc30"])) < 1e-6
+    assert abs(M.calculate_auc_np(g["rel_r_deg"], g["rel_t_deg"], max_threshold=30) - float(g["auc30"])) < 1e-6
+    for k in (5, 15, 30):
+        assert abs(s[f"Racc_{k}"] - np.mean(g["rel_r_deg"] < k) * 100) < 1e-4
+        assert abs(s[f"Tacc_{k}"] - np.mean(g["rel_t_deg"] < k) * 100) < 1e-4
+    are = M.compute_ARE(torch.from_numpy(g["R_pred"]).to(DEV), torch.from_numpy(g["R_gt"]).to(DEV))
+    assert np.abs(are - g["are_deg"]).max() < 2e-2
+    i1, i2 = M.batched_all_pairs(B, int(g["N"]))
+    assert len(i1) == len(g["rel_r_deg"]) and int(i1[1]) == 0 and int(i2[1]) == 2
+
+
+def test_metrics_random_shapes_vs_oracle():
+    M = _metric_module()
+    from posediffusion_amd.compat import PerspectiveCameras
+    for B, N, seed in ((1, 2, 0), (3, 5, 1), (2, 20, 2), (1, 50, 3)):
+        g = torch.Generator().manual_seed(seed)
+        Rg, Rp = O.quaternion_to_matrix(torch.randn(B * N, 4, generator=g)), O.quaternion_to_matrix(torch.randn(B * N, 4, generator=g))
+        Tg, Tp = torch.randn(B * N, 3, generator=g), torch.randn(B * N, 3, generator=g)
+        ro, to = O.camera_to_rel_deg(Rp.double(), Tp.double(), Rg.double(), Tg.double(), B)
+        one = torch.ones(B * N, 2)
+        r, t = M.camera_to_rel_deg(PerspectiveCameras(focal_length=one, R=Rp, T=Tp), PerspectiveCameras(focal_length=one, R=Rg, T=Tg),
+                                   torch.device(DEV), B)
+        assert np.abs(r.cpu().numpy() - ro.numpy()).max() < 5e-2 and np.abs(t.cpu().numpy() - to.numpy()).max() < 5e-2
+        s = M.metrics_summary(r, t, 30)
+        assert abs(s["Auc_30"] - O.calculate_auc_np(r.cpu().numpy().astype(np.float64), t.cpu().numpy().astype(np.float64))) < 1e-5
+
+
+def test_camera_alignment_vs_oracle_and_exact_recovery():
+    M = _metric_module()
+    from posediffusion_amd.compat import PerspectiveCameras
+    torch.manual_seed(5)
+    n = 20
+    R = O.quaternion_to_matrix(torch.randn(n, 4, dtype=torch.float64))
+    T = torch.randn(n, 3, dtype=torch.float64) + torch.tensor([0.0, 0.0, 6.0], dtype=torch.float64)
+    RA = O.quaternion_to_matrix(torch.randn(1, 4, dtype=torch.float64))[0]
+    TA, s = torch.randn(3, dtype=torch.float64), 0.6
+    Rt = RA.T[None] @ R
+    Tt = s * T - (TA[None, None] @ Rt)[:, 0]
+    one = torch.ones(n, 2)
+    src = PerspectiveCameras(focal_length=one, R=R.float().to(DEV), T=T.float().to(DEV))
+    # exact similarity: the aligned source cameras ARE the target cameras
+    al = M.corresponding_cameras_alignment(src, PerspectiveCameras(focal_length=one, R=Rt.float().to(DEV), T=Tt.float().to(DEV)),
+                                           estimate_scale=True, mode="extrinsics", eps=1e-9)
+    assert (al.R.cpu().double() - Rt).abs().max() < 5e-6 and (al.T.cpu().double() - Tt).abs().max() < 5e-5
+    assert float(M.compute_ARE(al.R, Rt.float().to(DEV)).mean()) < 0.06          # degrees; fp32 acos near 0
+    # noisy target: the same least-squares solution as the oracle's restatement (torch SVD)
+    Rn = O.quaternion_to_matrix(torch.randn(n, 4, dtype=torch.float64) * 0.05 + torch.tensor([1.0, 0, 0, 0], dtype=torch.float64)) @ Rt
+    Tn = Tt + 0.05 * torch.randn(n, 3, dtype=torch.float64)
+    Ro, To, _ = O.corresponding_cameras_alignment(R, T, Rn, Tn)
+    al = M.corresponding_cameras_alignment(src, PerspectiveCameras(focal_length=one, R=Rn.float().to(DEV), T=Tn.float().to(DEV)))
+    assert (al.R.cpu().double() - Ro).abs().max() < 5e-6 and (al.T.cpu().double() - To).abs().max() < 5e-5
+    with pytest.raises(ValueError):
+        M.corresponding_cameras_alignment(src, src, mode="centers")

@@ -219,3 +219,28 @@ def test_harmonic_embedding_layout():
     # 0.7.x computes cos as sin(. + pi/2) with pi/2 held in float32 (4.4e-8 off): the restatement keeps that
     assert np.abs(e[0, 30:60].numpy() - np.cos(arg)).max() < 1e-7
     assert torch.equal(e[0, 60:], x[0])
+
+
+# ---------------------------------------------------------------------------------------------- N3: evaluation metrics
+def test_metrics_oracle_against_reference_fixture(golden):
+    g = golden["metrics"]
+    r, t = O.camera_to_rel_deg(torch.from_numpy(g["R_pred"]), torch.from_numpy(g["T_pred"]), torch.from_numpy(g["R_gt"]),
+                               torch.from_numpy(g["T_gt"]), int(g["B"]))
+    assert np.abs(r.numpy() - g["rel_r_deg"]).max() < 1e-5 and np.abs(t.numpy() - g["rel_t_deg"]).max() < 1e-5
+    assert abs(O.calculate_auc_np(g["rel_r_deg"], g["rel_t_deg"]) - float(g["auc30"])) < 1e-12
+    assert np.abs(O.compute_ARE(g["R_pred"], g["R_gt"]) - g["are_deg"]).max() < 1e-5
+
+
+def test_camera_alignment_recovers_a_similarity_exactly():
+    """The restated pytorch3d alignment (unpinned against pytorch3d's source) must at least undo any similarity of the
+    world: X' = s X R_A + T_A maps cameras (R, T) to (R_A^T R, s T - T_A R_A^T R)."""
+    torch.manual_seed(3)
+    n = 9
+    R = O.quaternion_to_matrix(torch.randn(n, 4, dtype=torch.float64))
+    T = torch.randn(n, 3, dtype=torch.float64)
+    RA = O.quaternion_to_matrix(torch.randn(1, 4, dtype=torch.float64))[0]
+    TA, s = torch.randn(3, dtype=torch.float64), 2.3
+    Rt = RA.T[None] @ R
+    Tt = s * T - (TA[None, None] @ Rt)[:, 0]
+    Ral, Tal, (ra, ta, ss) = O.corresponding_cameras_alignment(R, T, Rt, Tt)
+    assert (Ral - Rt).abs().max() < 1e-12 and (Tal - Tt).abs().max() < 1e-12 and abs(float(ss) - s) < 1e-12
