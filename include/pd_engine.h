@@ -229,6 +229,13 @@ int pd_metrics_are(const float *R_a, const float *R_b, int n, float *err_deg, vo
 int pd_align_cameras(const float *R_src, const float *T_src, const float *R_tgt, const float *T_tgt, int n, int estimate_scale,
                      float eps, float *R_out, float *T_out, float *s_R_T_out, void *stream);
 
+/* ---- image preprocessing (stateless) -------------------------------------- */
+
+/* One frame of load_and_preprocess_images (util/load_img_folder.py:15-48): rgb_hwc [height, width, 3] uint8 DEVICE ->
+ * out_chw [3, image_size, image_size] float32 DEVICE in [0, 1]: centre crop to min(h, w) (:68-73), bilinear resize with
+ * torch's align_corners=False rule, no antialiasing (:35-40). */
+int pd_preprocess_image(const unsigned char *rgb_hwc, int height, int width, int image_size, float *out_chw, void *stream);
+
 /* ---- measurement helpers ------------------------------------------------------------------ */
 
 /* Times `reps` launches of the dominant kernels with hipEvents on `stream` (the stream the

@@ -194,9 +194,74 @@ def make_metrics():
     print("metrics.npz", os.path.getsize(os.path.join(OUT, "metrics.npz")))
 
 
+
+def make_preprocess():
+    """tests/golden/preprocess.npz (+ tests/golden/images/*.png, a few KB): the reference's util/load_img_folder.py
+    executed in place on three small synthetic images (portrait, landscape, square; lossless PNG) at image_size 32 and
+    17; plus colmap_keypoint_to_pytorch3d of util/match_extraction.py on synthetic COLMAP-style inputs (that function is
+    plain numpy; the module's hloc / pycolmap imports are stubbed for the import only)."""
+    import importlib.util
+    import types
+    from PIL import Image
+    img_dir = os.path.join(OUT, "images")
+    os.makedirs(img_dir, exist_ok=True)
+    rng = np.random.default_rng(77)
+    for k, (h, w) in enumerate(((61, 97), (120, 80), (64, 64))):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx + yy) * 3) % 256], -1)
+        im = np.clip(base + rng.integers(-20, 21, size=(h, w, 3)), 0, 255).astype(np.uint8)
+        Image.fromarray(im, "RGB").save(os.path.join(img_dir, f"frame{k:02d}.png"))
+    spec = importlib.util.spec_from_file_location("_ref_load_img", os.path.join(RS.REF_PKG, "util", "load_img_folder.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    out = {}
+    for S in (32, 17):
+        imgs, info = m.load_and_preprocess_images(img_dir, S)
+        out[f"images_{S}"] = imgs.numpy()
+        out[f"bboxes_{S}"] = info["bboxes_xyxy"]
+        out[f"scales_{S}"] = info["resized_scales"]
+        out[f"size_{S}"] = np.array(info["size"])
+    # keypoint bookkeeping
+    saved = {k: sys.modules.get(k) for k in ("pycolmap", "hloc", "hloc.triangulation", "hloc.utils", "hloc.utils.database", "hloc.reconstruction")}
+    class _Anything:                      # whatever the module body asks of the absent packages at import time
+        def __getattr__(self, n):
+            return _Anything()
+
+        def __call__(self, *a, **k):
+            return _Anything()
+
+    anyattr = type("Any", (types.ModuleType,), {"__getattr__": lambda self, n: _Anything()})
+    for k in saved:
+        sys.modules[k] = anyattr(k)
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_match", os.path.join(RS.REF_PKG, "util", "match_extraction.py"))
+        mm = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mm)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    keypoints = {i + 1: rng.uniform(0, 60, size=(12, 2)) for i in range(3)}
+    matches = {(1, 2): rng.integers(0, 12, size=(7, 2)), (1, 3): None, (2, 3): rng.integers(0, 12, size=(4, 2))}
+    info = {"bboxes_xyxy": out["bboxes_32"], "resized_scales": out["scales_32"]}
+    kp1, kp2, i12 = mm.colmap_keypoint_to_pytorch3d({k: v.copy() if v is not None else None for k, v in matches.items()},
+                                                    {k: v.copy() for k, v in keypoints.items()}, info)
+    for i in range(3):
+        out[f"colmap_kp_{i + 1}"] = keypoints[i + 1]
+    out["colmap_m_12"], out["colmap_m_23"] = matches[(1, 2)], matches[(2, 3)]
+    out["kp1"], out["kp2"], out["i12"] = kp1, kp2, i12
+    np.savez(os.path.join(OUT, "preprocess.npz"), **out)
+    print("preprocess.npz", os.path.getsize(os.path.join(OUT, "preprocess.npz")))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         make_metrics()          # only the N3 fixture (the others stay byte-identical)
+    elif len(sys.argv) > 1 and sys.argv[1] == "preprocess":
+        make_preprocess()       # only the N4 fixture
     else:
         main()
         make_metrics()
+        make_preprocess()

@@ -63,6 +63,7 @@ SIGNATURES = {
     "pd_metrics_rel_pose_errors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "pd_metrics_summary": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pd_metrics_are": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "pd_preprocess_image": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pd_align_cameras": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
     "pd_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp, _i, _vp]),
     "pd_sample_phase": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _i, _vp, _vp, _vp, _i, _vp]),

@@ -1,4 +1,4 @@
-// pd_metrics.hip -- evaluation metrics of the reference on the device.
+// pd_metrics.hip -- evaluation metrics and image preprocessing (row N4) on the device.
 //
 // Replaces (paths relative to /root/reference/pose_diffusion/):
 //   util/metric.py:14-47     camera_to_rel_deg: pairwise relative poses of all i < j per sequence, rotation angle and
@@ -265,6 +265,41 @@ extern "C" int pd_align_cameras(const float *R_src, const float *T_src, const fl
     }
     hipLaunchKernelGGL(pd_align_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, R_src, T_src, R_tgt, T_tgt, n, estimate_scale, eps,
                        R_out, T_out, s_R_T_out);
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}
+
+// ---- N4: image preprocessing (util/load_img_folder.py:15-48) ----------------------------------------
+// One frame: uint8 RGB HWC -> float32 CHW in [0, 1], centre-cropped to a square (:68-73) and resized to
+// image_size x image_size with torch's bilinear rule for align_corners=False (:35-40): source index
+// (dst + 0.5) * (crop / image_size) - 0.5 clamped at 0, neighbour i1 = min(i0 + 1, crop - 1), no antialiasing.
+__global__ void pd_preprocess_image_kernel(const unsigned char *__restrict__ rgb, int H, int W, int S, float *__restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * S) return;
+    const int oy = idx / S, ox = idx - oy * S;
+    const int crop = H < W ? H : W, top = (H - crop) / 2, left = (W - crop) / 2;
+    const float scale = (float)crop / (float)S;
+    const float sy = fmaxf(scale * ((float)oy + 0.5f) - 0.5f, 0.0f), sx = fmaxf(scale * ((float)ox + 0.5f) - 0.5f, 0.0f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < crop - 1 ? 1 : 0), x1 = x0 + (x0 < crop - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    const unsigned char *p00 = rgb + ((size_t)(top + y0) * W + left + x0) * 3, *p01 = rgb + ((size_t)(top + y0) * W + left + x1) * 3;
+    const unsigned char *p10 = rgb + ((size_t)(top + y1) * W + left + x0) * 3, *p11 = rgb + ((size_t)(top + y1) * W + left + x1) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a = (float)p00[c] / 255.0f, b = (float)p01[c] / 255.0f, d = (float)p10[c] / 255.0f, e = (float)p11[c] / 255.0f;   // :62
+        out[((size_t)c * S + oy) * S + ox] = hy * (hx * a + lx * b) + ly * (hx * d + lx * e);
+    }
+}
+
+extern "C" int pd_preprocess_image(const unsigned char *rgb_hwc, int height, int width, int image_size, float *out_chw, void *stream) {
+    if (!rgb_hwc || !out_chw || height < 2 || width < 2 || image_size < 1) {
+        pd_set_error("pd_preprocess_image: invalid arguments (h=%d w=%d size=%d)", height, width, image_size);
+        return PD_ERR_INVALID_ARG;
+    }
+    const int total = image_size * image_size;
+    hipLaunchKernelGGL(pd_preprocess_image_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, rgb_hwc, height, width,
+                       image_size, out_chw);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }

@@ -160,3 +160,24 @@ def test_product_never_touches_the_oracle():
     assert uses and all(bench.index("def cpu_baseline") < u < bench.index("def main") for u in uses), \
         "bench.py may import the oracle only inside cpu_baseline()"
     assert "oracle" in body
+
+
+def test_colmap_keypoint_bookkeeping_vs_reference_fixture(golden):
+    """dropin util/match_extraction.colmap_keypoint_to_pytorch3d against the reference's function run in place
+    (tests/golden/preprocess.npz): COLMAP keypoints -> cropped + resized frame coordinates, (kp1, kp2, i12)."""
+    import importlib
+    import sys
+    import posediffusion_amd
+    if posediffusion_amd.DROPIN_PATH not in sys.path:
+        sys.path.insert(0, posediffusion_amd.DROPIN_PATH)
+    me = importlib.import_module("util.match_extraction")
+    g = golden["preprocess"]
+    keypoints = {i + 1: g[f"colmap_kp_{i + 1}"].copy() for i in range(3)}
+    matches = {(1, 2): g["colmap_m_12"], (1, 3): None, (2, 3): g["colmap_m_23"]}
+    info = {"bboxes_xyxy": g["bboxes_32"], "resized_scales": g["scales_32"]}
+    kp1, kp2, i12 = me.colmap_keypoint_to_pytorch3d(matches, keypoints, info)
+    assert np.array_equal(i12, g["i12"]) and kp1.dtype == np.float64
+    assert np.array_equal(kp1, g["kp1"]) and np.array_equal(kp2, g["kp2"])
+    assert np.array_equal(keypoints[1], g["colmap_kp_1"])                     # the caller's dict is not modified
+    with pytest.raises(ImportError):
+        me.extract_match(image_folder_path="x")
