@@ -236,6 +236,35 @@ int pd_align_cameras(const float *R_src, const float *T_src, const float *R_tgt,
  * torch's align_corners=False rule, no antialiasing (:35-40). */
 int pd_preprocess_image(const unsigned char *rgb_hwc, int height, int width, int image_size, float *out_chw, void *stream);
 
+/* ---- image features -------------------------------------------------------- */
+
+/* MultiScaleImageFeatureExtractor (models/image_feature_extractor.py:28-87) around a DINO ViT-S/16 (:40-42, third-party
+ * facebookresearch/dino vision_transformer.py; restated).  All weight pointers DEVICE fp32 in the layouts of the DINO
+ * state_dict: patch_embed.proj.weight [384,3,16,16], cls_token [384], pos_embed [1 + pos_grid^2, 384], per block
+ * norm1/norm2 [384], attn.qkv [1152,384], attn.proj [384,384], mlp.fc1 [1536,384], mlp.fc2 [384,1536], norm [384].
+ * The engine repacks what it needs at creation; the caller's tensors are not referenced afterwards. */
+typedef struct pd_vit_layer_weights {
+    const float *norm1_w, *norm1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} pd_vit_layer_weights;
+typedef struct pd_vit_weights {
+    int32_t dim, depth, num_heads, mlp_hidden, patch_size, pos_grid, reserved0, reserved1;   /* 384, 12, 6, 1536, 16, 14 */
+    const float *patch_w, *patch_b, *cls_token, *pos_embed, *norm_w, *norm_b;
+    pd_vit_layer_weights layers[16];
+} pd_vit_weights;
+typedef struct pd_vit pd_vit;
+int pd_vit_create(const pd_vit_weights *w, pd_vit **out);
+void pd_vit_destroy(pd_vit *v);
+
+/* One scale of _compute_multiscale_features (:65-84): images [n_img,3,H,W] DEVICE fp32 in [0,1] -> ImageNet normalisation
+ * (:62-63), F.interpolate(scale_factor, bilinear, align_corners=False) (:86-87; skipped for scale_factor == 1), ViT,
+ * CLS feature after the final LayerNorm;  z_out[n_img,384] = (accumulate ? z_out : 0) + weight * feature.
+ * pos_scaled: DINO's interpolate_pos_encoding for this token grid, [1 + gh*gw, 384] DEVICE (bicubic resampling of the
+ * trained grid; the caller -- posediffusion_amd/dropin/models/image_feature_extractor.py -- computes it once per image
+ * size); may be NULL when the grid is the trained pos_grid x pos_grid.  At most 256 tokens per image (<= 240 x 240 pixels
+ * after scaling) in this version. */
+int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, int H, int W, float scale_factor, const float *pos_scaled,
+                         float weight, int accumulate, float *z_out, void *stream);
+
 /* ---- measurement helpers ------------------------------------------------------------------ */
 
 /* Times `reps` launches of the dominant kernels with hipEvents on `stream` (the stream the

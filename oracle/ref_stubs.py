@@ -210,6 +210,29 @@ def load_reference_metric():
     return _loaded_metric
 
 
+def load_reference_extractor(net: torch.nn.Module):
+    """The reference's models/image_feature_extractor.py executed in place with `torch.hub.load` answering with `net`
+    (the DINO hub code is third-party and absent) and a stub `torchvision`.  -> a reference
+    MultiScaleImageFeatureExtractor("dino_vits16") wrapped around `net`."""
+    if not available():
+        raise RuntimeError(f"reference not found under {REF_ROOT}")
+    saved_tv, saved_hub = sys.modules.get("torchvision"), torch.hub.load
+    _mod("torchvision", models=types.SimpleNamespace())
+    torch.hub.load = lambda repo, name, *a, **k: net
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_extractor", os.path.join(REF_PKG, "models", "image_feature_extractor.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        ext = m.MultiScaleImageFeatureExtractor(modelname="dino_vits16")
+    finally:
+        torch.hub.load = saved_hub
+        if saved_tv is None:
+            sys.modules.pop("torchvision", None)
+        else:
+            sys.modules["torchvision"] = saved_tv
+    return ext.eval()
+
+
 TRANSFORMER_CFG = {  # cfgs/default.yaml:27-35
     "_target_": "models.TransformerEncoderWrapper",
     "d_model": 512,

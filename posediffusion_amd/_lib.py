@@ -38,6 +38,17 @@ class pd_weights(C.Structure):
     )
 
 
+class pd_vit_layer_weights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2_w", "norm2_b",
+                                          "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class pd_vit_weights(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("dim", "depth", "num_heads", "mlp_hidden", "patch_size", "pos_grid", "reserved0", "reserved1")]
+                + [(n, C.c_void_p) for n in ("patch_w", "patch_b", "cls_token", "pos_embed", "norm_w", "norm_b")]
+                + [("layers", pd_vit_layer_weights * 16)])
+
+
 class pd_ggs_cfg(C.Structure):
     _fields_ = [("alpha", C.c_float), ("learning_rate", C.c_float), ("iter_num", C.c_int32),
                 ("sampson_max", C.c_float), ("min_matches", C.c_int32), ("momentum", C.c_float),
@@ -63,6 +74,9 @@ SIGNATURES = {
     "pd_metrics_rel_pose_errors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "pd_metrics_summary": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pd_metrics_are": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "pd_vit_create": (_i, [C.POINTER(pd_vit_weights), C.POINTER(_vp)]),
+    "pd_vit_destroy": (None, [_vp]),
+    "pd_vit_forward_scale": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _vp, C.c_float, _i, _vp, _vp]),
     "pd_preprocess_image": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pd_align_cameras": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
     "pd_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp, _i, _vp]),

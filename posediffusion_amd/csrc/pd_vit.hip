@@ -1,0 +1,539 @@
+// pd_vit.hip -- the multi-scale DINO ViT-S/16 image feature extractor.
+//
+// Replaces (paths relative to /root/reference/pose_diffusion/):
+//   models/image_feature_extractor.py:57-87   ImageNet normalisation, bilinear rescaling by every scale factor,
+//                                             backbone at every scale, average of the CLS features
+//   models/image_feature_extractor.py:40-42   the backbone: torch.hub "facebookresearch/dino:main" dino_vits16 -- third-party
+//                                             code that is NOT in the reference tree; restated from the published algorithm
+//                                             (vision_transformer.py: patch embedding conv 16x16/16, CLS token, bicubically
+//                                             resampled position grid, 12 pre-norm blocks [LayerNorm eps 1e-6, 6-head
+//                                             attention, GELU MLP 384-1536-384], final LayerNorm, CLS output)
+// Everything is fp32 on the exact-fp32 matrix instruction (the features feed the denoiser, whose parity contract is 1e-4).
+// Structure per scale, batched over all frames:  normalise+resize -> patch GEMM (im2col in the A staging, position embedding
+// and token placement in the epilogue) -> 12 x [LN+QKV GEMM, attention, proj GEMM + residual, LN+FC1 GEMM + GELU,
+// FC2 GEMM + residual (two 768-deep halves)] -> LayerNorm of the CLS rows, accumulated over the scales.
+// The GEMM is the denoiser's small-tile kernel shape (32 x 32 output tile, 4 waves split K, activation tile staged once in
+// LDS with the LayerNorm fused, weights pre-packed in MFMA fragment order) generalised to K = 384 / 768.
+#include "pd_internal.h"
+
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define VD 384          // embedding dim
+#define VH 6            // heads
+#define VDH 64          // head dim
+#define VFF 1536        // MLP hidden
+#define VP 16           // patch size
+#define VKP 768         // 3 * 16 * 16
+#define VT_MAX 256      // tokens per image this version's attention kernel holds in LDS (images up to 240 x 240)
+#define VDEPTH_MAX 16
+
+struct pd_vit {
+    int device = 0, depth = 0, grid0 = 0;       // grid0: side of the trained position grid (14)
+    float *patch_wp = nullptr, *patch_b = nullptr, *cls = nullptr, *pos = nullptr;   // pos [1 + grid0^2, 384]
+    struct Layer {
+        float *qkv_wp, *qkv_b, *proj_wp, *proj_b, *fc1_wp, *fc1_b, *fc2a_wp, *fc2b_wp, *fc2_b;
+    } L[VDEPTH_MAX];
+    float *norm_w = nullptr, *norm_b = nullptr, *zero_b = nullptr;
+    // workspaces, sized at the first forward / grown on demand
+    size_t cap_tokens = 0, cap_pixels = 0;
+    float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *hid = nullptr, *img = nullptr;
+    std::vector<void *> allocs;
+};
+
+// ---- small kernels -----------------------------------------------------------------------------------
+// W[Nout][K] (row stride ldw, column offset koff) -> fragment order for v_mfma_f32_32x32x2_f32, optional per-column scale
+__global__ void vit_repack_kernel(const float *__restrict__ W, int Nout, int K, int ldw, int koff, float *__restrict__ Wp, size_t total,
+                                  const float *__restrict__ colscale) {
+    const int KC = K / 8;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 3, l = (idx >> 2) & 63;
+        const size_t rest = idx >> 8;
+        const int kc = (int)(rest % KC), nt = (int)(rest / KC);
+        const int n = nt * 32 + (l & 31), k = kc * 8 + 4 * (l >> 5) + e;
+        float v = (n < Nout) ? W[(size_t)n * ldw + koff + k] : 0.0f;
+        if (colscale) v *= colscale[k];
+        Wp[idx] = v;
+    }
+}
+// b'[n] = b[n] + sum_k W[n][k] beta[k]
+__global__ void vit_fold_bias_kernel(const float *__restrict__ W, const float *__restrict__ beta, const float *__restrict__ b, int Nout,
+                                     int K, float *__restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Nout) return;
+    float a = 0.0f;
+    for (int k = 0; k < K; ++k) a = fmaf(W[(size_t)n * K + k], beta[k], a);
+    out[n] = b[n] + a;
+}
+
+// (image - mean) / std (image_feature_extractor.py:62-63), then F.interpolate(scale_factor, bilinear, align_corners=False)
+// (:86-87): source index (dst + 0.5) / scale_factor - 0.5 clamped at 0.  [n,3,H,W] -> [n,3,Hs,Ws]
+__global__ void vit_prep_kernel(const float *__restrict__ in, int n, int H, int W, int Hs, int Ws, float inv_sf, int identity,
+                                float *__restrict__ out) {
+    const size_t total = (size_t)n * 3 * Hs * Ws;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int ox = (int)(idx % Ws), oy = (int)((idx / Ws) % Hs), c = (int)((idx / ((size_t)Ws * Hs)) % 3);
+    const size_t im = idx / ((size_t)3 * Hs * Ws);
+    const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f), sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+    const float *src = in + (im * 3 + c) * (size_t)H * W;
+    float v;
+    if (identity) {
+        v = (src[(size_t)oy * W + ox] - mean) / sd;
+    } else {
+        const float sy = fmaxf(inv_sf * ((float)oy + 0.5f) - 0.5f, 0.0f), sx = fmaxf(inv_sf * ((float)ox + 0.5f) - 0.5f, 0.0f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+        const float a = (src[(size_t)y0 * W + x0] - mean) / sd, b = (src[(size_t)y0 * W + x1] - mean) / sd;
+        const float d = (src[(size_t)y1 * W + x0] - mean) / sd, e = (src[(size_t)y1 * W + x1] - mean) / sd;
+        v = hy * (hx * a + lx * b) + ly * (hx * d + lx * e);
+    }
+    out[idx] = v;
+}
+
+// CLS rows: x[img * T] = cls_token + pos[0]
+__global__ void vit_cls_kernel(const float *__restrict__ cls, const float *__restrict__ pos0, int n_img, int T, float *__restrict__ x) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_img * VD) return;
+    const int im = idx / VD, d = idx - im * VD;
+    x[(size_t)im * T * VD + d] = cls[d] + pos0[d];
+}
+
+// final LayerNorm (eps 1e-6) of the CLS rows; z (+)= LN(x[img * T]) * weight: one wave per image, 6 values per lane
+__global__ __launch_bounds__(64) void vit_final_kernel(const float *__restrict__ x, int T, const float *__restrict__ w, const float *__restrict__ b,
+                                                       float scale, int accumulate, float *__restrict__ z) {
+    const int im = blockIdx.x, lane = threadIdx.x;
+    const float *row = x + (size_t)im * T * VD;
+    float v[6], s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v[i] = row[lane + 64 * i];
+        s += v[i];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s * (1.0f / VD);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) q += (v[i] - mean) * (v[i] - mean);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / VD) + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int d = lane + 64 * i;
+        const float o = ((v[i] - mean) * rstd * w[d] + b[d]) * scale;
+        z[(size_t)im * VD + d] = accumulate ? z[(size_t)im * VD + d] + o : o;
+    }
+}
+
+// ---- GEMM -----------------------------------------------------------------------------------------------
+//   C[m, n] = epi( sum_k A'[m, k] W[n, k] + bias[n] ),  32 x 32 tile per workgroup, split-K over the 4 waves
+//   AMODE 0: A' = A rows (row stride lda)      1: A' = LayerNorm(A) without affine (folded into W / bias), eps 1e-6
+//   AMODE 3: A' = im2col of the prepared images: row = (image, patch), k = c * 256 + ky * 16 + kx
+//   EPI   0: + bias   2: + bias + C (residual, in place)   3: gelu(+ bias)   4: + bias + pos[1 + patch], row -> token row
+struct VitGemmArgs {
+    const float *A, *Wp, *bias, *pos, *img;
+    float *C;
+    int M, Nout, lda, T, gh, gw, Hs, Ws;
+};
+
+template <int K, int AMODE, int EPI>
+__global__ __launch_bounds__(256) void vit_gemm_kernel(VitGemmArgs g) {
+    constexpr int LDA = K + 4;
+    constexpr int KC = K / 8, CPW = KC / 4;        // 8-deep fragments, chunks per wave
+    constexpr int BATCH = CPW / 2;                 // two register batches (12 / 24 float4 each)
+    static_assert(KC % 4 == 0 && CPW % 2 == 0, "chunk batching");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int MT = (g.M + 31) / 32;
+    const int ntile = blockIdx.x / MT, mtile = blockIdx.x % MT;     // consecutive blocks share the weight tile (L2)
+    const int m0 = mtile * 32, n0 = ntile * 32;
+    const float4 *wp = (const float4 *)g.Wp + ((size_t)ntile * KC + (size_t)wave * CPW) * 64 + lane;
+    float4 w0[BATCH];
+#pragma unroll
+    for (int c = 0; c < BATCH; ++c) w0[c] = wp[(size_t)c * 64];
+    {
+        const int r = tid >> 3, sub = tid & 7;
+        const int m = m0 + r;
+        const bool live = m < g.M;
+        const int mr = live ? m : g.M - 1;
+        float *dst = As + r * LDA;
+        if constexpr (AMODE == 3) {
+            // one patch row: 3 channels x 16 lines of 16 pixels; thread `sub` takes lines sub, sub + 8 of every channel
+            const int P = g.gh * g.gw;
+            const int im = mr / P, p = mr - im * P, py = p / g.gw, px = p - py * g.gw;
+            const float keep = live ? 1.0f : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int ky = sub + 8 * hh;
+                    const float *src = g.img + (((size_t)im * 3 + c) * g.Hs + (py * VP + ky)) * g.Ws + px * VP;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 v = make_float4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);   // rows may be unaligned (Ws odd)
+                        v.x *= keep; v.y *= keep; v.z *= keep; v.w *= keep;
+                        *(float4 *)(dst + c * 256 + ky * 16 + 4 * q) = v;
+                    }
+                }
+        } else if constexpr (AMODE == 1) {
+            float4 v[K / 32];
+            const float4 *src = (const float4 *)(g.A + (size_t)mr * g.lda);
+#pragma unroll
+            for (int i = 0; i < K / 32; ++i) v[i] = src[sub + 8 * i];
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < K / 32; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            const float mean = s * (1.0f / K);
+            float q = 0.0f;
+#pragma unroll
+            for (int i = 0; i < K / 32; ++i) {
+                const float a = v[i].x - mean, b2 = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+                q += (a * a + b2 * b2) + (cc * cc + d * d);
+            }
+            q += __shfl_xor(q, 1, 64);
+            q += __shfl_xor(q, 2, 64);
+            q += __shfl_xor(q, 4, 64);
+            const float rstd = live ? 1.0f / sqrtf(q * (1.0f / K) + 1e-6f) : 0.0f;
+#pragma unroll
+            for (int i = 0; i < K / 32; ++i) {
+                float4 o;
+                o.x = (v[i].x - mean) * rstd;
+                o.y = (v[i].y - mean) * rstd;
+                o.z = (v[i].z - mean) * rstd;
+                o.w = (v[i].w - mean) * rstd;
+                *(float4 *)(dst + 4 * (sub + 8 * i)) = o;
+            }
+        } else {
+            const float4 *src = (const float4 *)(g.A + (size_t)mr * g.lda);
+            const float keep = live ? 1.0f : 0.0f;
+#pragma unroll
+            for (int i0 = 0; i0 < K / 32; i0 += 12) {
+                float4 v[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) v[i] = src[sub + 8 * (i0 + i)];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    float4 o = v[i];
+                    o.x *= keep; o.y *= keep; o.z *= keep; o.w *= keep;
+                    *(float4 *)(dst + 4 * (sub + 8 * (i0 + i))) = o;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float4 w1[BATCH];
+#pragma unroll
+    for (int c = 0; c < BATCH; ++c) w1[c] = wp[(size_t)(BATCH + c) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const float *arow = As + (lane & 31) * LDA + wave * CPW * 8 + 4 * (lane >> 5);
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const float4 wf = (c < BATCH) ? w0[c < BATCH ? c : 0] : w1[c >= BATCH ? c - BATCH : 0];
+        const float4 af = *(const float4 *)(arow + c * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, wf.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, wf.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, wf.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, wf.w, acc, 0, 0, 0);
+    }
+    __syncthreads();
+    float *red = lds;   // [4][16][64]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
+    __syncthreads();
+    const int col = n0 + (lane & 31);
+    const float bias = g.bias[col];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int reg = wave * 4 + i;
+        float v = red[(0 * 16 + reg) * 64 + lane];
+        v += red[(1 * 16 + reg) * 64 + lane];
+        v += red[(2 * 16 + reg) * 64 + lane];
+        v += red[(3 * 16 + reg) * 64 + lane];
+        v += bias;
+        const int row = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (row < g.M) {
+            if constexpr (EPI == 4) {
+                const int P = g.gh * g.gw, im = row / P, p = row - im * P;
+                g.C[((size_t)im * g.T + 1 + p) * g.Nout + col] = v + g.pos[(size_t)(1 + p) * g.Nout + col];
+            } else {
+                float *cp = g.C + (size_t)row * g.Nout + col;
+                if constexpr (EPI == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // nn.GELU(), exact form
+                if constexpr (EPI == 2) v += *cp;
+                *cp = v;
+            }
+        }
+    }
+}
+
+// LDS hand-over between the lanes of ONE wave (waves run different numbers of rows, so no workgroup barrier here)
+#define VIT_WAVE_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
+    } while (0)
+
+// ---- attention: one workgroup per (image, head); K and V of that head in LDS, a wave per query row -----------------
+__global__ __launch_bounds__(256) void vit_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int T) {
+    constexpr int LK = VDH + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Ks = lds, *Vs = Ks + (size_t)T * LK, *Qs = Vs + (size_t)T * VDH, *Ps = Qs + 4 * VDH;   // Ps [4][VT_MAX]
+    const int im = blockIdx.x / VH, h = blockIdx.x % VH, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *base = qkv + (size_t)im * T * (3 * VD) + h * VDH;
+    for (int idx = tid; idx < T * VDH; idx += 256) {
+        const int j = idx >> 6, d = idx & 63;
+        Ks[j * LK + d] = base[(size_t)j * (3 * VD) + VD + d];
+        Vs[j * VDH + d] = base[(size_t)j * (3 * VD) + 2 * VD + d];
+    }
+    __syncthreads();
+    for (int i = wave; i < T; i += 4) {
+        Qs[wave * VDH + lane] = base[(size_t)i * (3 * VD) + lane] * 0.125f;       // head_dim ** -0.5
+        VIT_WAVE_SYNC();
+        float s[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = lane + 64 * jj, jc = j < T ? j : T - 1;
+            float a = 0.0f;
+#pragma unroll 16
+            for (int d = 0; d < VDH; ++d) a = fmaf(Qs[wave * VDH + d], Ks[jc * LK + d], a);
+            s[jj] = j < T ? a : -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        float e[4], sum = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            e[jj] = (lane + 64 * jj < T) ? expf(s[jj] - mx) : 0.0f;
+            sum += e[jj];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) Ps[wave * VT_MAX + lane + 64 * jj] = e[jj] * inv;
+        VIT_WAVE_SYNC();
+        float o = 0.0f;
+        for (int j = 0; j < T; ++j) o = fmaf(Ps[wave * VT_MAX + j], Vs[j * VDH + lane], o);
+        ctx[((size_t)im * T + i) * VD + h * VDH + lane] = o;
+        VIT_WAVE_SYNC();
+    }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------
+#define VIT_TRY(expr)        \
+    do {                     \
+        int _rc = (expr);    \
+        if (_rc) return _rc; \
+    } while (0)
+
+static int vit_alloc(pd_vit *v, float **p, size_t n) {
+    PD_HIP_CHECK(hipMalloc((void **)p, n * sizeof(float)));
+    v->allocs.push_back(*p);
+    return PD_OK;
+}
+static int vit_copy(pd_vit *v, float **dst, const float *src, size_t n) {
+    if (!src) {
+        pd_set_error("pd_vit_create: a weight pointer is NULL");
+        return PD_ERR_INVALID_ARG;
+    }
+    VIT_TRY(vit_alloc(v, dst, n));
+    PD_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice));
+    return PD_OK;
+}
+static int vit_pack(pd_vit *v, float **dst, const float *W, int Nout, int K, int ldw, int koff, const float *gamma) {
+    if (!W) {
+        pd_set_error("pd_vit_create: a weight pointer is NULL");
+        return PD_ERR_INVALID_ARG;
+    }
+    const size_t total = (size_t)(Nout / 32) * (K / 8) * 256;
+    VIT_TRY(vit_alloc(v, dst, total));
+    hipLaunchKernelGGL(vit_repack_kernel, dim3(512), dim3(256), 0, 0, W, Nout, K, ldw, koff, *dst, total, gamma);
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}
+static int vit_fold(pd_vit *v, float **dst, const float *W, const float *beta, const float *b, int Nout, int K) {
+    if (!W || !beta || !b) {
+        pd_set_error("pd_vit_create: a weight pointer is NULL");
+        return PD_ERR_INVALID_ARG;
+    }
+    VIT_TRY(vit_alloc(v, dst, Nout));
+    hipLaunchKernelGGL(vit_fold_bias_kernel, dim3((Nout + 127) / 128), dim3(128), 0, 0, W, beta, b, Nout, K, *dst);
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}
+
+template <typename KernelT>
+static int vit_set_lds(KernelT kern, size_t bytes) {
+    PD_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PD_OK;
+}
+
+extern "C" void pd_vit_destroy(pd_vit *v) {
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    (void)hipDeviceSynchronize();
+    for (void *p : v->allocs) (void)hipFree(p);
+    delete v;
+}
+
+extern "C" int pd_vit_create(const pd_vit_weights *w, pd_vit **out) {
+    if (!w || !out) {
+        pd_set_error("pd_vit_create: NULL argument");
+        return PD_ERR_INVALID_ARG;
+    }
+    if (w->dim != VD || w->num_heads != VH || w->mlp_hidden != VFF || w->patch_size != VP || w->depth < 1 || w->depth > VDEPTH_MAX ||
+        w->pos_grid < 1 || w->pos_grid > 15) {
+        pd_set_error("pd_vit_create: unsupported ViT shape (built for dim 384, 6 heads, MLP 1536, patch 16, <= %d blocks, position grid <= 15)",
+                     VDEPTH_MAX);
+        return PD_ERR_UNSUPPORTED;
+    }
+    pd_vit *v = new pd_vit();
+    *out = nullptr;
+    PD_HIP_CHECK(hipGetDevice(&v->device));
+    v->depth = w->depth;
+    v->grid0 = w->pos_grid;
+    int rc = PD_OK;
+    do {
+        if ((rc = vit_pack(v, &v->patch_wp, w->patch_w, VD, VKP, VKP, 0, nullptr))) break;
+        if ((rc = vit_copy(v, &v->patch_b, w->patch_b, VD))) break;
+        if ((rc = vit_copy(v, &v->cls, w->cls_token, VD))) break;
+        if ((rc = vit_copy(v, &v->pos, w->pos_embed, (size_t)(1 + w->pos_grid * w->pos_grid) * VD))) break;
+        if ((rc = vit_copy(v, &v->norm_w, w->norm_w, VD))) break;
+        if ((rc = vit_copy(v, &v->norm_b, w->norm_b, VD))) break;
+        if ((rc = vit_alloc(v, &v->zero_b, VD))) break;
+        if (hipMemset(v->zero_b, 0, VD * sizeof(float)) != hipSuccess) {
+            rc = PD_ERR_HIP;
+            break;
+        }
+        for (int l = 0; l < w->depth && !rc; ++l) {
+            const pd_vit_layer_weights &s = w->layers[l];
+            pd_vit::Layer &L = v->L[l];
+            // LayerNorm affine folded: W' = W diag(gamma), b' = b + W beta
+            if ((rc = vit_pack(v, &L.qkv_wp, s.qkv_w, 3 * VD, VD, VD, 0, s.norm1_w))) break;
+            if ((rc = vit_fold(v, &L.qkv_b, s.qkv_w, s.norm1_b, s.qkv_b, 3 * VD, VD))) break;
+            if ((rc = vit_pack(v, &L.proj_wp, s.proj_w, VD, VD, VD, 0, nullptr))) break;
+            if ((rc = vit_copy(v, &L.proj_b, s.proj_b, VD))) break;
+            if ((rc = vit_pack(v, &L.fc1_wp, s.fc1_w, VFF, VD, VD, 0, s.norm2_w))) break;
+            if ((rc = vit_fold(v, &L.fc1_b, s.fc1_w, s.norm2_b, s.fc1_b, VFF, VD))) break;
+            if ((rc = vit_pack(v, &L.fc2a_wp, s.fc2_w, VD, VKP, VFF, 0, nullptr))) break;     // K columns [0, 768)
+            if ((rc = vit_pack(v, &L.fc2b_wp, s.fc2_w, VD, VKP, VFF, VKP, nullptr))) break;   // K columns [768, 1536)
+            if ((rc = vit_copy(v, &L.fc2_b, s.fc2_b, VD))) break;
+        }
+        if (rc) break;
+        if ((rc = vit_set_lds(vit_gemm_kernel<VKP, 3, 4>, 32 * (VKP + 4) * 4))) break;
+        if ((rc = vit_set_lds(vit_gemm_kernel<VD, 1, 0>, 32 * (VD + 4) * 4))) break;
+        if ((rc = vit_set_lds(vit_gemm_kernel<VD, 0, 2>, 32 * (VD + 4) * 4))) break;
+        if ((rc = vit_set_lds(vit_gemm_kernel<VD, 1, 3>, 32 * (VD + 4) * 4))) break;
+        if ((rc = vit_set_lds(vit_gemm_kernel<VKP, 0, 2>, 32 * (VKP + 4) * 4))) break;
+        if ((rc = vit_set_lds(vit_attn_kernel, (VT_MAX * (2 * VDH + 1) + 4 * VDH + 4 * VT_MAX) * 4))) break;
+        if (hipDeviceSynchronize() != hipSuccess) rc = PD_ERR_HIP;
+    } while (0);
+    if (rc) {
+        pd_vit_destroy(v);
+        return rc;
+    }
+    *out = v;
+    return PD_OK;
+}
+
+static int vit_reserve(pd_vit *v, size_t tokens, size_t pixels) {
+    auto grow = [&](float **p, size_t n) -> int {
+        if (*p) {
+            (void)hipFree(*p);
+            for (auto &q : v->allocs)
+                if (q == *p) q = nullptr;
+        }
+        return vit_alloc(v, p, n);
+    };
+    if (tokens > v->cap_tokens) {
+        PD_HIP_CHECK(hipDeviceSynchronize());
+        VIT_TRY(grow(&v->x, tokens * VD));
+        VIT_TRY(grow(&v->qkv, tokens * 3 * VD));
+        VIT_TRY(grow(&v->ctx, tokens * VD));
+        VIT_TRY(grow(&v->hid, tokens * VFF));
+        v->cap_tokens = tokens;
+    }
+    if (pixels > v->cap_pixels) {
+        PD_HIP_CHECK(hipDeviceSynchronize());
+        VIT_TRY(grow(&v->img, pixels));
+        v->cap_pixels = pixels;
+    }
+    return PD_OK;
+}
+
+template <int K, int AMODE, int EPI>
+static void vit_gemm(const VitGemmArgs &g, hipStream_t s) {
+    const int MT = (g.M + 31) / 32;
+    hipLaunchKernelGGL((vit_gemm_kernel<K, AMODE, EPI>), dim3(MT * (g.Nout / 32)), dim3(256), 32 * (K + 4) * 4, s, g);
+}
+
+// one scale: images [n,3,H,W] in [0,1] -> z (+)= norm(ViT(prep(images)))[:, 0] * weight.  pos_scaled: the position table of
+// this token grid [1 + gh*gw, 384] (DEVICE), resampled by the caller (bicubic, as DINO's interpolate_pos_encoding does).
+extern "C" int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, int H, int W, float scale_factor,
+                                    const float *pos_scaled, float weight, int accumulate, float *z_out, void *stream) {
+    if (!v || !images || !z_out || n_img <= 0 || H < VP || W < VP || !(scale_factor > 0.0f)) {
+        pd_set_error("pd_vit_forward_scale: invalid arguments (n=%d H=%d W=%d scale=%g)", n_img, H, W, (double)scale_factor);
+        return PD_ERR_INVALID_ARG;
+    }
+    const bool identity = scale_factor == 1.0f;
+    const int Hs = identity ? H : (int)floor((double)H * (double)scale_factor), Ws = identity ? W : (int)floor((double)W * (double)scale_factor);
+    const int gh = Hs / VP, gw = Ws / VP, P = gh * gw, T = P + 1;
+    if (gh < 1 || gw < 1 || T > VT_MAX) {
+        pd_set_error("pd_vit_forward_scale: %d x %d pixels give %d tokens per image (1..%d supported)", Hs, Ws, T, VT_MAX);
+        return PD_ERR_UNSUPPORTED;
+    }
+    const bool native = (gh == v->grid0 && gw == v->grid0);
+    if (!native && !pos_scaled) {
+        pd_set_error("pd_vit_forward_scale: a %d x %d token grid needs the resampled position table (pos_scaled)", gh, gw);
+        return PD_ERR_INVALID_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t tokens = (size_t)n_img * T;
+    VIT_TRY(vit_reserve(v, tokens, (size_t)n_img * 3 * Hs * Ws));
+    const float *pos = native && !pos_scaled ? v->pos : pos_scaled;
+    {
+        const size_t total = (size_t)n_img * 3 * Hs * Ws;
+        hipLaunchKernelGGL(vit_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, images, n_img, H, W, Hs, Ws,
+                           1.0f / scale_factor, identity ? 1 : 0, v->img);
+    }
+    VitGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.T = T; g.gh = gh; g.gw = gw; g.Hs = Hs; g.Ws = Ws;
+    // patch embedding + position, CLS rows
+    g.img = v->img; g.Wp = v->patch_wp; g.bias = v->patch_b; g.pos = pos; g.C = v->x; g.M = n_img * P; g.Nout = VD; g.lda = VKP;
+    vit_gemm<VKP, 3, 4>(g, s);
+    hipLaunchKernelGGL(vit_cls_kernel, dim3((n_img * VD + 255) / 256), dim3(256), 0, s, v->cls, pos, n_img, T, v->x);
+    g.M = (int)tokens;
+    const size_t attn_lds = ((size_t)T * (2 * VDH + 1) + 4 * VDH + 4 * VT_MAX) * 4;
+    for (int l = 0; l < v->depth; ++l) {
+        const pd_vit::Layer &L = v->L[l];
+        g.A = v->x; g.lda = VD; g.Wp = L.qkv_wp; g.bias = L.qkv_b; g.C = v->qkv; g.Nout = 3 * VD;
+        vit_gemm<VD, 1, 0>(g, s);
+        hipLaunchKernelGGL(vit_attn_kernel, dim3(n_img * VH), dim3(256), attn_lds, s, v->qkv, v->ctx, T);
+        g.A = v->ctx; g.lda = VD; g.Wp = L.proj_wp; g.bias = L.proj_b; g.C = v->x; g.Nout = VD;
+        vit_gemm<VD, 0, 2>(g, s);
+        g.A = v->x; g.lda = VD; g.Wp = L.fc1_wp; g.bias = L.fc1_b; g.C = v->hid; g.Nout = VFF;
+        vit_gemm<VD, 1, 3>(g, s);
+        g.A = v->hid; g.lda = VFF; g.Wp = L.fc2a_wp; g.bias = L.fc2_b; g.C = v->x; g.Nout = VD;
+        vit_gemm<VKP, 0, 2>(g, s);
+        g.A = v->hid + VKP; g.Wp = L.fc2b_wp; g.bias = v->zero_b;
+        vit_gemm<VKP, 0, 2>(g, s);
+    }
+    hipLaunchKernelGGL(vit_final_kernel, dim3(n_img), dim3(64), 0, s, v->x, T, v->norm_w, v->norm_b, weight, accumulate, z_out);
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}

@@ -194,6 +194,15 @@ def test_pose_diffusion_model_forward_api(seeded_diffuser):
     assert torch.equal(cams.T.cpu(), ref["T"])
     with pytest.raises(NotImplementedError):
         model(image=None, training=True, z=z)
+    # images in: the extractor (csrc/pd_vit.hip) feeds the sampler; same noise -> the same poses as with its z handed in
+    img = torch.rand(2, 5, 3, 224, 224, generator=torch.Generator().manual_seed(3)).to(DEV)
+    z_img = model.image_feature_extractor(img.reshape(10, 3, 224, 224)).reshape(2, 5, -1)
+    assert z_img.shape == (2, 5, 384) and torch.isfinite(z_img).all()
+    torch.manual_seed(11)
+    a = model(image=img, training=False)["pose_encoding"]
+    torch.manual_seed(11)
+    b = model(image=None, training=False, z=z_img)["pose_encoding"]
+    assert torch.equal(a, b)
 
 
 # ------------------------------------------------------------------------------------------------ GGS
@@ -797,3 +806,76 @@ def test_image_preprocessing_vs_reference_fixture(golden):
         assert np.abs(imgs[0].cpu().numpy() - ref.numpy()).max() < 2e-6
     with pytest.raises(NotImplementedError):
         li.load_and_preprocess_images(img_dir, 32, mode="nearest")
+
+
+# ------------------------------------------------------------------------------------------------ N1: image features
+@pytest.fixture(scope="module")
+def vit_pair():
+    from oracle import vit_oracle as VO
+    from posediffusion_amd.vit import VitEngine, vit_state
+    net = VO.make_vit(seed=0)
+    eng = VitEngine(vit_state(net), torch.device(DEV))
+    yield net, eng, VO
+    eng.close()
+
+
+def test_vit_single_scale_vs_oracle(vit_pair):
+    """patch embedding, CLS / position tokens, 12 blocks, final LayerNorm at the trained 14 x 14 grid."""
+    net, eng, VO = vit_pair
+    x = torch.rand(3, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    ref = VO.multiscale_features(net, x, (1,))
+    out = eng.multiscale(x.to(DEV), (1,)).cpu()
+    assert rel_err(out, ref) < 2e-5, rel_err(out, ref)
+
+
+def test_vit_multiscale_vs_oracle(vit_pair):
+    """the reference's three scales (1, 1/2, 1/3): bilinear rescaling, resampled position grids (7 x 7, 4 x 4), average."""
+    net, eng, VO = vit_pair
+    x = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+    ref = VO.multiscale_features(net, x, (1, 1 / 2, 1 / 3))
+    out = eng.multiscale(x.to(DEV), (1, 1 / 2, 1 / 3)).cpu()
+    assert rel_err(out, ref) < 2e-5, rel_err(out, ref)
+    for sf in (1 / 2, 1 / 3):           # each scale on its own
+        assert rel_err(eng.multiscale(x.to(DEV), (sf,)).cpu(), VO.multiscale_features(net, x, (sf,))) < 2e-5
+
+
+def test_dropin_feature_extractor_loads_dino_names_and_matches_oracle(vit_pair):
+    """the drop-in module: DINO-named parameters (strict load), engine rebuilt when the parameters change, frozen flag,
+    injected backbones, unknown names."""
+    net, _, VO = vit_pair
+    models = synth._dropin()
+    ext = models.MultiScaleImageFeatureExtractor(modelname="dino_vits16", freeze=True).to(DEV)
+    assert ext.get_output_dim() == 384 and not any(p.requires_grad for p in ext.parameters())
+    ext._net.load_state_dict(net.state_dict(), strict=True)
+    x = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(7))
+    ref = VO.multiscale_features(net, x, (1, 1 / 2, 1 / 3))
+    assert rel_err(ext(x.to(DEV)).cpu(), ref) < 2e-5
+    e0 = ext._engine()
+    assert ext._engine() is e0                                   # cached while the parameters stand
+    net2 = VO.make_vit(seed=9)
+    ext._net.load_state_dict(net2.state_dict(), strict=True)      # in-place copy -> version bump -> engine rebuilt
+    assert rel_err(ext(x.to(DEV)).cpu(), VO.multiscale_features(net2, x, (1, 1 / 2, 1 / 3))) < 2e-5
+    assert ext._engine() is not e0
+    ext.scale_factors = [1 / 2]
+    assert rel_err(ext(x.to(DEV)).cpu(), VO.multiscale_features(net2, x, (1 / 2,))) < 2e-5
+    ext.backbone = lambda im: im.mean(dim=(2, 3))
+    assert ext(x.to(DEV)).shape == (2, 3)
+    with pytest.raises(ValueError):
+        models.MultiScaleImageFeatureExtractor(modelname="vgg16")
+    other = models.MultiScaleImageFeatureExtractor(modelname="resnet50")
+    with pytest.raises(RuntimeError, match="not implemented"):
+        other(x)
+    with pytest.raises(RuntimeError, match="AMD GPU"):
+        models.MultiScaleImageFeatureExtractor()(x)               # parameters on the CPU: no fallback
+
+
+def test_vit_other_image_sizes_and_limits(vit_pair):
+    """non-square and non-multiple-of-16 inputs (ragged token counts, resampled position grid); too many tokens raise."""
+    net, eng, VO = vit_pair
+    for (H, W) in ((96, 160), (130, 77), (240, 240)):
+        x = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(H))
+        assert rel_err(eng.multiscale(x.to(DEV), (1, 1 / 2)).cpu(), VO.multiscale_features(net, x, (1, 1 / 2))) < 2e-5, (H, W)
+    with pytest.raises(RuntimeError, match="tokens per image"):
+        eng.multiscale(torch.rand(1, 3, 336, 336).to(DEV), (1,))
+    with pytest.raises(ValueError):
+        eng.multiscale(torch.rand(1, 3, 224, 224).to(DEV), ())

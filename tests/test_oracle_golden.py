@@ -244,3 +244,29 @@ def test_camera_alignment_recovers_a_similarity_exactly():
     Tt = s * T - (TA[None, None] @ Rt)[:, 0]
     Ral, Tal, (ra, ta, ss) = O.corresponding_cameras_alignment(R, T, Rt, Tt)
     assert (Ral - Rt).abs().max() < 1e-12 and (Tal - Tt).abs().max() < 1e-12 and abs(float(ss) - s) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------- N1: image features
+def test_multiscale_wrapper_against_live_reference():
+    """oracle/vit_oracle.multiscale_features (normalise, rescale by 1, 1/2, 1/3, average) against the reference's own
+    models/image_feature_extractor.py executed in place around the same (restated) ViT."""
+    from oracle import ref_stubs as RS
+    from oracle import vit_oracle as VO
+    if not RS.available():
+        pytest.skip("reference tree not mounted")
+    net = VO.make_vit(seed=3)
+    ext = RS.load_reference_extractor(net)
+    x = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        ref = ext(x)
+    ours = VO.multiscale_features(net, x, (1, 1 / 2, 1 / 3))
+    assert ext.get_output_dim() == 384 and tuple(ref.shape) == (2, 384)
+    assert torch.equal(ref, ours)
+
+
+def test_vit_oracle_loads_dino_state_dict_names():
+    from oracle import vit_oracle as VO
+    keys = set(VO.make_vit(0).state_dict())
+    for k in ("cls_token", "pos_embed", "patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.bias", "norm.weight"):
+        assert k in keys
+    assert sum(v.numel() for v in VO.make_vit(0).state_dict().values()) == 21665664      # ViT-S/16
