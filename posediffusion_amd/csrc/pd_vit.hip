@@ -28,7 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define VFF 1536        // MLP hidden
 #define VP 16           // patch size
 #define VKP 768         // 3 * 16 * 16
-#define VT_MAX 256      // tokens per image this version's attention kernel holds in LDS (images up to 240 x 240)
+#define VT_MAX 1056     // tokens per image: the attention kernel keeps one 32 x T score block in LDS (images up to 512 x 512)
 #define VDEPTH_MAX 16
 
 struct pd_vit {
@@ -36,11 +36,12 @@ struct pd_vit {
     float *patch_wp = nullptr, *patch_b = nullptr, *cls = nullptr, *pos = nullptr;   // pos [1 + grid0^2, 384]
     struct Layer {
         float *qkv_wp, *qkv_b, *proj_wp, *proj_b, *fc1_wp, *fc1_b, *fc2a_wp, *fc2b_wp, *fc2_b;
+        float *qkv_wf, *proj_wf, *fc1_wf, *fc2_wf;      // row-major copies (LayerNorm scale folded) for the streamed GEMM
     } L[VDEPTH_MAX];
     float *norm_w = nullptr, *norm_b = nullptr, *zero_b = nullptr;
     // workspaces, sized at the first forward / grown on demand
     size_t cap_tokens = 0, cap_pixels = 0;
-    float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *hid = nullptr, *img = nullptr;
+    float *x = nullptr, *xn = nullptr, *qkv = nullptr, *ctx = nullptr, *hid = nullptr, *img = nullptr;
     std::vector<void *> allocs;
 };
 
@@ -278,59 +279,297 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(VitGemmArgs g) {
     }
 }
 
-// LDS hand-over between the lanes of ONE wave (waves run different numbers of rows, so no workgroup barrier here)
-#define VIT_WAVE_SYNC()                                        \
-    do {                                                       \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
-        __builtin_amdgcn_wave_barrier();                       \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
-    } while (0)
+// ---- GEMM for many rows (M >= VIT_STREAM_MIN_ROWS) ------------------------------------------------------------------
+// LayerNorm without affine (folded into the next weight), eps 1e-6: x [M, 384] -> xn; one wave per row, 6 values per lane
+__global__ __launch_bounds__(256) void vit_ln_kernel(const float *__restrict__ x, float *__restrict__ xn, int M) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float *src = x + (size_t)row * VD;
+    float v[6], s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v[i] = src[lane + 64 * i];
+        s += v[i];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s * (1.0f / VD);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) q += (v[i] - mean) * (v[i] - mean);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / VD) + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xn[(size_t)row * VD + lane + 64 * i] = (v[i] - mean) * rstd;
+}
+// W[n][k] * gamma[k] -> Wf (row-major copy with the LayerNorm scale folded in)
+__global__ void vit_scale_cols_kernel(const float *__restrict__ W, const float *__restrict__ gamma, int K, size_t total, float *__restrict__ Wf) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+        Wf[idx] = gamma ? W[idx] * gamma[idx % K] : W[idx];
+}
 
-// ---- attention: one workgroup per (image, head); K and V of that head in LDS, a wave per query row -----------------
-__global__ __launch_bounds__(256) void vit_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int T) {
-    constexpr int LK = VDH + 1;
+//   C[m, n] = epi( sum_k A[m, k] W[n, k] + bias[n] ): a (64 WM) x (64 WN) tile per workgroup, one (32 WM) x (32 WN) quadrant
+//   per wave over the whole K; A and W (both row-major, k contiguous) stream through LDS in 32-deep chunks, double buffered
+//   with a register stage.  Blocks walk groups of ~2048 rows x all column tiles, so that a group's A rows and the whole W
+//   stay in the L2s.  EPI as above (0, 2, 3).
+struct VitStreamArgs {
+    const float *A, *W, *bias;
+    float *C;
+    int M, Nout, K, lda, ldw;
+};
+#define VIT_STREAM_KC 32
+#define VIT_STREAM_LR (VIT_STREAM_KC + 4)      // LDS row stride: fragment reads and staging writes both conflict free
+// staging registers are named scalars (arrays of float4 held across the K loop end up in scratch)
+#define VS_EACH(X) X(0) X(1) X(2) X(3)
+
+template <int EPI, int WM, int WN>
+__global__ __launch_bounds__(256) void vit_gemm_stream_kernel(VitStreamArgs g) {
+    constexpr int KC = VIT_STREAM_KC, LR = VIT_STREAM_LR, TM = 64 * WM, TN = 64 * WN, PA = 2 * WM, PW = 2 * WN, GROUP = 2048 / TM;
+    static_assert(KC == 32 && PA <= 4 && PW <= 4, "staging: 8 float4 per row, passes of 32 rows");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *Ks = lds, *Vs = Ks + (size_t)T * LK, *Qs = Vs + (size_t)T * VDH, *Ps = Qs + 4 * VDH;   // Ps [4][VT_MAX]
-    const int im = blockIdx.x / VH, h = blockIdx.x % VH, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *base = qkv + (size_t)im * T * (3 * VD) + h * VDH;
-    for (int idx = tid; idx < T * VDH; idx += 256) {
-        const int j = idx >> 6, d = idx & 63;
-        Ks[j * LK + d] = base[(size_t)j * (3 * VD) + VD + d];
-        Vs[j * VDH + d] = base[(size_t)j * (3 * VD) + 2 * VD + d];
+    float *As = lds, *Ws = lds + 2 * TM * LR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5, wm = wave & 1, wn = wave >> 1;
+    const int MT = (g.M + TM - 1) / TM, NT = g.Nout / TN;
+    int mtile, ntile;
+    {
+        const int b = blockIdx.x, full = (MT / GROUP) * GROUP * NT;
+        if (b < full) {
+            const int grp = b / (NT * GROUP), r = b - grp * (NT * GROUP);
+            ntile = r / GROUP;
+            mtile = grp * GROUP + r % GROUP;
+        } else {
+            const int r = b - full, rest = MT % GROUP;
+            ntile = r / rest;
+            mtile = (MT / GROUP) * GROUP + r % rest;
+        }
+    }
+    const int m0 = mtile * TM, n0 = ntile * TN;
+    const int sr = tid >> 3, sc = tid & 7, st = sr * LR + 4 * sc;
+#define VS_DECL(j)                                                                                                        \
+    const float4 *ap##j = (const float4 *)(g.A + (size_t)min(m0 + sr + 32 * (j < PA ? j : 0), g.M - 1) * g.lda) + sc;       \
+    const float4 *wp##j = (const float4 *)(g.W + (size_t)(n0 + sr + 32 * (j < PW ? j : 0)) * g.ldw) + sc;                   \
+    float4 ra##j, rw##j;
+#define VS_LOAD(j)                       \
+    if constexpr (j < PA) ra##j = ap##j[nx]; \
+    if constexpr (j < PW) rw##j = wp##j[nx];
+#define VS_STORE(j)                                                    \
+    if constexpr (j < PA) *(float4 *)(da + st + j * 32 * LR) = ra##j; \
+    if constexpr (j < PW) *(float4 *)(dw + st + j * 32 * LR) = rw##j;
+    VS_EACH(VS_DECL)
+    {
+        const int nx = 0;
+        float *da = As, *dw = Ws;
+        VS_EACH(VS_LOAD)
+        VS_EACH(VS_STORE)
     }
     __syncthreads();
-    for (int i = wave; i < T; i += 4) {
-        Qs[wave * VDH + lane] = base[(size_t)i * (3 * VD) + lane] * 0.125f;       // head_dim ** -0.5
-        VIT_WAVE_SYNC();
-        float s[4];
+    f32x16 acc[WM][WN];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = lane + 64 * jj, jc = j < T ? j : T - 1;
-            float a = 0.0f;
-#pragma unroll 16
-            for (int d = 0; d < VDH; ++d) a = fmaf(Qs[wave * VDH + d], Ks[jc * LK + d], a);
-            s[jj] = j < T ? a : -INFINITY;
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.0f;
+    const int nk = g.K / KC;
+    const int aoff = (wm * 32 * WM + l31) * LR + 4 * hi, boff = (wn * 32 * WN + l31) * LR + 4 * hi;
+    for (int kc = 0; kc < nk; ++kc) {
+        // the chunk after the last is the last again: loads and LDS writes stay unconditional (straight-line loop body)
+        const int nx = min(kc + 1, nk - 1) * (KC / 4);
+        VS_EACH(VS_LOAD)
+        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the matrix work
+        const float *a = As + (kc & 1) * TM * LR + aoff, *b = Ws + (kc & 1) * TN * LR + boff;
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            float4 af[WM], bf[WN];
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) af[mi] = *(const float4 *)(a + mi * 32 * LR + kk * 8);
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) bf[ni] = *(const float4 *)(b + ni * 32 * LR + kk * 8);
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+                }
         }
-        float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-        float e[4], sum = 0.0f;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            e[jj] = (lane + 64 * jj < T) ? expf(s[jj] - mx) : 0.0f;
-            sum += e[jj];
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) Ps[wave * VT_MAX + lane + 64 * jj] = e[jj] * inv;
-        VIT_WAVE_SYNC();
-        float o = 0.0f;
-        for (int j = 0; j < T; ++j) o = fmaf(Ps[wave * VT_MAX + j], Vs[j * VDH + lane], o);
-        ctx[((size_t)im * T + i) * VD + h * VDH + lane] = o;
-        VIT_WAVE_SYNC();
+        __builtin_amdgcn_sched_barrier(0);
+        float *da = As + ((kc + 1) & 1) * TM * LR, *dw = Ws + ((kc + 1) & 1) * TN * LR;
+        VS_EACH(VS_STORE)
+        __syncthreads();
     }
+#undef VS_DECL
+#undef VS_LOAD
+#undef VS_STORE
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            const int col = n0 + (wn * WN + ni) * 32 + l31, r0 = m0 + (wm * WM + mi) * 32 + 4 * hi;
+            const float bias = g.bias[col];
+            float res[16];
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)      // all residual loads in flight at once (rows past M re-read the last row)
+                    res[i] = g.C[(size_t)min(r0 + (i & 3) + 8 * (i >> 2), g.M - 1) * g.Nout + col];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = r0 + (i & 3) + 8 * (i >> 2);
+                float v = acc[mi][ni][i] + bias;
+                if constexpr (EPI == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                if constexpr (EPI == 2) v += res[i];
+                if (row < g.M) g.C[(size_t)row * g.Nout + col] = v;
+            }
+        }
+}
+
+// ---- attention on the matrix cores: one workgroup per (image, head, block of 32 query rows) --------------------------
+//   S = (Q / 8) K^T : wave w takes the key tiles w, w + 4, ... (32 keys each); Q and K fragments come straight from global
+//                     memory (L2) in the MFMA operand layout, the S tile goes to LDS [32][nkt * 32 + 4] (-inf past T)
+//   P = softmax(S)  : 8 threads per row, in place
+//   O = P V         : waves = 2 column tiles (32 of the 64 head dims) x 2 halves of the keys; V fragments from global memory
+//                     (32 consecutive dims per half wave), the two halves summed through LDS
+__global__ __launch_bounds__(256) void vit_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int T, int nqb) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nkt = (T + 31) >> 5, LP = nkt * 32 + 4;
+    float *S = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    int b = blockIdx.x;
+    const int qb = b % nqb;
+    b /= nqb;
+    const int h = b % VH, im = b / VH, q0 = qb * 32;
+    const float *base = qkv + (size_t)im * T * (3 * VD) + h * VDH;
+    float4 qf[8];
+    {
+        const int qr = min(q0 + l31, T - 1);
+        const float4 *src = (const float4 *)(base + (size_t)qr * (3 * VD)) + hi;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float4 v = src[2 * c];
+            qf[c] = make_float4(v.x * 0.125f, v.y * 0.125f, v.z * 0.125f, v.w * 0.125f);      // head_dim ** -0.5, exact
+        }
+    }
+    float4 kf[8];
+    if (wave < nkt) {
+        const float4 *src = (const float4 *)(base + (size_t)min(wave * 32 + l31, T - 1) * (3 * VD) + VD) + hi;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) kf[c] = src[2 * c];
+    }
+    for (int kt = wave; kt < nkt; kt += 4) {
+        float4 kn[8];
+        const bool more = kt + 4 < nkt;
+        if (more) {
+            const float4 *src = (const float4 *)(base + (size_t)min((kt + 4) * 32 + l31, T - 1) * (3 * VD) + VD) + hi;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) kn[c] = src[2 * c];
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[c].x, kf[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[c].y, kf[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[c].z, kf[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[c].w, kf[c].w, acc, 0, 0, 0);
+        }
+        const bool valid = kt * 32 + l31 < T;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[((i & 3) + 8 * (i >> 2) + 4 * hi) * LP + kt * 32 + l31] = valid ? acc[i] : -INFINITY;
+        if (more) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) kf[c] = kn[c];
+        }
+    }
+    // V fragments of this wave's first 16 key chunks: issued now, they land while the softmax runs
+    const int nt = wave & 1, kh = wave >> 1;
+    const int nk8 = (T + 7) >> 3, c_begin = kh ? (nk8 >> 1) : 0, c_end = kh ? nk8 : (nk8 >> 1);
+    const float *vbase = base + 2 * VD + nt * 32 + l31;
+    float vpre[16][4];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int k0 = min(c_begin + u, max(c_end - 1, 0)) * 8 + 4 * hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vpre[u][e] = vbase[(size_t)min(k0 + e, T - 1) * (3 * VD)];          // P is 0 past T
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    {
+        float *row = S + (tid >> 3) * LP;
+        const int sub = tid & 7, ncol = nkt * 32;
+        float mx = -INFINITY;
+        for (int j = sub; j < ncol; j += 8) mx = fmaxf(mx, row[j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+        float sum = 0.0f;
+        for (int j = sub; j < ncol; j += 8) {
+            const float e = expf(row[j] - mx);
+            row[j] = e;
+            sum += e;
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        sum += __shfl_xor(sum, 4, 64);
+        for (int j = sub; j < ncol; j += 8) row[j] = row[j] / sum;
+    }
+    __syncthreads();
+    const float *prow = S + l31 * LP + 4 * hi;
+    f32x16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        if (c_begin + u < c_end) {
+            const float4 pf = *(const float4 *)(prow + (c_begin + u) * 8);
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.x, vpre[u][0], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.y, vpre[u][1], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.z, vpre[u][2], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(pf.w, vpre[u][3], o, 0, 0, 0);
+        }
+    }
+    for (int c4 = c_begin + 16; c4 < c_end; c4 += 4) {     // more than 256 keys: 4 chunks of 8 keys per trip, 16 loads in flight
+        float vv[4][4];
+        float4 pf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = min(c4 + u, c_end - 1), k0 = c * 8 + 4 * hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[u][e] = vbase[(size_t)min(k0 + e, T - 1) * (3 * VD)];      // P is 0 past T
+            pf[u] = *(const float4 *)(prow + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c4 + u < c_end) {
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[u].x, vv[u][0], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[u].y, vv[u][1], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[u].z, vv[u][2], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[u].w, vv[u][3], o, 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    float *red = lds;      // [2][16][64]
+    if (kh) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[(nt * 16 + i) * 64 + lane] = o[i];
+    }
+    __syncthreads();
+    if (!kh) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int qr = q0 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+            if (qr < T) ctx[((size_t)im * T + qr) * VD + h * VDH + nt * 32 + l31] = o[i] + red[(nt * 16 + i) * 64 + lane];
+        }
+    }
+}
+static size_t vit_attn_lds(int T) {
+    const size_t s = (size_t)32 * (((T + 31) / 32) * 32 + 4);
+    return (s > 2048 ? s : 2048) * sizeof(float);
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------
@@ -372,6 +611,14 @@ static int vit_fold(pd_vit *v, float **dst, const float *W, const float *beta, c
     }
     VIT_TRY(vit_alloc(v, dst, Nout));
     hipLaunchKernelGGL(vit_fold_bias_kernel, dim3((Nout + 127) / 128), dim3(128), 0, 0, W, beta, b, Nout, K, *dst);
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}
+
+static int vit_rowmajor(pd_vit *v, float **dst, const float *W, int Nout, int K, const float *gamma) {
+    const size_t total = (size_t)Nout * K;
+    VIT_TRY(vit_alloc(v, dst, total));
+    hipLaunchKernelGGL(vit_scale_cols_kernel, dim3(512), dim3(256), 0, 0, W, gamma, K, total, *dst);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }
@@ -432,6 +679,10 @@ extern "C" int pd_vit_create(const pd_vit_weights *w, pd_vit **out) {
             if ((rc = vit_pack(v, &L.fc2a_wp, s.fc2_w, VD, VKP, VFF, 0, nullptr))) break;     // K columns [0, 768)
             if ((rc = vit_pack(v, &L.fc2b_wp, s.fc2_w, VD, VKP, VFF, VKP, nullptr))) break;   // K columns [768, 1536)
             if ((rc = vit_copy(v, &L.fc2_b, s.fc2_b, VD))) break;
+            if ((rc = vit_rowmajor(v, &L.qkv_wf, s.qkv_w, 3 * VD, VD, s.norm1_w))) break;
+            if ((rc = vit_rowmajor(v, &L.proj_wf, s.proj_w, VD, VD, nullptr))) break;
+            if ((rc = vit_rowmajor(v, &L.fc1_wf, s.fc1_w, VFF, VD, s.norm2_w))) break;
+            if ((rc = vit_rowmajor(v, &L.fc2_wf, s.fc2_w, VD, VFF, nullptr))) break;
         }
         if (rc) break;
         if ((rc = vit_set_lds(vit_gemm_kernel<VKP, 3, 4>, 32 * (VKP + 4) * 4))) break;
@@ -439,7 +690,7 @@ extern "C" int pd_vit_create(const pd_vit_weights *w, pd_vit **out) {
         if ((rc = vit_set_lds(vit_gemm_kernel<VD, 0, 2>, 32 * (VD + 4) * 4))) break;
         if ((rc = vit_set_lds(vit_gemm_kernel<VD, 1, 3>, 32 * (VD + 4) * 4))) break;
         if ((rc = vit_set_lds(vit_gemm_kernel<VKP, 0, 2>, 32 * (VKP + 4) * 4))) break;
-        if ((rc = vit_set_lds(vit_attn_kernel, (VT_MAX * (2 * VDH + 1) + 4 * VDH + 4 * VT_MAX) * 4))) break;
+        if ((rc = vit_set_lds(vit_attn_kernel, vit_attn_lds(VT_MAX)))) break;
         if (hipDeviceSynchronize() != hipSuccess) rc = PD_ERR_HIP;
     } while (0);
     if (rc) {
@@ -462,6 +713,7 @@ static int vit_reserve(pd_vit *v, size_t tokens, size_t pixels) {
     if (tokens > v->cap_tokens) {
         PD_HIP_CHECK(hipDeviceSynchronize());
         VIT_TRY(grow(&v->x, tokens * VD));
+        VIT_TRY(grow(&v->xn, tokens * VD));
         VIT_TRY(grow(&v->qkv, tokens * 3 * VD));
         VIT_TRY(grow(&v->ctx, tokens * VD));
         VIT_TRY(grow(&v->hid, tokens * VFF));
@@ -479,6 +731,16 @@ template <int K, int AMODE, int EPI>
 static void vit_gemm(const VitGemmArgs &g, hipStream_t s) {
     const int MT = (g.M + 31) / 32;
     hipLaunchKernelGGL((vit_gemm_kernel<K, AMODE, EPI>), dim3(MT * (g.Nout / 32)), dim3(256), 32 * (K + 4) * 4, s, g);
+}
+
+#define VIT_STREAM_MIN_ROWS 1024
+// 64 x 64 tiles: 128 x 64 and 128 x 128 (WM / WN = 2) measured no faster at 31 520 rows and slower at 3 940
+// (profiles/round1_j_vit_notes.md), so only <EPI, 1, 1> is instantiated
+template <int EPI>
+static void vit_gemm_stream(const float *A, int lda, const float *W, int K, const float *bias, float *C, int M, int Nout, hipStream_t s) {
+    VitStreamArgs g{A, W, bias, C, M, Nout, K, lda, K};
+    const size_t lds = (size_t)2 * 128 * VIT_STREAM_LR * sizeof(float);
+    hipLaunchKernelGGL((vit_gemm_stream_kernel<EPI, 1, 1>), dim3(((M + 63) / 64) * (Nout / 64)), dim3(256), lds, s, g);
 }
 
 // one scale: images [n,3,H,W] in [0,1] -> z (+)= norm(ViT(prep(images)))[:, 0] * weight.  pos_scaled: the position table of
@@ -518,12 +780,25 @@ extern "C" int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, i
     vit_gemm<VKP, 3, 4>(g, s);
     hipLaunchKernelGGL(vit_cls_kernel, dim3((n_img * VD + 255) / 256), dim3(256), 0, s, v->cls, pos, n_img, T, v->x);
     g.M = (int)tokens;
-    const size_t attn_lds = ((size_t)T * (2 * VDH + 1) + 4 * VDH + 4 * VT_MAX) * 4;
+    const size_t attn_lds = vit_attn_lds(T);
+    const int nqb = (T + 31) / 32;
+    const bool streamed = (int)tokens >= VIT_STREAM_MIN_ROWS;
     for (int l = 0; l < v->depth; ++l) {
         const pd_vit::Layer &L = v->L[l];
+        if (streamed) {
+            const int M = (int)tokens;
+            hipLaunchKernelGGL(vit_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M);
+            vit_gemm_stream<0>(v->xn, VD, L.qkv_wf, VD, L.qkv_b, v->qkv, M, 3 * VD, s);
+            hipLaunchKernelGGL(vit_attn_kernel, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
+            vit_gemm_stream<2>(v->ctx, VD, L.proj_wf, VD, L.proj_b, v->x, M, VD, s);
+            hipLaunchKernelGGL(vit_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M);
+            vit_gemm_stream<3>(v->xn, VD, L.fc1_wf, VD, L.fc1_b, v->hid, M, VFF, s);
+            vit_gemm_stream<2>(v->hid, VFF, L.fc2_wf, VFF, L.fc2_b, v->x, M, VD, s);
+            continue;
+        }
         g.A = v->x; g.lda = VD; g.Wp = L.qkv_wp; g.bias = L.qkv_b; g.C = v->qkv; g.Nout = 3 * VD;
         vit_gemm<VD, 1, 0>(g, s);
-        hipLaunchKernelGGL(vit_attn_kernel, dim3(n_img * VH), dim3(256), attn_lds, s, v->qkv, v->ctx, T);
+        hipLaunchKernelGGL(vit_attn_kernel, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
         g.A = v->ctx; g.lda = VD; g.Wp = L.proj_wp; g.bias = L.proj_b; g.C = v->x; g.Nout = VD;
         vit_gemm<VD, 0, 2>(g, s);
         g.A = v->x; g.lda = VD; g.Wp = L.fc1_wp; g.bias = L.fc1_b; g.C = v->hid; g.Nout = VFF;

@@ -3,7 +3,7 @@
 ``forward(image, gt_cameras=None, sequence_name=None, cond_fn=None, cond_start_step=0, training=True,
 batch_repeat=-1)`` keeps the reference signature; `training=False` returns
 ``{"pred_cameras": PerspectiveCameras(R, T, focal_length) in PyTorch3D NDC, "z": features}``.
-Extension: ``z=`` accepts precomputed image features (the DINO extractor is out of scope)."""
+Extension: ``z=`` accepts precomputed image features instead of ``image`` (skips the feature extractor)."""
 from typing import Dict, List, Optional
 
 import torch

@@ -872,10 +872,11 @@ def test_dropin_feature_extractor_loads_dino_names_and_matches_oracle(vit_pair):
 def test_vit_other_image_sizes_and_limits(vit_pair):
     """non-square and non-multiple-of-16 inputs (ragged token counts, resampled position grid); too many tokens raise."""
     net, eng, VO = vit_pair
-    for (H, W) in ((96, 160), (130, 77), (240, 240)):
+    for (H, W, sc) in ((96, 160, (1, 1 / 2)), (130, 77, (1, 1 / 2)), (240, 240, (1, 1 / 2)), (336, 336, (1, 1 / 3)), (16, 16, (1,)),
+                       (512, 512, (1,))):
         x = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(H))
-        assert rel_err(eng.multiscale(x.to(DEV), (1, 1 / 2)).cpu(), VO.multiscale_features(net, x, (1, 1 / 2))) < 2e-5, (H, W)
+        assert rel_err(eng.multiscale(x.to(DEV), sc).cpu(), VO.multiscale_features(net, x, sc)) < 2e-5, (H, W)
     with pytest.raises(RuntimeError, match="tokens per image"):
-        eng.multiscale(torch.rand(1, 3, 336, 336).to(DEV), (1,))
+        eng.multiscale(torch.rand(1, 3, 528, 528).to(DEV), (1,))
     with pytest.raises(ValueError):
         eng.multiscale(torch.rand(1, 3, 224, 224).to(DEV), ())
