@@ -72,6 +72,13 @@ def build_inputs(eng, diff, B, dev, seed0):
     return z, noise
 
 
+def _vit_flops(n, size, sf, D=384, L=12, FF=1536, P=16):
+    hs = size if sf == 1 else int(size * sf)
+    p = (hs // P) ** 2
+    t = p + 1
+    return n * (2 * p * 3 * P * P * D + L * (2 * t * (D * 3 * D + D * D + 2 * D * FF) + 4 * t * t * D))
+
+
 def pmc_traffic():
     """HBM-side traffic per launch from the committed rocprofv3 PMC summary (bench.py cannot collect counters
     itself: they need their own `rocprofv3 --pmc` passes).  -> (ggs_bytes, denoiser_step_bytes, provenance) or Nones."""
@@ -150,6 +157,8 @@ def main():
     ap.add_argument("--denoiser-wgs-per-xcd", type=int, default=-1,
                     help="per-XCD persistent denoiser kernel: workgroups per XCD (0 = per-launch kernels, -1 = default)")
     ap.add_argument("--trace", action="store_true", help="print the pipeline timeline (per-batch phase times) to stderr")
+    ap.add_argument("--no-image-features", action="store_true",
+                    help="skip the extra (untimed for `value`) images -> features -> poses measurement")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0, help="CPU seconds for the cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -239,6 +248,52 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = total * args.steps / dt
 
+    # ---- extra, outside the timed region of `value`: the same pipe fed from images (DINO ViT-S/16 at three
+    # scales on every frame, csrc/pd_vit.hip) -- each batch's features are computed on its context's stream right before its pass
+    feat = None
+    if not args.no_image_features and pipe.whole_pass_streams:
+        from posediffusion_amd.vit import VitEngine, vit_state
+        torch.manual_seed(1)
+        ext = synth._dropin().MultiScaleImageFeatureExtractor().to(dev)              # random-init DINO-shaped parameters
+        vits = [VitEngine(vit_state(ext._net), dev) for _ in range(depth)]
+        images = [torch.rand(B * N_FRAMES, 3, IMG, IMG, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + j))
+                  for j in range(depth)]
+        scales = (1, 1 / 2, 1 / 3)
+
+        def one_step_images():
+            j = pipe.next_context()
+            with torch.cuda.stream(pipe.next_stream()):
+                zj = vits[j].multiscale(images[j], scales).reshape(B, N_FRAMES, -1)
+            return pipe.submit(zj, inputs[j][1], COND_START, cfg, use_graph=use_graph, want_process=False)
+
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(pipe.u_stream):
+            for rep in range(3):
+                if rep == 1:
+                    e0.record()
+                vits[0].multiscale(images[0], scales)
+            e1.record()
+        torch.cuda.synchronize()
+        feat_ms = e0.elapsed_time(e1) / 2
+        for _ in range(depth):
+            one_step_images()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        pend = [one_step_images() for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        for e in engines:
+            e.check_async()
+        feat_flops = sum(_vit_flops(B * N_FRAMES, IMG, sf) for sf in scales)
+        feat = {"value": B * args.steps / dt2, "unit": "sequences/s on this GPU, images resident in HBM", "steps": args.steps,
+                "features_ms_per_batch_alone": feat_ms, "features_tflops_alone": feat_flops / (feat_ms * 1e-3) / 1e12,
+                "features_gflop_per_batch": feat_flops / 1e9, "frames_per_batch": B * N_FRAMES, "scales": "1, 1/2, 1/3",
+                "outputs_finite": bool(all(torch.isfinite(p.pose).all().item() for p in pend[-depth:])),
+                "precision": "split (bf16 hi + lo, three bf16 MFMA products, fp32 accumulate; z within 1e-5 of the fp32 network)",
+                "note": "ViT-S/16 with random-init weights (no checkpoint offline); TFLOP/s are fp32-equivalent; not part of `value`"}
+        for v in vits:
+            v.close()
+
     # every guided step must have run its full 700 iterations (no data-dependent early exit skipped work)
     iters = torch.stack([r[1][:, :, :, 1].sum(dim=(0, 2)).cpu() for r in results])    # [pass, local sequence]
     finite = bool(torch.isfinite(gathered).all().item())
@@ -304,6 +359,8 @@ def main():
         },
         "per_step_ms": {"denoiser_step": den_ms, "ggs_guided_step": ggs_ms, "ggs_iteration_us": ggs_ms * 1e3 / (7 * cfg.iter_num)},
     }
+    if feat is not None:
+        out["from_images"] = feat
     if rank == 0:
         if args.cpu_budget_s > 0 and world == 1:
             try:

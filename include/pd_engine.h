@@ -254,15 +254,20 @@ typedef struct pd_vit_weights {
 typedef struct pd_vit pd_vit;
 int pd_vit_create(const pd_vit_weights *w, pd_vit **out);
 void pd_vit_destroy(pd_vit *v);
+/* PD_VIT_OPT_EXACT_FP32: 0 (default) = batches of >= 1024 token rows run their GEMMs in split precision (every fp32 operand
+ * as bf16 hi + bf16 lo, three bf16 matrix products, fp32 accumulation; features deviate ~1e-5 of max|z| from the fp32
+ * network, the contract is 1e-4); 1 = the exact-fp32 matrix instruction everywhere. */
+#define PD_VIT_OPT_EXACT_FP32 1
+int pd_vit_set_option(pd_vit *v, int option, int value);
 
 /* One scale of _compute_multiscale_features (:65-84): images [n_img,3,H,W] DEVICE fp32 in [0,1] -> ImageNet normalisation
  * (:62-63), F.interpolate(scale_factor, bilinear, align_corners=False) (:86-87; skipped for scale_factor == 1), ViT,
  * CLS feature after the final LayerNorm;  z_out[n_img,384] = (accumulate ? z_out : 0) + weight * feature.
  * pos_scaled: DINO's interpolate_pos_encoding for this token grid, [1 + gh*gw, 384] DEVICE (bicubic resampling of the
  * trained grid; the caller -- posediffusion_amd/dropin/models/image_feature_extractor.py -- computes it once per image
- * size); may be NULL when the grid is the trained pos_grid x pos_grid.  At most 256 tokens per image (<= 240 x 240 pixels
- * after scaling) in this version. */
-int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, int H, int W, float scale_factor, const float *pos_scaled,
+ * size); may be NULL when the grid is the trained pos_grid x pos_grid.  At most 1056 tokens per image (<= 512 x 512 pixels
+ * after scaling). */
+int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, int H, int W, double scale_factor, const float *pos_scaled,
                          float weight, int accumulate, float *z_out, void *stream);
 
 /* ---- measurement helpers ------------------------------------------------------------------ */

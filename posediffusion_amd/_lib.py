@@ -76,7 +76,8 @@ SIGNATURES = {
     "pd_metrics_are": (_i, [_vp, _vp, _i, _vp, _vp]),
     "pd_vit_create": (_i, [C.POINTER(pd_vit_weights), C.POINTER(_vp)]),
     "pd_vit_destroy": (None, [_vp]),
-    "pd_vit_forward_scale": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _vp, C.c_float, _i, _vp, _vp]),
+    "pd_vit_set_option": (_i, [_vp, _i, _i]),
+    "pd_vit_forward_scale": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _vp, C.c_float, _i, _vp, _vp]),
     "pd_preprocess_image": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pd_align_cameras": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
     "pd_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp, _i, _vp]),

@@ -21,6 +21,14 @@
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// split precision (see vit_gemm_split_kernel): fp32 -> {hi bf16 | lo bf16 << 16}, v ~= hi + lo
+__device__ __forceinline__ unsigned vit_split_word(float v) {
+    const __bf16 h = (__bf16)v;
+    const __bf16 l = (__bf16)(v - (float)h);
+    return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
 
 #define VD 384          // embedding dim
 #define VH 6            // heads
@@ -33,10 +41,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct pd_vit {
     int device = 0, depth = 0, grid0 = 0;       // grid0: side of the trained position grid (14)
+    int exact_fp32 = 0;                         // PD_VIT_OPT_EXACT_FP32
     float *patch_wp = nullptr, *patch_b = nullptr, *cls = nullptr, *pos = nullptr;   // pos [1 + grid0^2, 384]
     struct Layer {
         float *qkv_wp, *qkv_b, *proj_wp, *proj_b, *fc1_wp, *fc1_b, *fc2a_wp, *fc2b_wp, *fc2_b;
         float *qkv_wf, *proj_wf, *fc1_wf, *fc2_wf;      // row-major copies (LayerNorm scale folded) for the streamed GEMM
+        unsigned *qkv_ws, *proj_ws, *fc1_ws, *fc2_ws;   // split into bf16 hi / lo, in MFMA fragment order (vit_frag_split_kernel)
     } L[VDEPTH_MAX];
     float *norm_w = nullptr, *norm_b = nullptr, *zero_b = nullptr;
     // workspaces, sized at the first forward / grown on demand
@@ -281,6 +291,7 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(VitGemmArgs g) {
 
 // ---- GEMM for many rows (M >= VIT_STREAM_MIN_ROWS) ------------------------------------------------------------------
 // LayerNorm without affine (folded into the next weight), eps 1e-6: x [M, 384] -> xn; one wave per row, 6 values per lane
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void vit_ln_kernel(const float *__restrict__ x, float *__restrict__ xn, int M) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
@@ -301,7 +312,13 @@ __global__ __launch_bounds__(256) void vit_ln_kernel(const float *__restrict__ x
     for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
     const float rstd = 1.0f / sqrtf(q * (1.0f / VD) + 1e-6f);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) xn[(size_t)row * VD + lane + 64 * i] = (v[i] - mean) * rstd;
+    for (int i = 0; i < 6; ++i) {
+        const float o = (v[i] - mean) * rstd;
+        if constexpr (SPLIT)
+            ((unsigned *)xn)[(size_t)row * VD + lane + 64 * i] = vit_split_word(o);      // for vit_gemm_split_kernel
+        else
+            xn[(size_t)row * VD + lane + 64 * i] = o;
+    }
 }
 // W[n][k] * gamma[k] -> Wf (row-major copy with the LayerNorm scale folded in)
 __global__ void vit_scale_cols_kernel(const float *__restrict__ W, const float *__restrict__ gamma, int K, size_t total, float *__restrict__ Wf) {
@@ -427,12 +444,222 @@ __global__ __launch_bounds__(256) void vit_gemm_stream_kernel(VitStreamArgs g) {
         }
 }
 
+// ---- the same GEMM in split precision: x ~= hi + lo (two bf16), x.w ~= hi.hi + hi.lo + lo.hi on the bf16 matrix instruction ----
+// (16 x the rate of the f32 instruction per product, three products; fp32 accumulation).  Measured deviation of the CLS
+// features from the fp32 network: 8e-6 .. 1e-5 of max|z| (oracle-side simulation and GPU tests), a tenth of the 1e-4 contract.
+//   activations between kernels: one 32-bit word per element {hi | lo << 16} (stores keep the fp32 pattern); the A staging
+//   un-zips 8 words into an 8 x hi and an 8 x lo fragment on their way to LDS.  Weights are split and grouped at creation:
+//   per row, per 8 k: 8 hi then 8 lo (32 B), so their staging is a plain copy.  LDS rows as in the f32 kernel (36 dwords).
+// 8 consecutive fp32 (two float4) * scale -> an 8 x hi and an 8 x lo bf16 fragment
+__device__ __forceinline__ void vit_split8(const float4 &a, const float4 &c, float scale, bf16x8 &h, bf16x8 &l) {
+    const float v[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, c.x * scale, c.y * scale, c.z * scale, c.w * scale};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = (__bf16)v[e];
+        l[e] = (__bf16)(v[e] - (float)h[e]);
+    }
+}
+
+// GELU for the split-precision path: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, below the 2^-17 the split operands
+// keep), a dozen instructions instead of erff's ~35 -- the epilogue of fc1 is as long as its matrix loop otherwise.
+// 0.5 v (1 + erf(v / sqrt 2)) = v (1 - q / 2) for v >= 0 and v q / 2 for v < 0, q = erfc(|v| / sqrt 2) (no cancellation).
+__device__ __forceinline__ float vit_gelu_fast(float v) {
+    const float x = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float q = 0.5f * p * t * __expf(-x * x);
+    return v * (v >= 0.0f ? 1.0f - q : q);
+}
+
+// W[n][k] * gamma[k] -> split and packed in MFMA fragment order: [n / 32][k / 16][hi | lo][lane] x 16 B, lane = (n % 32) +
+// 32 * ((k / 8) % 2), 8 consecutive k per lane: one wave-wide 16-byte load is 1 KB contiguous
+__global__ void vit_frag_split_kernel(const float *__restrict__ W, const float *__restrict__ gamma, int K, size_t total, uint4 *__restrict__ out) {
+    const int KS = K / 16;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const size_t t = idx >> 6;
+        const int ks = (int)(t % KS), nt = (int)(t / KS);
+        const int n = nt * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+        unsigned w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = W[(size_t)n * K + k0 + e];
+            w[e] = vit_split_word(gamma ? v * gamma[k0 + e] : v);
+        }
+        uint4 hi, lo;
+        hi.x = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u); lo.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
+        hi.y = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u); lo.y = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+        hi.z = __builtin_amdgcn_perm(w[5], w[4], 0x05040100u); lo.z = __builtin_amdgcn_perm(w[5], w[4], 0x07060302u);
+        hi.w = __builtin_amdgcn_perm(w[7], w[6], 0x05040100u); lo.w = __builtin_amdgcn_perm(w[7], w[6], 0x07060302u);
+        out[(t * 2) * 64 + lane] = hi;
+        out[(t * 2 + 1) * 64 + lane] = lo;
+    }
+}
+
+struct VitSplitArgs {
+    const unsigned *A, *W;      // A: split words [M][lda]; W: vit_frag_split_kernel's fragment order
+    const float *bias;
+    void *C;                    // EPI 0 / 2: fp32 [M][Nout]; EPI 3: split words [M][Nout]
+    int M, Nout, K, lda;
+};
+
+// A rows stream through LDS (un-zipped into hi / lo fragments on the way, shared by the waves of a row block); the weight
+// fragments go straight from global memory / L2 to registers, one chunk ahead (they are already in operand order, and
+// keeping them out of LDS halves its traffic -- the LDS array, not the matrix pipe, limited the first version).
+template <int EPI, int WM, int WN>
+__global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
+    constexpr int KC = VIT_STREAM_KC, LR = VIT_STREAM_LR, TM = 64 * WM, TN = 64 * WN, GROUP = 2048 / TM;
+    static_assert(KC == 32 && WM <= 2 && WN <= 2, "staging: 4 groups of 8 per row chunk, passes of 64 rows");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned *As = (unsigned *)lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5, wm = wave & 1, wn = wave >> 1;
+    const int MT = (g.M + TM - 1) / TM, NT = g.Nout / TN;
+    int mtile, ntile;
+    {
+        const int b = blockIdx.x, full = (MT / GROUP) * GROUP * NT;
+        if (b < full) {
+            const int grp = b / (NT * GROUP), r = b - grp * (NT * GROUP);
+            ntile = r / GROUP;
+            mtile = grp * GROUP + r % GROUP;
+        } else {
+            const int r = b - full, rest = MT % GROUP;
+            ntile = r / rest;
+            mtile = (MT / GROUP) * GROUP + r % rest;
+        }
+    }
+    const int m0 = mtile * TM, n0 = ntile * TN;
+    const int sr = tid >> 2, sg = tid & 3, st = sr * LR + 8 * sg;      // 4 threads per row chunk, one group of 8 each
+    const int KS = g.K / 16;
+#define VP_EACH(X) X(0) X(1)
+#define VP_DECL(j)                                                                                                            \
+    const uint4 *ap##j = (const uint4 *)(g.A + (size_t)min(m0 + sr + 64 * (j < WM ? j : 0), g.M - 1) * g.lda) + 2 * sg;        \
+    const uint4 *wq##j = (const uint4 *)g.W + (size_t)(n0 / 32 + wn * WN + (j < WN ? j : 0)) * KS * 128 + lane;                 \
+    uint4 ra##j##a, ra##j##b, cw##j##0h, cw##j##0l, cw##j##1h, cw##j##1l, nw##j##0h, nw##j##0l, nw##j##1h, nw##j##1l;
+#define VP_LOAD(j)                                  \
+    if constexpr (j < WM) {                         \
+        ra##j##a = ap##j[nx];                       \
+        ra##j##b = ap##j[nx + 1];                   \
+    }                                               \
+    if constexpr (j < WN) {                         \
+        nw##j##0h = wq##j[(size_t)(nc * 4 + 0) * 64]; \
+        nw##j##0l = wq##j[(size_t)(nc * 4 + 1) * 64]; \
+        nw##j##1h = wq##j[(size_t)(nc * 4 + 2) * 64]; \
+        nw##j##1l = wq##j[(size_t)(nc * 4 + 3) * 64]; \
+    }
+#define VP_ROLL(j)             \
+    if constexpr (j < WN) {    \
+        cw##j##0h = nw##j##0h; \
+        cw##j##0l = nw##j##0l; \
+        cw##j##1h = nw##j##1h; \
+        cw##j##1l = nw##j##1l; \
+    }
+#define VP_STORE(j)                                                                                       \
+    if constexpr (j < WM) {                                                                               \
+        uint4 h, l;                                                                                       \
+        h.x = __builtin_amdgcn_perm(ra##j##a.y, ra##j##a.x, 0x05040100u);                                 \
+        l.x = __builtin_amdgcn_perm(ra##j##a.y, ra##j##a.x, 0x07060302u);                                 \
+        h.y = __builtin_amdgcn_perm(ra##j##a.w, ra##j##a.z, 0x05040100u);                                 \
+        l.y = __builtin_amdgcn_perm(ra##j##a.w, ra##j##a.z, 0x07060302u);                                 \
+        h.z = __builtin_amdgcn_perm(ra##j##b.y, ra##j##b.x, 0x05040100u);                                 \
+        l.z = __builtin_amdgcn_perm(ra##j##b.y, ra##j##b.x, 0x07060302u);                                 \
+        h.w = __builtin_amdgcn_perm(ra##j##b.w, ra##j##b.z, 0x05040100u);                                 \
+        l.w = __builtin_amdgcn_perm(ra##j##b.w, ra##j##b.z, 0x07060302u);                                 \
+        *(uint4 *)(da + st + j * 64 * LR) = h;                                                            \
+        *(uint4 *)(da + st + j * 64 * LR + 4) = l;                                                        \
+    }
+// the three products of one (column tile j, k step s) against every row tile
+#define VP_MMA(j, s)                                                                                                         \
+    if constexpr (j < WN) {                                                                                                  \
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, cw##j##s##h), bl = __builtin_bit_cast(bf16x8, cw##j##s##l);               \
+        _Pragma("unroll") for (int mi = 0; mi < WM; ++mi) {                                                                  \
+            acc[mi][j < WN ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al##s[mi], bh, acc[mi][j < WN ? j : 0], 0, 0, 0); \
+            acc[mi][j < WN ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah##s[mi], bl, acc[mi][j < WN ? j : 0], 0, 0, 0); \
+            acc[mi][j < WN ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah##s[mi], bh, acc[mi][j < WN ? j : 0], 0, 0, 0); \
+        }                                                                                                                    \
+    }
+    VP_EACH(VP_DECL)
+    {
+        const int nx = 0, nc = 0;
+        unsigned *da = As;
+        VP_EACH(VP_LOAD)
+        VP_EACH(VP_STORE)
+        VP_EACH(VP_ROLL)
+    }
+    __syncthreads();
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.0f;
+    const int nk = g.K / KC;
+    const int aoff = (wm * 32 * WM + l31) * LR + 8 * hi;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int nc = min(kc + 1, nk - 1), nx = nc * (KC / 4);       // the chunk after the last is the last again
+        VP_EACH(VP_LOAD)
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned *a = As + (kc & 1) * TM * LR + aoff;
+        bf16x8 ah0[WM], al0[WM], ah1[WM], al1[WM];     // 16 k per step: lanes 0-31 take group 2 s, lanes 32-63 group 2 s + 1
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+            ah0[mi] = __builtin_bit_cast(bf16x8, *(const uint4 *)(a + mi * 32 * LR));
+            al0[mi] = __builtin_bit_cast(bf16x8, *(const uint4 *)(a + mi * 32 * LR + 4));
+            ah1[mi] = __builtin_bit_cast(bf16x8, *(const uint4 *)(a + mi * 32 * LR + 16));
+            al1[mi] = __builtin_bit_cast(bf16x8, *(const uint4 *)(a + mi * 32 * LR + 20));
+        }
+        VP_MMA(0, 0)
+        VP_MMA(1, 0)
+        VP_MMA(0, 1)
+        VP_MMA(1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned *da = As + ((kc + 1) & 1) * TM * LR;
+        VP_EACH(VP_STORE)
+        VP_EACH(VP_ROLL)
+        __syncthreads();
+    }
+#undef VP_DECL
+#undef VP_LOAD
+#undef VP_ROLL
+#undef VP_STORE
+#undef VP_MMA
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            const int col = n0 + (wn * WN + ni) * 32 + l31, r0 = m0 + (wm * WM + mi) * 32 + 4 * hi;
+            const float bias = g.bias[col];
+            float res[16];
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) res[i] = ((const float *)g.C)[(size_t)min(r0 + (i & 3) + 8 * (i >> 2), g.M - 1) * g.Nout + col];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = r0 + (i & 3) + 8 * (i >> 2);
+                float v = acc[mi][ni][i] + bias;
+                if constexpr (EPI == 3) v = vit_gelu_fast(v);
+                if constexpr (EPI == 2) v += res[i];
+                if (row < g.M) {
+                    if constexpr (EPI == 3)
+                        ((unsigned *)g.C)[(size_t)row * g.Nout + col] = vit_split_word(v);
+                    else
+                        ((float *)g.C)[(size_t)row * g.Nout + col] = v;
+                }
+            }
+        }
+}
+
 // ---- attention on the matrix cores: one workgroup per (image, head, block of 32 query rows) --------------------------
 //   S = (Q / 8) K^T : wave w takes the key tiles w, w + 4, ... (32 keys each); Q and K fragments come straight from global
 //                     memory (L2) in the MFMA operand layout, the S tile goes to LDS [32][nkt * 32 + 4] (-inf past T)
 //   P = softmax(S)  : 8 threads per row, in place
 //   O = P V         : waves = 2 column tiles (32 of the 64 head dims) x 2 halves of the keys; V fragments from global memory
 //                     (32 consecutive dims per half wave), the two halves summed through LDS
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void vit_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int T, int nqb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nkt = (T + 31) >> 5, LP = nkt * 32 + 4;
@@ -443,6 +670,53 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const float *__restrict__
     b /= nqb;
     const int h = b % VH, im = b / VH, q0 = qb * 32;
     const float *base = qkv + (size_t)im * T * (3 * VD) + h * VDH;
+    if constexpr (SPLIT) {
+        // S = (Q / 8) K^T in split precision: 8 consecutive head dims per lane and 16-k step (lanes 0-31 the even groups of 8,
+        // lanes 32-63 the odd ones), each fp32 fragment split into bf16 hi + lo in registers, three bf16 products per step
+        bf16x8 qh[4], ql[4];
+        {
+            const float4 *src = (const float4 *)(base + (size_t)min(q0 + l31, T - 1) * (3 * VD)) + 2 * hi;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const float4 a = src[4 * st], c = src[4 * st + 1];
+                vit_split8(a, c, 0.125f, qh[st], ql[st]);                                   // head_dim ** -0.5, exact
+            }
+        }
+        float4 ka[4], kb[4];
+        if (wave < nkt) {
+            const float4 *src = (const float4 *)(base + (size_t)min(wave * 32 + l31, T - 1) * (3 * VD) + VD) + 2 * hi;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                ka[st] = src[4 * st];
+                kb[st] = src[4 * st + 1];
+            }
+        }
+        for (int kt = wave; kt < nkt; kt += 4) {
+            bf16x8 kh8[4], kl8[4];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) vit_split8(ka[st], kb[st], 1.0f, kh8[st], kl8[st]);
+            if (kt + 4 < nkt) {          // next tile's loads fly during this tile's products
+                const float4 *src = (const float4 *)(base + (size_t)min((kt + 4) * 32 + l31, T - 1) * (3 * VD) + VD) + 2 * hi;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    ka[st] = src[4 * st];
+                    kb[st] = src[4 * st + 1];
+                }
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql[st], kh8[st], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[st], kl8[st], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[st], kh8[st], acc, 0, 0, 0);
+            }
+            const bool valid = kt * 32 + l31 < T;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[((i & 3) + 8 * (i >> 2) + 4 * hi) * LP + kt * 32 + l31] = valid ? acc[i] : -INFINITY;
+        }
+    } else {
     float4 qf[8];
     {
         const int qr = min(q0 + l31, T - 1);
@@ -484,6 +758,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const float *__restrict__
 #pragma unroll
             for (int c = 0; c < 8; ++c) kf[c] = kn[c];
         }
+    }
     }
     // V fragments of this wave's first 16 key chunks: issued now, they land while the softmax runs
     const int nt = wave & 1, kh = wave >> 1;
@@ -563,10 +838,18 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const float *__restrict__
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int qr = q0 + (i & 3) + 8 * (i >> 2) + 4 * hi;
-            if (qr < T) ctx[((size_t)im * T + qr) * VD + h * VDH + nt * 32 + l31] = o[i] + red[(nt * 16 + i) * 64 + lane];
+            if (qr < T) {
+                const float v = o[i] + red[(nt * 16 + i) * 64 + lane];
+                float *dst = ctx + ((size_t)im * T + qr) * VD + h * VDH + nt * 32 + l31;
+                if constexpr (SPLIT)
+                    *(unsigned *)dst = vit_split_word(v);       // feeds vit_gemm_split_kernel
+                else
+                    *dst = v;
+            }
         }
     }
 }
+static constexpr size_t vit_split_lds(int WM) { return (size_t)2 * 64 * WM * VIT_STREAM_LR * sizeof(float); }
 static size_t vit_attn_lds(int T) {
     const size_t s = (size_t)32 * (((T + 31) / 32) * 32 + 4);
     return (s > 2048 ? s : 2048) * sizeof(float);
@@ -619,6 +902,16 @@ static int vit_rowmajor(pd_vit *v, float **dst, const float *W, int Nout, int K,
     const size_t total = (size_t)Nout * K;
     VIT_TRY(vit_alloc(v, dst, total));
     hipLaunchKernelGGL(vit_scale_cols_kernel, dim3(512), dim3(256), 0, 0, W, gamma, K, total, *dst);
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}
+
+static int vit_grouped(pd_vit *v, unsigned **dst, const float *W, int Nout, int K, const float *gamma) {
+    const size_t total = (size_t)(Nout / 32) * (K / 16) * 64;        // one thread per (32-column tile, 16-k step, lane)
+    float *p = nullptr;
+    VIT_TRY(vit_alloc(v, &p, (size_t)Nout * K));
+    *dst = (unsigned *)p;
+    hipLaunchKernelGGL(vit_frag_split_kernel, dim3(512), dim3(256), 0, 0, W, gamma, K, total, (uint4 *)p);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }
@@ -683,6 +976,10 @@ extern "C" int pd_vit_create(const pd_vit_weights *w, pd_vit **out) {
             if ((rc = vit_rowmajor(v, &L.proj_wf, s.proj_w, VD, VD, nullptr))) break;
             if ((rc = vit_rowmajor(v, &L.fc1_wf, s.fc1_w, VFF, VD, s.norm2_w))) break;
             if ((rc = vit_rowmajor(v, &L.fc2_wf, s.fc2_w, VD, VFF, nullptr))) break;
+            if ((rc = vit_grouped(v, &L.qkv_ws, s.qkv_w, 3 * VD, VD, s.norm1_w))) break;
+            if ((rc = vit_grouped(v, &L.proj_ws, s.proj_w, VD, VD, nullptr))) break;
+            if ((rc = vit_grouped(v, &L.fc1_ws, s.fc1_w, VFF, VD, s.norm2_w))) break;
+            if ((rc = vit_grouped(v, &L.fc2_ws, s.fc2_w, VD, VFF, nullptr))) break;
         }
         if (rc) break;
         if ((rc = vit_set_lds(vit_gemm_kernel<VKP, 3, 4>, 32 * (VKP + 4) * 4))) break;
@@ -690,7 +987,8 @@ extern "C" int pd_vit_create(const pd_vit_weights *w, pd_vit **out) {
         if ((rc = vit_set_lds(vit_gemm_kernel<VD, 0, 2>, 32 * (VD + 4) * 4))) break;
         if ((rc = vit_set_lds(vit_gemm_kernel<VD, 1, 3>, 32 * (VD + 4) * 4))) break;
         if ((rc = vit_set_lds(vit_gemm_kernel<VKP, 0, 2>, 32 * (VKP + 4) * 4))) break;
-        if ((rc = vit_set_lds(vit_attn_kernel, vit_attn_lds(VT_MAX)))) break;
+        if ((rc = vit_set_lds(vit_attn_kernel<false>, vit_attn_lds(VT_MAX)))) break;
+        if ((rc = vit_set_lds(vit_attn_kernel<true>, vit_attn_lds(VT_MAX)))) break;
         if (hipDeviceSynchronize() != hipSuccess) rc = PD_ERR_HIP;
     } while (0);
     if (rc) {
@@ -743,16 +1041,33 @@ static void vit_gemm_stream(const float *A, int lda, const float *W, int K, cons
     hipLaunchKernelGGL((vit_gemm_stream_kernel<EPI, 1, 1>), dim3(((M + 63) / 64) * (Nout / 64)), dim3(256), lds, s, g);
 }
 
-// one scale: images [n,3,H,W] in [0,1] -> z (+)= norm(ViT(prep(images)))[:, 0] * weight.  pos_scaled: the position table of
-// this token grid [1 + gh*gw, 384] (DEVICE), resampled by the caller (bicubic, as DINO's interpolate_pos_encoding does).
-extern "C" int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, int H, int W, float scale_factor,
-                                    const float *pos_scaled, float weight, int accumulate, float *z_out, void *stream) {
-    if (!v || !images || !z_out || n_img <= 0 || H < VP || W < VP || !(scale_factor > 0.0f)) {
-        pd_set_error("pd_vit_forward_scale: invalid arguments (n=%d H=%d W=%d scale=%g)", n_img, H, W, (double)scale_factor);
+// split precision: 128 x 128 tiles where the column count gives enough of them, 128 x 64 for the 384-wide outputs
+template <int EPI, int WM, int WN>
+static void vit_gemm_split(const unsigned *A, int lda, const unsigned *W, int K, const float *bias, void *C, int M, int Nout, hipStream_t s) {
+    VitSplitArgs g{A, W, bias, C, M, Nout, K, lda};
+    constexpr int TM = 64 * WM, TN = 64 * WN;
+    hipLaunchKernelGGL((vit_gemm_split_kernel<EPI, WM, WN>), dim3(((M + TM - 1) / TM) * (Nout / TN)), dim3(256), vit_split_lds(WM), s, g);
+}
+
+extern "C" int pd_vit_set_option(pd_vit *v, int option, int value) {
+    if (!v || option != PD_VIT_OPT_EXACT_FP32 || (value != 0 && value != 1)) {
+        pd_set_error("pd_vit_set_option: unknown option %d / value %d", option, value);
         return PD_ERR_INVALID_ARG;
     }
-    const bool identity = scale_factor == 1.0f;
-    const int Hs = identity ? H : (int)floor((double)H * (double)scale_factor), Ws = identity ? W : (int)floor((double)W * (double)scale_factor);
+    v->exact_fp32 = value;
+    return PD_OK;
+}
+
+// one scale: images [n,3,H,W] in [0,1] -> z (+)= norm(ViT(prep(images)))[:, 0] * weight.  pos_scaled: the position table of
+// this token grid [1 + gh*gw, 384] (DEVICE), resampled by the caller (bicubic, as DINO's interpolate_pos_encoding does).
+extern "C" int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, int H, int W, double scale_factor,
+                                    const float *pos_scaled, float weight, int accumulate, float *z_out, void *stream) {
+    if (!v || !images || !z_out || n_img <= 0 || H < VP || W < VP || !(scale_factor > 0.0)) {
+        pd_set_error("pd_vit_forward_scale: invalid arguments (n=%d H=%d W=%d scale=%g)", n_img, H, W, scale_factor);
+        return PD_ERR_INVALID_ARG;
+    }
+    const bool identity = scale_factor == 1.0;
+    const int Hs = identity ? H : (int)floor((double)H * scale_factor), Ws = identity ? W : (int)floor((double)W * scale_factor);   // torch: floor(size * scale) in double
     const int gh = Hs / VP, gw = Ws / VP, P = gh * gw, T = P + 1;
     if (gh < 1 || gw < 1 || T > VT_MAX) {
         pd_set_error("pd_vit_forward_scale: %d x %d pixels give %d tokens per image (1..%d supported)", Hs, Ws, T, VT_MAX);
@@ -770,7 +1085,7 @@ extern "C" int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, i
     {
         const size_t total = (size_t)n_img * 3 * Hs * Ws;
         hipLaunchKernelGGL(vit_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, images, n_img, H, W, Hs, Ws,
-                           1.0f / scale_factor, identity ? 1 : 0, v->img);
+                           (float)(1.0 / scale_factor), identity ? 1 : 0, v->img);      // torch: float(1 / scale_factor) as the coordinate scale
     }
     VitGemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -785,20 +1100,31 @@ extern "C" int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, i
     const bool streamed = (int)tokens >= VIT_STREAM_MIN_ROWS;
     for (int l = 0; l < v->depth; ++l) {
         const pd_vit::Layer &L = v->L[l];
+        if (streamed && !v->exact_fp32) {
+            const int M = (int)tokens;
+            hipLaunchKernelGGL(vit_ln_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M);
+            vit_gemm_split<0, 2, 2>((const unsigned *)v->xn, VD, L.qkv_ws, VD, L.qkv_b, v->qkv, M, 3 * VD, s);
+            hipLaunchKernelGGL(vit_attn_kernel<true>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
+            vit_gemm_split<2, 2, 1>((const unsigned *)v->ctx, VD, L.proj_ws, VD, L.proj_b, v->x, M, VD, s);
+            hipLaunchKernelGGL(vit_ln_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M);
+            vit_gemm_split<3, 2, 2>((const unsigned *)v->xn, VD, L.fc1_ws, VD, L.fc1_b, v->hid, M, VFF, s);
+            vit_gemm_split<2, 2, 1>((const unsigned *)v->hid, VFF, L.fc2_ws, VFF, L.fc2_b, v->x, M, VD, s);
+            continue;
+        }
         if (streamed) {
             const int M = (int)tokens;
-            hipLaunchKernelGGL(vit_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M);
+            hipLaunchKernelGGL(vit_ln_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M);
             vit_gemm_stream<0>(v->xn, VD, L.qkv_wf, VD, L.qkv_b, v->qkv, M, 3 * VD, s);
-            hipLaunchKernelGGL(vit_attn_kernel, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
+            hipLaunchKernelGGL(vit_attn_kernel<false>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
             vit_gemm_stream<2>(v->ctx, VD, L.proj_wf, VD, L.proj_b, v->x, M, VD, s);
-            hipLaunchKernelGGL(vit_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M);
+            hipLaunchKernelGGL(vit_ln_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M);
             vit_gemm_stream<3>(v->xn, VD, L.fc1_wf, VD, L.fc1_b, v->hid, M, VFF, s);
             vit_gemm_stream<2>(v->hid, VFF, L.fc2_wf, VFF, L.fc2_b, v->x, M, VD, s);
             continue;
         }
         g.A = v->x; g.lda = VD; g.Wp = L.qkv_wp; g.bias = L.qkv_b; g.C = v->qkv; g.Nout = 3 * VD;
         vit_gemm<VD, 1, 0>(g, s);
-        hipLaunchKernelGGL(vit_attn_kernel, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
+        hipLaunchKernelGGL(vit_attn_kernel<false>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
         g.A = v->ctx; g.lda = VD; g.Wp = L.proj_wp; g.bias = L.proj_b; g.C = v->x; g.Nout = VD;
         vit_gemm<VD, 0, 2>(g, s);
         g.A = v->x; g.lda = VD; g.Wp = L.fc1_wp; g.bias = L.fc1_b; g.C = v->hid; g.Nout = VFF;

@@ -164,6 +164,12 @@ class SamplingPipeline:
         """The context (engine index) the next `submit` will use; upload that batch's matches there."""
         return self._submitted % self.contexts
 
+    def next_stream(self) -> torch.cuda.Stream:
+        """The stream the next `submit` starts on: work enqueued there first (e.g. the image feature extractor that
+        produces ``z``) is ordered before the sampler without an event."""
+        i = self._submitted
+        return self.g_streams[i % self.ggs_slots] if self.whole_pass_streams else self.u_streams[i % len(self.u_streams)]
+
     def submit(self, z: torch.Tensor, noise: torch.Tensor, cond_start_step: int = 0, ggs_cfg=None,
                use_graph: bool = True, want_process: bool = False,
                inputs_ready: Optional[torch.cuda.Event] = None) -> PendingSample:

@@ -22,7 +22,10 @@ def vit_state(net: torch.nn.Module) -> Dict[str, torch.Tensor]:
     """The DINO state_dict entries the engine reads, as contiguous fp32 device tensors."""
     sd = {k: v.detach() for k, v in net.state_dict().items()}
     need = ["patch_embed.proj.weight", "patch_embed.proj.bias", "cls_token", "pos_embed", "norm.weight", "norm.bias"]
-    depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+    blocks = [int(k.split(".")[1]) for k in sd if k.startswith("blocks.")]
+    if not blocks:
+        raise KeyError("not a DINO ViT state_dict: no `blocks.N.*` entries")
+    depth = 1 + max(blocks)
     for l in range(depth):
         need += [f"blocks.{l}.{n}" for n in ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
                                               "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
@@ -61,6 +64,10 @@ class VitEngine:
             _lib.check(self.lib.pd_vit_create(C.byref(w), C.byref(h)), "pd_vit_create")
         self._h = h
         self._pos_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    def set_exact_fp32(self, on: bool):
+        """True: the exact-fp32 matrix instruction everywhere; False (default): split-precision GEMMs for large batches."""
+        _lib.check(self.lib.pd_vit_set_option(self._h, 1, int(bool(on))), "pd_vit_set_option")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -102,7 +109,7 @@ class VitEngine:
         for i, sf in enumerate(scale_factors):
             hs, ws = (H, W) if sf == 1 else (int(math.floor(H * sf)), int(math.floor(W * sf)))
             pos = self._pos_for(hs, ws)
-            _lib.check(self.lib.pd_vit_forward_scale(self._h, x.data_ptr(), n, H, W, C.c_float(float(sf)),
+            _lib.check(self.lib.pd_vit_forward_scale(self._h, x.data_ptr(), n, H, W, C.c_double(float(sf)),
                                                      None if pos is None else pos.data_ptr(), C.c_float(1.0 / len(scale_factors)),
                                                      int(i > 0), z.data_ptr(), stream), "pd_vit_forward_scale")
         return z

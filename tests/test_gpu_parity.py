@@ -869,6 +869,47 @@ def test_dropin_feature_extractor_loads_dino_names_and_matches_oracle(vit_pair):
         models.MultiScaleImageFeatureExtractor()(x)               # parameters on the CPU: no fallback
 
 
+@pytest.mark.parametrize("exact", [True, False])
+def test_vit_large_batch_gemm_paths_vs_oracle(vit_pair, exact):
+    """>= 1024 token rows take the streamed GEMMs: exact fp32 (64 x 64 tiles) or split precision (bf16 hi + lo, three
+    products, 128-row tiles); ragged last row tiles; tolerance 2e-5 / 5e-5 against the 1e-4 contract."""
+    net, eng, VO = vit_pair
+    eng.set_exact_fp32(exact)
+    try:
+        tol = 2e-5 if exact else 5e-5
+        x = torch.rand(6, 3, 224, 224, generator=torch.Generator().manual_seed(21))            # 1 182 rows at scale 1
+        e1 = rel_err(eng.multiscale(x.to(DEV), (1, 1 / 2)).cpu(), VO.multiscale_features(net, x, (1, 1 / 2)))
+        x2 = torch.rand(11, 3, 240, 208, generator=torch.Generator().manual_seed(22))          # 2 156 rows, 15 x 13 grid
+        e2 = rel_err(eng.multiscale(x2.to(DEV), (1,)).cpu(), VO.multiscale_features(net, x2, (1,)))
+        assert e1 < tol and e2 < tol, (exact, e1, e2)
+        if not exact:      # the split path is a different rounding, not a different function: close to the exact path too
+            a = eng.multiscale(x.to(DEV), (1,))
+            eng.set_exact_fp32(True)
+            b = eng.multiscale(x.to(DEV), (1,))
+            assert 0 < rel_err(a, b) < 5e-5
+    finally:
+        eng.set_exact_fp32(False)
+
+
+def test_vit_shallow_network_and_rejected_shapes():
+    """`depth` is a parameter of the engine (here 2 blocks); other widths are refused at creation, loudly."""
+    from oracle import vit_oracle as VO
+    from posediffusion_amd.vit import VitEngine, vit_state
+    torch.manual_seed(0)
+    net = VO.DinoViT(depth=2).eval()
+    eng = VitEngine(vit_state(net), torch.device(DEV))
+    x = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    assert rel_err(eng.multiscale(x.to(DEV), (1, 1 / 2)).cpu(), VO.multiscale_features(net, x, (1, 1 / 2))) < 2e-5
+    eng.close()
+    wide = VO.DinoViT(dim=768, num_heads=12, depth=1).eval()
+    with pytest.raises(RuntimeError, match="unsupported ViT shape"):
+        VitEngine(vit_state(wide), torch.device(DEV))
+    with pytest.raises(KeyError):
+        vit_state(torch.nn.Linear(3, 3))
+    with pytest.raises(KeyError, match="missing"):
+        vit_state(torch.nn.ModuleDict({"blocks": torch.nn.ModuleList([torch.nn.Linear(3, 3)])}))
+
+
 def test_vit_other_image_sizes_and_limits(vit_pair):
     """non-square and non-multiple-of-16 inputs (ragged token counts, resampled position grid); too many tokens raise."""
     net, eng, VO = vit_pair
