@@ -5,10 +5,12 @@ A "step" = one full pass of the hot path over one batch of synthetic sequences:
   100 DDPM steps (transformer denoiser + posterior update) and, on the last `cond_start_step`=10
   steps, Geometry-Guided Sampling (5 optimisations = 700 clipped-momentum-SGD iterations per guided
   step, 7000 per sequence) over M = 57 000 pairwise matches per 20-frame sequence.
-Workload (config.workload): BASELINE.json configs[3] per-GPU shard = configs[2] x 8 concurrent:
-  8 independent 20-frame sequences per GPU, GGS on, 224^2, 190 pairs x 300 matches; weak scaling
-  (per-GPU work fixed, total sequences = 8 x n_gpus; at 8 GPUs this is exactly "64 sequences
-  sharded across 8 x MI355X").  Inputs are resident in HBM before the timed region.
+Workload (config.workload): BASELINE.json configs[3], "batch of 64 independent 20-frame sequences, GGS on"
+  (224^2, 190 pairs x 300 matches each), the whole batch on ONE GPU ("also run 64 on 1/2/4 GPUs"); weak
+  scaling: every GPU runs its own 64-sequence batches (total = 64 x n_gpus per step).  Four batches are in flight per
+  GPU (posediffusion_amd/pipeline.py), i.e. 256 sequences, one GGS workgroup = one CU per sequence; throughput
+  against the number in flight is in DESIGN.md section 5 (`--seqs-per-gpu 8`: 273 sequences/s at 73 ms latency).
+  Inputs are resident in HBM before the timed region.
 
 Launch: `python bench.py --gpus N --steps K --warmup W`; for N > 1 under torch.distributed.run
 (one rank per GPU, RCCL): ranks shard the sequences, no collective on the data path, one final
@@ -37,12 +39,14 @@ from posediffusion_amd import shard, synth  # noqa: E402
 N_FRAMES = 20
 IMG = 224
 PER_PAIR = 300
-SEQS_PER_GPU = 8
+SEQS_PER_GPU = 64                    # BASELINE configs[3]: one batch of 64 independent sequences
 COND_START = 10                      # cfgs/default.yaml:8
 FLOP_PER_MATCH_ITER = 100.0          # 36 fwd + 64 bwd
 DENOISER_PARAMS = 17_298_697         # fp32 -> 69.19 MB read per denoiser step
 FP32_PEAK_TFLOPS = 157.3             # MI355X fp32 vector ALU = dense fp32 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
+MATCH_BYTES = 16                     # kp1, kp2: 2 x float2 per match (pair indices are per work item)
+L2_TOTAL_BYTES = 8 * 4 * 2 ** 20     # 8 XCDs x 4 MiB
 
 
 # per-XCD persistent denoiser: workgroups per XCD when [alone on the chip, several batches in flight]; 0 = per-launch kernels
@@ -86,9 +90,10 @@ def pmc_traffic():
     try:
         with open(path) as f:
             d = json.load(f)
-        return (d["ggs_launch_B8"]["traffic_bytes_corrected"], d["denoiser_step_B8"]["traffic_bytes_corrected"],
+        return (d["ggs_launch"]["traffic_bytes_corrected"], d["denoiser_step"]["traffic_bytes_corrected"],
                 "profiles/round1_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, separate --pmc passes, "
-                "gfx950 FETCH_SIZE x2 correction; fabric-side counters (Infinity-Cache hits included); measured at 8 seq/GPU")
+                "gfx950 FETCH_SIZE x2 correction; fabric-side counters (Infinity-Cache hits included); measured on one "
+                f"{SEQS_PER_GPU}-sequence batch, one GGS workgroup per sequence")
     except Exception:
         return None, None, None
 
@@ -323,35 +328,55 @@ def main():
     den_gbs = DENOISER_PARAMS * 4 / (den_ms * 1e-3) / 1e9
 
     ggs_traffic, den_traffic, traffic_src = pmc_traffic() if B == SEQS_PER_GPU else (None, None, None)
+    # Which roof: with few sequences in flight the matches of a sequence stay in registers (24 workgroups per sequence) or in
+    # the L2s and the kernel is priced against the fp32 vector ALU.  With the default 256 in flight (one workgroup
+    # = one CU per sequence) their 16 B per match (kp1, kp2 as 2 x float2; the pair index is per work item) total
+    # 233 MB and are streamed from the fabric EVERY iteration -- the PMC traffic equals these algorithmic bytes -- so the
+    # kernel is priced against HBM.
+    match_bytes = float(B) * M * MATCH_BYTES * 7 * cfg.iter_num                 # one launch = 700 iterations
+    streams_matches = B * depth * M * MATCH_BYTES > L2_TOTAL_BYTES and (wgs or 24) < 24
+    alu = {"achieved": ggs_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ggs_tflops / FP32_PEAK_TFLOPS,
+           "achieved_all_launches": ggs_set_tflops, "frac_all_launches": ggs_set_tflops / FP32_PEAK_TFLOPS,
+           "algorithmic_flops_per_launch": ggs_flops}
+    roofline = {
+        "kernel": "pd_ggs_kernel (one launch = one guided step = 700 iterations x %d sequences)" % B,
+        "traffic": ggs_traffic, "traffic_source": traffic_src, "launch_ms": ggs_ms,
+        "co_resident_launches": depth, "all_launches_ms": ggs_set_ms,
+    }
+    if streams_matches:
+        gbs, set_gbs = match_bytes / (ggs_ms * 1e-3) / 1e9, depth * match_bytes / (ggs_set_ms * 1e-3) / 1e9
+        roofline.update({
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "achieved_all_launches": set_gbs, "frac_all_launches": set_gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": match_bytes, "fp32_alu": alu,
+            "note": f"{B * depth} sequences in flight: their matches ({B * depth * M * MATCH_BYTES / 1e6:.0f} MB) exceed the L2s "
+                    "and stream from Infinity Cache / HBM every iteration, 16 B per match. `achieved` is ONE launch alone on the "
+                    "chip (its workgroups cover a quarter of the CUs); `achieved_all_launches` is the set of co-resident "
+                    "launches of all contexts, as they run in the pipe. `fp32_alu` prices the same launches against the "
+                    "vector ALU (100 FLOP per match and iteration, SURVEY 8d)"})
+    else:
+        roofline.update(dict(alu, bound="mfma", bound_detail="fp32 vector ALU; its peak equals the dense fp32 MFMA peak (157.3 TFLOP/s)",
+                             note=("matches stay in registers for the whole launch" if (wgs or 24) >= 24 else
+                                   "matches are re-read from L2 every iteration (more than one work item per wave)") +
+                                  "; the fabric traffic is the per-iteration cross-workgroup exchange, not match streaming. "
+                                  "`achieved` is ONE launch; `achieved_all_launches` is the set of co-resident launches of all "
+                                  "contexts, as in the pipe"))
     out = {
         "metric": "sequences/sec (20-frame, GGS on)", "value": value, "unit": "sequences/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[3] per-GPU shard: {B} independent 20-frame sequences per GPU "
-                        f"({total} total), 100 DDPM steps, GGS on for the last {COND_START} steps "
+            "workload": f"BASELINE configs[3]: batches of {B} independent 20-frame sequences, one batch per step and GPU "
+                        f"({total} sequences per step in total), {depth} batches in flight per GPU; 100 DDPM steps, GGS on for the last {COND_START} steps "
                         f"(7000 iterations/sequence), M={M} matches/sequence (190 pairs x {PER_PAIR}), {IMG}x{IMG}; "
                         "random-init reference-rule weights, matches epipolar-consistent with the engine's own "
                         "unguided model mean at t=9",
-            "sequences_per_gpu": B, "frames": N_FRAMES, "matches_per_sequence": M, "diffusion_steps": 100,
+            "sequences_per_gpu": B, "sequences_in_flight_per_gpu": B * depth, "frames": N_FRAMES, "matches_per_sequence": M, "diffusion_steps": 100,
             "ggs_iterations_per_sequence_run": float(iters.min().item()), "hip_graph": use_graph,
             "denoiser_wgs_per_xcd": den_wgs, "pipeline_depth": depth, "ggs_slots": slots, "unguided_streams": 0 if pipe.whole_pass_streams else len(pipe.u_streams), "pass_latency_ms_unpipelined": pass_latency_ms, "ggs_workgroups_per_sequence": wgs or 24,
             "parallelism": f"dp{world} (independent sequences, one final all_gather)", "outputs_finite": finite,
         },
-        "roofline": {
-            "kernel": "pd_ggs_kernel (one launch = one guided step = 700 iterations x %d sequences)" % B,
-            "bound": "mfma", "bound_detail": "fp32 vector ALU; its peak equals the dense fp32 MFMA peak (157.3 TFLOP/s)",
-            "achieved": ggs_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ggs_tflops / FP32_PEAK_TFLOPS,
-            "traffic": ggs_traffic, "traffic_source": traffic_src, "launch_ms": ggs_ms,
-            "co_resident_launches": depth, "achieved_all_launches": ggs_set_tflops,
-            "frac_all_launches": ggs_set_tflops / FP32_PEAK_TFLOPS, "all_launches_ms": ggs_set_ms,
-            "algorithmic_flops_per_launch": ggs_flops,
-            "note": ("matches stay in registers for the whole launch" if (wgs or 24) >= 24 else
-                     "matches are re-read from L2 every iteration (more than one work item per wave)") +
-                    "; the fabric traffic is the per-iteration cross-workgroup exchange, not match streaming "
-                    "(20 B/match/iteration would be 6.4 GB per launch). `achieved` is ONE launch (64 CUs at 8 workgroups "
-                    "per sequence); `achieved_all_launches` is the set of co-resident launches of all contexts, as in the pipe",
-        },
+        "roofline": roofline,
         "roofline_denoiser": {
             "kernel": "one denoiser step = 43 launches (pd_gemm_kernel x34, pd_attn_kernel x8, pd_tail_kernel)",
             "bound": "hbm", "achieved": den_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": den_gbs / HBM_PEAK_GBS,

@@ -14,9 +14,12 @@ serialise, so at most 4 streams are used and the pipeline measures which torch s
 overlap (`pick_concurrent_streams`).  Two ways to use them:
 
 * ``unguided_streams = 0`` (default of bench.py): every stream runs whole passes (unguided half,
-  then guided half) of every 4th batch.  With 8 workgroups per sequence a guided kernel of 8
-  sequences holds 64 CUs, so even four guided halves at once are co-resident (4 x 64 = 256 CUs)
-  and the small denoiser launches of the other batches fill whatever is free.
+  then guided half) of every 4th batch.  `wgs_per_seq(B)` sizes a guided kernel to a quarter of
+  the CUs (8 workgroups per sequence for batches of 8, one for batches of 64), so even four guided
+  halves at once are co-resident (4 x 64 = 256 CUs) and the denoiser launches of the other batches
+  fill whatever is free.  Fewer workgroups per sequence cost less CU time per sequence (the serial
+  part of an iteration is replicated on every workgroup): 272 sequences/s with 4 x 8 in flight,
+  464 with 4 x 64.
 * ``unguided_streams = u > 0``: a two-stage pipeline, u streams run unguided halves back to back
   and ``ggs_slots`` streams run guided halves (submission i uses slot i % ggs_slots);
   ``ggs_slots * B * wgs_per_seq`` is sized to leave a quarter of the CUs to the unguided streams.

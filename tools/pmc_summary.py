@@ -54,14 +54,14 @@ def main():
                 den += n * v["traffic_bytes_per_dispatch_corrected"]
     out = {
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `{cmd}` "
-                  "(8 sequences, N=20, GGS on, 8 GGS workgroups per sequence as in the default 4-batch pipeline), 1x MI355X; tools/collect_pmc.sh + tools/pmc_summary.py",
+                  "(one batch of the default size, N=20, GGS on, GGS workgroups per sequence as in the default 4-batch pipeline), 1x MI355X; tools/collect_pmc.sh + tools/pmc_summary.py",
         "units": "KB per dispatch as reported by rocprofv3 (FETCH_SIZE / WRITE_SIZE); bytes = KB * 1024",
         "gfx950_correction": "MI355X_MICROARCH.md section HBM: FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) "
                              "coalesced read stream on gfx950 -> doubled in *_corrected; Infinity-Cache hits are counted "
                              "(fabric-side counter), so this is L2-miss traffic, an upper bound on HBM bytes",
         "kernels": kernels,
-        "ggs_launch_B8": {"traffic_bytes_corrected": corrected("pd_ggs_kernel")},
-        "denoiser_step_B8": {"traffic_bytes_corrected": den},
+        "ggs_launch": {"traffic_bytes_corrected": corrected("pd_ggs_kernel")},
+        "denoiser_step": {"traffic_bytes_corrected": den},
     }
     json.dump(out, sys.stdout, indent=1)
 
