@@ -375,6 +375,49 @@ def test_full_size_properties_n20_m57000(engine):
     assert 0.2 < final_loss < 0.45, final_loss
 
 
+def test_bench_default_shape_64_sequences_one_workgroup_each(seeded_diffuser, engine):
+    """bench.py's default launch shape: 64 sequences in one persistent launch, one workgroup (= one CU) per sequence, all 190
+    pairs of a sequence on that workgroup.  Every slot must equal, bit for bit, the same sequence optimised alone (B = 1) at
+    1 and at 24 workgroups, and a guided sampling pass of the 64 must equal 64 single passes."""
+    from posediffusion_amd.engine import PoseEngine
+    from posediffusion_amd.host import denoiser_state
+    dev = torch.device(DEV)
+    diff = seeded_diffuser.to(dev)
+    B, N = 64, 20
+    eng = PoseEngine(denoiser_state(diff.model), {k: v for k, v in diff.named_buffers(recurse=False)}, device=dev, max_B=B, max_N=N)
+    mds, x0s = [], []
+    for b in range(B):
+        enc = synth.make_cameras(N, seed=3000 + b)
+        md = synth.make_matches(enc, 224, 224, per_pair=40 + (b % 5) * 7, seed=3000 + b)          # ragged sizes across slots
+        eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+        mds.append(md)
+        x0s.append(synth.perturb_pose(enc, seed=50 + b))
+    x0 = torch.cat(x0s).to(dev)
+    cfg1 = make_ggs_cfg(iter_num=6, wgs_per_seq=1)
+    out64, st64, _ = eng.ggs_optimize(x0, cfg=cfg1)
+    eng.check_async()
+    assert (st64.reshape(B, -1)[:, 1] == 12).all()                      # 6 iterations x 2 runs ("all" = T alone, then all) everywhere
+    for b in (0, 17, 42, 63):
+        md = mds[b]
+        engine.set_matches(0, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+        for k in (1, 24):
+            o, _, _ = engine.ggs_optimize(x0[b:b + 1], cfg=make_ggs_cfg(iter_num=6, wgs_per_seq=k))
+            engine.check_async()
+            assert torch.equal(o[0], out64[b]), (b, k)
+    # a whole guided pass of the batch (2 guided steps): hipGraph replay equals eager launches bit for bit, (single sequences are not compared here: at 1 280 token rows the denoiser takes other GEMM
+    # tilings than at 20, and 100 free-running steps amplify that rounding, cf. test_sampler_free_running_vs_fp64_oracle)
+    z = synth.make_z(B, N, seed=9).to(dev)
+    noise = torch.randn(101, B, N, 9, generator=torch.Generator().manual_seed(3)).to(dev)
+    gcfg = make_ggs_cfg(dict(synth.GGS_CFG, iter_num=4), wgs_per_seq=1)
+    pose_g, _, st_g = eng.sample(z, noise, 2, gcfg, use_graph=True, want_process=False)
+    pose_g, st_g = pose_g.clone(), st_g.clone()
+    pose_e, _, st_e = eng.sample(z, noise, 2, gcfg, use_graph=False, want_process=False)
+    eng.check_async()
+    assert torch.equal(pose_g, pose_e) and torch.isfinite(pose_g).all()
+    assert torch.equal(st_g.nan_to_num(-1.0), st_e.nan_to_num(-1.0))      # (random poses leave too few valid matches: early exits, 0 iterations)
+    eng.close()
+
+
 def test_long_sequence_n50(engine):
     """BASELINE configs[4] shape: 50 frames, 1225 pairs, 336^2 (matches thinned to 40/pair to keep the CPU
     oracle in seconds)."""
