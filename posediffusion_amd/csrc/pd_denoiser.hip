@@ -21,6 +21,7 @@
 //     streamed straight to VGPRs (each weight byte is read by exactly one wave per M-tile);
 //   * bias / ReLU / residual are fused into the epilogue.
 #include "pd_denoiser_dev.h"
+#include "pd_gemm_stream.h"
 
 #include <algorithm>
 #include <math.h>
@@ -443,6 +444,19 @@ static int dev_pack(PdDenoiserDev *d, float **dst, const float *W, int Nout, int
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }
+// row-major copy with gamma (nullable) folded in as a column scale, for pd_gemm_stream
+static int dev_rowmajor(PdDenoiserDev *d, float **dst, const float *W, int Nout, int K, const float *gamma) {
+    if (!W) {
+        pd_set_error("pd_engine_create: a weight pointer is NULL");
+        return PD_ERR_INVALID_ARG;
+    }
+    const size_t total = (size_t)Nout * K;
+    int rc = dev_alloc(d, dst, total);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pd_scale_cols_kernel, dim3(512), dim3(256), 0, 0, W, gamma, K, total, *dst);
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}
 // b' = b + W beta
 static int dev_fold_bias(PdDenoiserDev *d, float **dst, const float *W, const float *beta, const float *b, int Nout, int K) {
     if (!W || !beta || !b) {
@@ -517,6 +531,10 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
         PD_TRY(dev_copy(d, &L.out_b, s.out_proj_b, DM));
         PD_TRY(dev_fold_bias(d, &L.ff1_b, s.linear1_w, s.norm2_b, s.linear1_b, DFF, DM));
         PD_TRY(dev_copy(d, &L.ff2_b, s.linear2_b, DM));
+        PD_TRY(dev_rowmajor(d, &L.qkv_wf, s.in_proj_w, 3 * DM, DM, s.norm1_w));
+        PD_TRY(dev_rowmajor(d, &L.out_wf, s.out_proj_w, DM, DM, nullptr));
+        PD_TRY(dev_rowmajor(d, &L.ff1_wf, s.linear1_w, DFF, DM, s.norm2_w));
+        PD_TRY(dev_rowmajor(d, &L.ff2_wf, s.linear2_w, DM, DFF, nullptr));
     }
     PD_TRY(dev_copy(d, &d->last0_b, w->last0_b, HID));
     PD_TRY(dev_copy(d, &d->last_ln_w, w->last_ln_w, HID));
@@ -531,6 +549,7 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(dev_alloc(d, &d->ctx, rows * DM));
     PD_TRY(dev_alloc(d, &d->ff, rows * DFF));
     PD_TRY(dev_alloc(d, &d->hid, rows * HID));
+    if (rows >= PD_STREAM_MIN_ROWS) PD_TRY(dev_alloc(d, &d->hn, rows * DM));
     {
         std::vector<float> sc((size_t)w->timesteps * 8, 0.0f);
         for (int t = 0; t < w->timesteps; ++t) {
@@ -604,8 +623,22 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     g.bias = d->first_b; g.C = d->h; g.Nout = DM;
     g.x = x; g.z = z; g.temb = d->t_table + (size_t)t * 128; g.n_frames = N;
     launch_gemm<KFIRST_PAD, 2, 0>(g, d->first_wp, MT, eng->gemm_wide_min_tiles, s);
+    // >= 1024 token rows (52 sequences of 20 frames): the encoder GEMMs are large enough for 64 x 64 tiles streamed through LDS
+    // (pd_gemm_stream.h; same sums in another order than the 32-row split-K tiles below, i.e. rounding-level differences
+    // between small and large batches).  LayerNorm runs as its own kernel there (affine folded into the weights, as below).
+    const bool streamed = M >= PD_STREAM_MIN_ROWS && d->hn;
     for (int l = 0; l < d->num_layers; ++l) {
         const PdLayerDev &L = d->layers[l];
+        if (streamed) {
+            hipLaunchKernelGGL((pd_ln_rows_kernel<DM, false>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f);
+            pd_gemm_stream<0>(d->hn, DM, L.qkv_wf, DM, L.qkv_b, d->qkv, M, 3 * DM, s);
+            hipLaunchKernelGGL(pd_attn_kernel, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
+            pd_gemm_stream<2>(d->ctx, DM, L.out_wf, DM, L.out_b, d->h, M, DM, s);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<DM, false>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f);
+            pd_gemm_stream<1>(d->hn, DM, L.ff1_wf, DM, L.ff1_b, d->ff, M, DFF, s);
+            pd_gemm_stream<2>(d->ff, DFF, L.ff2_wf, DFF, L.ff2_b, d->h, M, DM, s);
+            continue;
+        }
         // x += MHA(LN1(x))
         g.A = d->h; g.bias = L.qkv_b; g.C = d->qkv; g.Nout = 3 * DM;
         launch_gemm<DM, 1, 0>(g, L.qkv_wp, MT, eng->gemm_wide_min_tiles, s);

@@ -32,6 +32,7 @@ struct PdLayerDev {          // [0] = 32-wide-tile packing, [1] = 16-wide-tile p
     float *out_wp[2], *out_b;
     float *ff1_wp[2], *ff1_b;  // LayerNorm-2 folded likewise
     float *ff2_wp[2], *ff2_b;
+    float *qkv_wf, *out_wf, *ff1_wf, *ff2_wf;   // row-major copies (LayerNorm scale folded) for the streamed GEMM at >= 1024 token rows
 };
 
 struct PdDenoiserDev {
@@ -42,6 +43,7 @@ struct PdDenoiserDev {
     float *last0_wp[2] = {nullptr, nullptr}, *last0_b = nullptr, *last_ln_w = nullptr, *last_ln_b = nullptr;
     float *last3_w = nullptr, *last3_b = nullptr;   // [9,128] plain
     float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ff = nullptr, *hid = nullptr;   // activations [rows, .]
+    float *hn = nullptr;               // LayerNorm(h) without affine, streamed path only
     // per-XCD persistent kernel (pd_denoiser_xcd.hip): XCD x owns activation rows [x * cap_x, (x + 1) * cap_x)
     int cap_x = 0;
     float *sched = nullptr;            // [T,8]: c_recip, c_recipm1, coef1, coef2, sigma per step

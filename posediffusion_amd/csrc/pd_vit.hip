@@ -20,15 +20,7 @@
 #include <string.h>
 #include <vector>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// split precision (see vit_gemm_split_kernel): fp32 -> {hi bf16 | lo bf16 << 16}, v ~= hi + lo
-__device__ __forceinline__ unsigned vit_split_word(float v) {
-    const __bf16 h = (__bf16)v;
-    const __bf16 l = (__bf16)(v - (float)h);
-    return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-}
+#include "pd_gemm_stream.h"
 
 #define VD 384          // embedding dim
 #define VH 6            // heads
@@ -289,161 +281,6 @@ __global__ __launch_bounds__(256) void vit_gemm_kernel(VitGemmArgs g) {
     }
 }
 
-// ---- GEMM for many rows (M >= VIT_STREAM_MIN_ROWS) ------------------------------------------------------------------
-// LayerNorm without affine (folded into the next weight), eps 1e-6: x [M, 384] -> xn; one wave per row, 6 values per lane
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void vit_ln_kernel(const float *__restrict__ x, float *__restrict__ xn, int M) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= M) return;
-    const float *src = x + (size_t)row * VD;
-    float v[6], s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        v[i] = src[lane + 64 * i];
-        s += v[i];
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-    const float mean = s * (1.0f / VD);
-    float q = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) q += (v[i] - mean) * (v[i] - mean);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / VD) + 1e-6f);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const float o = (v[i] - mean) * rstd;
-        if constexpr (SPLIT)
-            ((unsigned *)xn)[(size_t)row * VD + lane + 64 * i] = vit_split_word(o);      // for vit_gemm_split_kernel
-        else
-            xn[(size_t)row * VD + lane + 64 * i] = o;
-    }
-}
-// W[n][k] * gamma[k] -> Wf (row-major copy with the LayerNorm scale folded in)
-__global__ void vit_scale_cols_kernel(const float *__restrict__ W, const float *__restrict__ gamma, int K, size_t total, float *__restrict__ Wf) {
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
-        Wf[idx] = gamma ? W[idx] * gamma[idx % K] : W[idx];
-}
-
-//   C[m, n] = epi( sum_k A[m, k] W[n, k] + bias[n] ): a (64 WM) x (64 WN) tile per workgroup, one (32 WM) x (32 WN) quadrant
-//   per wave over the whole K; A and W (both row-major, k contiguous) stream through LDS in 32-deep chunks, double buffered
-//   with a register stage.  Blocks walk groups of ~2048 rows x all column tiles, so that a group's A rows and the whole W
-//   stay in the L2s.  EPI as above (0, 2, 3).
-struct VitStreamArgs {
-    const float *A, *W, *bias;
-    float *C;
-    int M, Nout, K, lda, ldw;
-};
-#define VIT_STREAM_KC 32
-#define VIT_STREAM_LR (VIT_STREAM_KC + 4)      // LDS row stride: fragment reads and staging writes both conflict free
-// staging registers are named scalars (arrays of float4 held across the K loop end up in scratch)
-#define VS_EACH(X) X(0) X(1) X(2) X(3)
-
-template <int EPI, int WM, int WN>
-__global__ __launch_bounds__(256) void vit_gemm_stream_kernel(VitStreamArgs g) {
-    constexpr int KC = VIT_STREAM_KC, LR = VIT_STREAM_LR, TM = 64 * WM, TN = 64 * WN, PA = 2 * WM, PW = 2 * WN, GROUP = 2048 / TM;
-    static_assert(KC == 32 && PA <= 4 && PW <= 4, "staging: 8 float4 per row, passes of 32 rows");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *As = lds, *Ws = lds + 2 * TM * LR;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5, wm = wave & 1, wn = wave >> 1;
-    const int MT = (g.M + TM - 1) / TM, NT = g.Nout / TN;
-    int mtile, ntile;
-    {
-        const int b = blockIdx.x, full = (MT / GROUP) * GROUP * NT;
-        if (b < full) {
-            const int grp = b / (NT * GROUP), r = b - grp * (NT * GROUP);
-            ntile = r / GROUP;
-            mtile = grp * GROUP + r % GROUP;
-        } else {
-            const int r = b - full, rest = MT % GROUP;
-            ntile = r / rest;
-            mtile = (MT / GROUP) * GROUP + r % rest;
-        }
-    }
-    const int m0 = mtile * TM, n0 = ntile * TN;
-    const int sr = tid >> 3, sc = tid & 7, st = sr * LR + 4 * sc;
-#define VS_DECL(j)                                                                                                        \
-    const float4 *ap##j = (const float4 *)(g.A + (size_t)min(m0 + sr + 32 * (j < PA ? j : 0), g.M - 1) * g.lda) + sc;       \
-    const float4 *wp##j = (const float4 *)(g.W + (size_t)(n0 + sr + 32 * (j < PW ? j : 0)) * g.ldw) + sc;                   \
-    float4 ra##j, rw##j;
-#define VS_LOAD(j)                       \
-    if constexpr (j < PA) ra##j = ap##j[nx]; \
-    if constexpr (j < PW) rw##j = wp##j[nx];
-#define VS_STORE(j)                                                    \
-    if constexpr (j < PA) *(float4 *)(da + st + j * 32 * LR) = ra##j; \
-    if constexpr (j < PW) *(float4 *)(dw + st + j * 32 * LR) = rw##j;
-    VS_EACH(VS_DECL)
-    {
-        const int nx = 0;
-        float *da = As, *dw = Ws;
-        VS_EACH(VS_LOAD)
-        VS_EACH(VS_STORE)
-    }
-    __syncthreads();
-    f32x16 acc[WM][WN];
-#pragma unroll
-    for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < WN; ++ni)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.0f;
-    const int nk = g.K / KC;
-    const int aoff = (wm * 32 * WM + l31) * LR + 4 * hi, boff = (wn * 32 * WN + l31) * LR + 4 * hi;
-    for (int kc = 0; kc < nk; ++kc) {
-        // the chunk after the last is the last again: loads and LDS writes stay unconditional (straight-line loop body)
-        const int nx = min(kc + 1, nk - 1) * (KC / 4);
-        VS_EACH(VS_LOAD)
-        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the matrix work
-        const float *a = As + (kc & 1) * TM * LR + aoff, *b = Ws + (kc & 1) * TN * LR + boff;
-#pragma unroll
-        for (int kk = 0; kk < KC / 8; ++kk) {
-            float4 af[WM], bf[WN];
-#pragma unroll
-            for (int mi = 0; mi < WM; ++mi) af[mi] = *(const float4 *)(a + mi * 32 * LR + kk * 8);
-#pragma unroll
-            for (int ni = 0; ni < WN; ++ni) bf[ni] = *(const float4 *)(b + ni * 32 * LR + kk * 8);
-#pragma unroll
-            for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < WN; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
-                }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        float *da = As + ((kc + 1) & 1) * TM * LR, *dw = Ws + ((kc + 1) & 1) * TN * LR;
-        VS_EACH(VS_STORE)
-        __syncthreads();
-    }
-#undef VS_DECL
-#undef VS_LOAD
-#undef VS_STORE
-#pragma unroll
-    for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < WN; ++ni) {
-            const int col = n0 + (wn * WN + ni) * 32 + l31, r0 = m0 + (wm * WM + mi) * 32 + 4 * hi;
-            const float bias = g.bias[col];
-            float res[16];
-            if constexpr (EPI == 2) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)      // all residual loads in flight at once (rows past M re-read the last row)
-                    res[i] = g.C[(size_t)min(r0 + (i & 3) + 8 * (i >> 2), g.M - 1) * g.Nout + col];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = r0 + (i & 3) + 8 * (i >> 2);
-                float v = acc[mi][ni][i] + bias;
-                if constexpr (EPI == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                if constexpr (EPI == 2) v += res[i];
-                if (row < g.M) g.C[(size_t)row * g.Nout + col] = v;
-            }
-        }
-}
-
 // ---- the same GEMM in split precision: x ~= hi + lo (two bf16), x.w ~= hi.hi + hi.lo + lo.hi on the bf16 matrix instruction ----
 // (16 x the rate of the f32 instruction per product, three products; fp32 accumulation).  Measured deviation of the CLS
 // features from the fp32 network: 8e-6 .. 1e-5 of max|z| (oracle-side simulation and GPU tests), a tenth of the 1e-4 contract.
@@ -487,7 +324,7 @@ __global__ void vit_frag_split_kernel(const float *__restrict__ W, const float *
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float v = W[(size_t)n * K + k0 + e];
-            w[e] = vit_split_word(gamma ? v * gamma[k0 + e] : v);
+            w[e] = pd_split_word(gamma ? v * gamma[k0 + e] : v);
         }
         uint4 hi, lo;
         hi.x = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u); lo.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
@@ -511,7 +348,7 @@ struct VitSplitArgs {
 // keeping them out of LDS halves its traffic -- the LDS array, not the matrix pipe, limited the first version).
 template <int EPI, int WM, int WN>
 __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
-    constexpr int KC = VIT_STREAM_KC, LR = VIT_STREAM_LR, TM = 64 * WM, TN = 64 * WN, GROUP = 2048 / TM;
+    constexpr int KC = PD_STREAM_KC, LR = PD_STREAM_LR, TM = 64 * WM, TN = 64 * WN, GROUP = 2048 / TM;
     static_assert(KC == 32 && WM <= 2 && WN <= 2, "staging: 4 groups of 8 per row chunk, passes of 64 rows");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned *As = (unsigned *)lds;
@@ -645,7 +482,7 @@ __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
                 if constexpr (EPI == 2) v += res[i];
                 if (row < g.M) {
                     if constexpr (EPI == 3)
-                        ((unsigned *)g.C)[(size_t)row * g.Nout + col] = vit_split_word(v);
+                        ((unsigned *)g.C)[(size_t)row * g.Nout + col] = pd_split_word(v);
                     else
                         ((float *)g.C)[(size_t)row * g.Nout + col] = v;
                 }
@@ -842,14 +679,14 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const float *__restrict__
                 const float v = o[i] + red[(nt * 16 + i) * 64 + lane];
                 float *dst = ctx + ((size_t)im * T + qr) * VD + h * VDH + nt * 32 + l31;
                 if constexpr (SPLIT)
-                    *(unsigned *)dst = vit_split_word(v);       // feeds vit_gemm_split_kernel
+                    *(unsigned *)dst = pd_split_word(v);       // feeds vit_gemm_split_kernel
                 else
                     *dst = v;
             }
         }
     }
 }
-static constexpr size_t vit_split_lds(int WM) { return (size_t)2 * 64 * WM * VIT_STREAM_LR * sizeof(float); }
+static constexpr size_t vit_split_lds(int WM) { return (size_t)2 * 64 * WM * PD_STREAM_LR * sizeof(float); }
 static size_t vit_attn_lds(int T) {
     const size_t s = (size_t)32 * (((T + 31) / 32) * 32 + 4);
     return (s > 2048 ? s : 2048) * sizeof(float);
@@ -901,7 +738,7 @@ static int vit_fold(pd_vit *v, float **dst, const float *W, const float *beta, c
 static int vit_rowmajor(pd_vit *v, float **dst, const float *W, int Nout, int K, const float *gamma) {
     const size_t total = (size_t)Nout * K;
     VIT_TRY(vit_alloc(v, dst, total));
-    hipLaunchKernelGGL(vit_scale_cols_kernel, dim3(512), dim3(256), 0, 0, W, gamma, K, total, *dst);
+    hipLaunchKernelGGL(pd_scale_cols_kernel, dim3(512), dim3(256), 0, 0, W, gamma, K, total, *dst);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }
@@ -1031,16 +868,6 @@ static void vit_gemm(const VitGemmArgs &g, hipStream_t s) {
     hipLaunchKernelGGL((vit_gemm_kernel<K, AMODE, EPI>), dim3(MT * (g.Nout / 32)), dim3(256), 32 * (K + 4) * 4, s, g);
 }
 
-#define VIT_STREAM_MIN_ROWS 1024
-// 64 x 64 tiles: 128 x 64 and 128 x 128 (WM / WN = 2) measured no faster at 31 520 rows and slower at 3 940
-// (profiles/round1_j_vit_notes.md), so only <EPI, 1, 1> is instantiated
-template <int EPI>
-static void vit_gemm_stream(const float *A, int lda, const float *W, int K, const float *bias, float *C, int M, int Nout, hipStream_t s) {
-    VitStreamArgs g{A, W, bias, C, M, Nout, K, lda, K};
-    const size_t lds = (size_t)2 * 128 * VIT_STREAM_LR * sizeof(float);
-    hipLaunchKernelGGL((vit_gemm_stream_kernel<EPI, 1, 1>), dim3(((M + 63) / 64) * (Nout / 64)), dim3(256), lds, s, g);
-}
-
 // split precision: 128 x 128 tiles where the column count gives enough of them, 128 x 64 for the 384-wide outputs
 template <int EPI, int WM, int WN>
 static void vit_gemm_split(const unsigned *A, int lda, const unsigned *W, int K, const float *bias, void *C, int M, int Nout, hipStream_t s) {
@@ -1097,29 +924,29 @@ extern "C" int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, i
     g.M = (int)tokens;
     const size_t attn_lds = vit_attn_lds(T);
     const int nqb = (T + 31) / 32;
-    const bool streamed = (int)tokens >= VIT_STREAM_MIN_ROWS;
+    const bool streamed = (int)tokens >= PD_STREAM_MIN_ROWS;
     for (int l = 0; l < v->depth; ++l) {
         const pd_vit::Layer &L = v->L[l];
         if (streamed && !v->exact_fp32) {
             const int M = (int)tokens;
-            hipLaunchKernelGGL(vit_ln_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, true>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f);
             vit_gemm_split<0, 2, 2>((const unsigned *)v->xn, VD, L.qkv_ws, VD, L.qkv_b, v->qkv, M, 3 * VD, s);
             hipLaunchKernelGGL(vit_attn_kernel<true>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
             vit_gemm_split<2, 2, 1>((const unsigned *)v->ctx, VD, L.proj_ws, VD, L.proj_b, v->x, M, VD, s);
-            hipLaunchKernelGGL(vit_ln_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, true>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f);
             vit_gemm_split<3, 2, 2>((const unsigned *)v->xn, VD, L.fc1_ws, VD, L.fc1_b, v->hid, M, VFF, s);
             vit_gemm_split<2, 2, 1>((const unsigned *)v->hid, VFF, L.fc2_ws, VFF, L.fc2_b, v->x, M, VD, s);
             continue;
         }
         if (streamed) {
             const int M = (int)tokens;
-            hipLaunchKernelGGL(vit_ln_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M);
-            vit_gemm_stream<0>(v->xn, VD, L.qkv_wf, VD, L.qkv_b, v->qkv, M, 3 * VD, s);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, false>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f);
+            pd_gemm_stream<0>(v->xn, VD, L.qkv_wf, VD, L.qkv_b, v->qkv, M, 3 * VD, s);
             hipLaunchKernelGGL(vit_attn_kernel<false>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
-            vit_gemm_stream<2>(v->ctx, VD, L.proj_wf, VD, L.proj_b, v->x, M, VD, s);
-            hipLaunchKernelGGL(vit_ln_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M);
-            vit_gemm_stream<3>(v->xn, VD, L.fc1_wf, VD, L.fc1_b, v->hid, M, VFF, s);
-            vit_gemm_stream<2>(v->hid, VFF, L.fc2_wf, VFF, L.fc2_b, v->x, M, VD, s);
+            pd_gemm_stream<2>(v->ctx, VD, L.proj_wf, VD, L.proj_b, v->x, M, VD, s);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, false>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f);
+            pd_gemm_stream<3>(v->xn, VD, L.fc1_wf, VD, L.fc1_b, v->hid, M, VFF, s);
+            pd_gemm_stream<2>(v->hid, VFF, L.fc2_wf, VFF, L.fc2_b, v->x, M, VD, s);
             continue;
         }
         g.A = v->x; g.lda = VD; g.Wp = L.qkv_wp; g.bias = L.qkv_b; g.C = v->qkv; g.Nout = 3 * VD;
