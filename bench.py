@@ -9,7 +9,7 @@ Workload (config.workload): BASELINE.json configs[3], "batch of 64 independent 2
   (224^2, 190 pairs x 300 matches each), the whole batch on ONE GPU ("also run 64 on 1/2/4 GPUs"); weak
   scaling: every GPU runs its own 64-sequence batches (total = 64 x n_gpus per step).  Four batches are in flight per
   GPU (posediffusion_amd/pipeline.py), i.e. 256 sequences, one GGS workgroup = one CU per sequence; throughput
-  against the number in flight is in DESIGN.md section 5 (`--seqs-per-gpu 8`: 273 sequences/s at 73 ms latency).
+  against the number in flight is in DESIGN.md section 5 (`--seqs-per-gpu 8`: 272 sequences/s at 73 ms latency).
   Inputs are resident in HBM before the timed region.
 
 Launch: `python bench.py --gpus N --steps K --warmup W`; for N > 1 under torch.distributed.run
@@ -43,6 +43,8 @@ SEQS_PER_GPU = 64                    # BASELINE configs[3]: one batch of 64 inde
 COND_START = 10                      # cfgs/default.yaml:8
 FLOP_PER_MATCH_ITER = 100.0          # 36 fwd + 64 bwd
 DENOISER_PARAMS = 17_298_697         # fp32 -> 69.19 MB read per denoiser step
+DENOISER_MFLOP_PER_TOKEN = 34.73     # SURVEY.md section 8(d), N = 20
+PD_STREAM_MIN_ROWS = 1024            # csrc/pd_gemm_stream.h
 FP32_PEAK_TFLOPS = 157.3             # MI355X fp32 vector ALU = dense fp32 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 MATCH_BYTES = 16                     # kp1, kp2: 2 x float2 per match (pair indices are per work item)
@@ -326,6 +328,14 @@ def main():
     ggs_set_ms = max(evs[0][0].elapsed_time(e1) for _, e1 in evs)
     ggs_set_tflops = depth * ggs_flops / (ggs_set_ms * 1e-3) / 1e12
     den_gbs = DENOISER_PARAMS * 4 / (den_ms * 1e-3) / 1e9
+    # the weight stream (69 MB per step, HBM) bounds the denoiser up to ~50 tokens, the exact-fp32 matrix pipe above
+    tokens = B * N_FRAMES
+    den_flops = tokens * DENOISER_MFLOP_PER_TOKEN * 1e6
+    den_tflops = den_flops / (den_ms * 1e-3) / 1e12
+    if tokens >= PD_STREAM_MIN_ROWS:
+        den_kernels = "one denoiser step = 59 launches (pd_gemm_stream_kernel x32, pd_ln_rows_kernel x16, pd_gemm_kernel x2, pd_attn_kernel x8, pd_tail_kernel)"
+    else:
+        den_kernels = "one denoiser step = 43 launches (pd_gemm_kernel x34, pd_attn_kernel x8, pd_tail_kernel)"
 
     ggs_traffic, den_traffic, traffic_src = pmc_traffic() if B == SEQS_PER_GPU else (None, None, None)
     # Which roof: with few sequences in flight the matches of a sequence stay in registers (24 workgroups per sequence) or in
@@ -361,6 +371,15 @@ def main():
                                   "; the fabric traffic is the per-iteration cross-workgroup exchange, not match streaming. "
                                   "`achieved` is ONE launch; `achieved_all_launches` is the set of co-resident launches of all "
                                   "contexts, as in the pipe"))
+    if tokens > 50:
+        roofline_den = {"kernel": den_kernels, "bound": "mfma", "bound_detail": "exact-fp32 matrix instruction (157.3 TFLOP/s)",
+                        "achieved": den_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": den_tflops / FP32_PEAK_TFLOPS,
+                        "traffic": den_traffic, "step_us": den_ms * 1e3, "algorithmic_flops_per_step": den_flops,
+                        "weights_GBps": den_gbs, "note": f"{tokens} token rows per step; one context alone (the pipe overlaps four)"}
+    else:
+        roofline_den = {"kernel": den_kernels, "bound": "hbm", "achieved": den_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": den_gbs / HBM_PEAK_GBS, "traffic": den_traffic, "step_us": den_ms * 1e3,
+                        "algorithmic_bytes_per_step": DENOISER_PARAMS * 4}
     out = {
         "metric": "sequences/sec (20-frame, GGS on)", "value": value, "unit": "sequences/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -377,11 +396,7 @@ def main():
             "parallelism": f"dp{world} (independent sequences, one final all_gather)", "outputs_finite": finite,
         },
         "roofline": roofline,
-        "roofline_denoiser": {
-            "kernel": "one denoiser step = 43 launches (pd_gemm_kernel x34, pd_attn_kernel x8, pd_tail_kernel)",
-            "bound": "hbm", "achieved": den_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": den_gbs / HBM_PEAK_GBS,
-            "traffic": den_traffic, "step_us": den_ms * 1e3, "algorithmic_bytes_per_step": DENOISER_PARAMS * 4,
-        },
+        "roofline_denoiser": roofline_den,
         "per_step_ms": {"denoiser_step": den_ms, "ggs_guided_step": ggs_ms, "ggs_iteration_us": ggs_ms * 1e3 / (7 * cfg.iter_num)},
     }
     if feat is not None:

@@ -19,7 +19,7 @@ overlap (`pick_concurrent_streams`).  Two ways to use them:
   halves at once are co-resident (4 x 64 = 256 CUs) and the denoiser launches of the other batches
   fill whatever is free.  Fewer workgroups per sequence cost less CU time per sequence (the serial
   part of an iteration is replicated on every workgroup): 272 sequences/s with 4 x 8 in flight,
-  464 with 4 x 64.
+  about 500 with 4 x 64.
 * ``unguided_streams = u > 0``: a two-stage pipeline, u streams run unguided halves back to back
   and ``ggs_slots`` streams run guided halves (submission i uses slot i % ggs_slots);
   ``ggs_slots * B * wgs_per_seq`` is sized to leave a quarter of the CUs to the unguided streams.

@@ -43,10 +43,13 @@ def main():
     def corrected(prefix):
         return sum(v["traffic_bytes_per_dispatch_corrected"] for k, v in kernels.items() if k.startswith(prefix))
 
-    # one denoiser step = 34 GEMM launches of 7 kinds + 8 attention + 1 tail; weight per kind by its launches per step
+    # one denoiser step = 34 GEMM launches of 7 kinds + 8 attention + 1 tail (+ 16 LayerNorm launches on the streamed path);
+    # weight per kind by its launches per step (kinds that did not run in the profiled process contribute nothing)
     per_step = {"pd_gemm_kernel<704": 1, "pd_gemm_kernel<512, 1, 0": 8, "pd_gemm_kernel<512, 0, 2": 8,
                 "pd_gemm_kernel<512, 1, 1": 8, "pd_gemm_kernel<1024, 0, 2": 8, "pd_gemm_kernel<512, 0, 0": 1,
-                "pd_attn_kernel": 8, "pd_tail_kernel": 1}
+                "pd_attn_kernel": 8, "pd_tail_kernel": 1,
+                # >= 1024 token rows: the encoder GEMMs of a layer run on the streamed kernel (pd_gemm_stream.h) instead
+                "pd_gemm_stream_kernel<0": 8, "pd_gemm_stream_kernel<2": 16, "pd_gemm_stream_kernel<1": 8, "pd_ln_rows_kernel<512": 16}
     den = 0.0
     for k, v in kernels.items():
         for pre, n in per_step.items():
