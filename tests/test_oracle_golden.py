@@ -56,8 +56,10 @@ def test_sampson_value_and_gradient_golden(golden, fname, smax):
     (grad,) = torch.autograd.grad(v.mean(), x)
     tag = f"sam_{fname}_max{smax}"
     assert len(v) == int(g[tag + "_nvalid"])
-    assert abs(v.mean().item() - float(g[tag + "_loss"])) < 2e-6 * abs(float(g[tag + "_loss"]))
-    assert abs(pr.item() - float(g[tag + "_print"])) < 2e-6 * abs(float(g[tag + "_print"]))
+    # fp32 means over the valid matches: the summation order depends on the host (vector width, thread partition); the fixture
+    # was written on another CPU than the GPU box's (3.5e-6 apart there at sampson_max = 0.3, where few matches survive)
+    assert abs(v.mean().item() - float(g[tag + "_loss"])) < 2e-5 * abs(float(g[tag + "_loss"]))
+    assert abs(pr.item() - float(g[tag + "_print"])) < 2e-5 * abs(float(g[tag + "_print"]))
     assert rel_err(grad, g[tag + "_grad"]) < 2e-5
 
 
