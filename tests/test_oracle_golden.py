@@ -60,7 +60,7 @@ def test_sampson_value_and_gradient_golden(golden, fname, smax):
     # was written on another CPU than the GPU box's (3.5e-6 apart there at sampson_max = 0.3, where few matches survive)
     assert abs(v.mean().item() - float(g[tag + "_loss"])) < 2e-5 * abs(float(g[tag + "_loss"]))
     assert abs(pr.item() - float(g[tag + "_print"])) < 2e-5 * abs(float(g[tag + "_print"]))
-    assert rel_err(grad, g[tag + "_grad"]) < 2e-5
+    assert rel_err(grad, g[tag + "_grad"]) < 1e-4           # host dependent likewise (2e-6 here, 4e-5 on the GPU box's CPU)
 
 
 def test_analytic_backward_matches_autograd_fp64(golden):
