@@ -1,5 +1,5 @@
 """Timings of the small stateless kernels of SURVEY 8f rows N3 (evaluation metrics) and N4 (image preprocessing), with the
-CPU restatement (oracle, torch / numpy) timed beside them.  usage: python tools/aux_bench.py  -> one JSON line"""
+CPU restatement (oracle, torch / numpy) timed beside them.  usage: python tests/perf/aux_bench.py  -> one JSON line"""
 import json
 import os
 import sys
@@ -9,7 +9,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import pd_oracle as O                          # CPU baseline only
 from posediffusion_amd import _lib, synth
 

@@ -147,7 +147,7 @@ def test_product_never_touches_the_oracle():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pat = re.compile(r"^\s*(from|import)\s+oracle\b|importlib\.import_module\(\s*[\"']oracle", re.M)
     offenders = []
-    for base, _, files in os.walk(os.path.join(root, "posediffusion_amd")):
+    for base, _, files in list(os.walk(os.path.join(root, "posediffusion_amd"))) + list(os.walk(os.path.join(root, "tools"))):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(base, f), errors="replace").read()

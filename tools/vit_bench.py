@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import vit_oracle as VO                       # weights only (random-init ViT-S/16); nothing is computed with it
+from posediffusion_amd import synth
 from posediffusion_amd.vit import VitEngine, vit_state
 
 
@@ -24,7 +24,9 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     size = int(sys.argv[3]) if len(sys.argv) > 3 else 224
     dev = torch.device("cuda:0")
-    eng = VitEngine(vit_state(VO.make_vit(0)), dev)
+    torch.manual_seed(0)
+    ext = synth._dropin().MultiScaleImageFeatureExtractor()          # random-init DINO-shaped parameters
+    eng = VitEngine(vit_state(ext._net), dev)
     x = torch.rand(n, 3, size, size, device=dev)
     scales = (1, 1 / 2, 1 / 3)
     out = {}
