@@ -256,8 +256,76 @@ def make_preprocess():
     print("preprocess.npz", os.path.getsize(os.path.join(OUT, "preprocess.npz")))
 
 
+def make_guided_free(seeds=(0, 1, 2), N=8, cond_start=3, per_pair=60):
+    """tests/golden/guided_free.npz -- SURVEY.md section 8c's FREE-RUNNING GGS-on criterion, scaled down from BASELINE
+    configs[2]: N = 8 frames, 28 pairs x 60 matches, 100 DDPM steps, the last `cond_start` = 3 of them guided with the
+    FULL default schedule (5 optimisations = 700 iterations per guided step, cfgs/default.yaml:6-13).  Per seed:
+      * the UNMODIFIED reference (models/gaussian_diffuser.py sample() + util/geometry_guided_sampling.py, fp32, CPU);
+      * the fp64 oracle on the same z / noise / matches;
+    and each one's final mean Sampson error over its valid matches (evaluated in fp64 at the final pose).
+    With random-init weights the sampled poses are arbitrary, so -- as bench.py does -- the matches are synthesised
+    to be epipolar-consistent (+0.5 px noise, 10 % outliers) with the fp32 model mean at the first guided step, which
+    puts the guided steps in the basin the trained model + SuperGlue matches would give (all 2 100 iterations run)."""
+    torch.set_num_threads(1)
+    ref = RS.load_reference()
+    diff = RS.build_reference_diffuser(seed=0)
+    synth.randomize_norm_and_bias_(diff.model)
+    sd = diff.model.state_dict()
+    sd32, sd64 = O.cast_state_dict(sd, torch.float32), O.cast_state_dict(sd, torch.float64)
+    t32, t64 = O.diffusion_tables(), O.diffusion_tables(dtype=torch.float64)
+    cfg = dict(GGS_CFG)                                      # iter_num 100 -> 200/100/100/100/200
+    out = {"seeds": np.array(seeds), "cond_start_step": cond_start, "weight_checksum": weight_checksum(sd)}
+    T = 100
+    for s in seeds:
+        z = synth.make_z(1, N, seed=1000 + s)
+        init, noises = O.draw_reference_noise((1, N, 9), torch.Generator().manual_seed(s), cond_start_step=cond_start, has_cond=True)
+        # the model mean GGS first sees (t = cond_start - 1), from the fp32 restatement of the unguided prefix
+        with torch.no_grad():
+            x = init
+            for t in reversed(range(cond_start, T)):
+                x, _ = O.p_sample(sd32, t32, x, t, z, noises[t])
+            mean = O.p_mean_variance(sd32, t32, x, cond_start - 1, z)[0]
+        md = synth.make_epipolar_matches(mean[0].numpy().astype(np.float64), 224, 224, per_pair, seed=2000 + s)
+        pm = O.prepare_matches(md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+        # (a) the reference itself, fp32
+        buf = io.StringIO()
+        torch.manual_seed(s)
+        with torch.no_grad(), contextlib.redirect_stdout(buf):
+            pose32, process32 = diff.sample([1, N, 9], z, cond_fn=partial(ref.geometry_guided_sampling, matches_dict=md, GGS_cfg=cfg),
+                                            cond_start_step=cond_start)
+        assert torch.equal(process32[0], init), "RNG replay does not match the reference's draw order"
+        n_it = buf.getvalue().count("sampson=")                 # one print per GGS_optimize call (:124)
+        assert "Drop this pair" not in buf.getvalue(), "an optimisation exited early: the fixture must run every iteration"
+        # (b) the fp64 oracle
+        with torch.no_grad():
+            pass
+        cond64 = lambda m, t: O.geometry_guided_sampling(m, t, md, cfg)       # noqa: E731
+        pose64, process64 = O.p_sample_loop(sd64, t64, z.double(), init.double(), [None if n is None else n.double() for n in noises],
+                                            cond_fn=cond64, cond_start_step=cond_start)
+        sam = {}
+        for name, pose in (("32", pose32), ("64", pose64)):
+            v, _ = O.compute_sampson_distance(pose.detach().double(), pm)
+            sam[name] = (float(v.mean()), len(v))
+        noise = np.zeros((T + 1, 1, N, 9), dtype=np.float32)
+        noise[0] = init.numpy()
+        for step in range(T):
+            if noises[T - 1 - step] is not None:
+                noise[step + 1] = noises[T - 1 - step].numpy()
+        dev = float(((pose32.double() - pose64).abs().max() / pose64.abs().max()))
+        print(f"seed {s}: reference ran {n_it} GGS_optimize calls to completion; |pose| max {float(pose64.abs().max()):.2f}; ref32 vs fp64 {dev:.3e}; "
+              f"final mean Sampson ref32 {sam['32'][0]:.6f} ({sam['32'][1]} valid), fp64 {sam['64'][0]:.6f} ({sam['64'][1]} valid)")
+        out.update({f"s{s}_z": z.numpy(), f"s{s}_noise": noise, f"s{s}_kp1": md["kp1"], f"s{s}_kp2": md["kp2"], f"s{s}_i12": md["i12"],
+                    f"s{s}_pose32": pose32.numpy(), f"s{s}_pose64": pose64.detach().numpy(), f"s{s}_mean_at_first_guided": mean.numpy(),
+                    f"s{s}_sampson32": np.array(sam["32"]), f"s{s}_sampson64": np.array(sam["64"]), f"s{s}_ref_optimize_calls": n_it})
+    out["img_shape"] = np.array([N, 3, 224, 224])
+    np.savez_compressed(os.path.join(OUT, "guided_free.npz"), **out)
+    print("guided_free.npz", os.path.getsize(os.path.join(OUT, "guided_free.npz")))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "metrics":
+    if len(sys.argv) > 1 and sys.argv[1] == "guided_free":
+        make_guided_free()      # only the free-running GGS-on fixture
+    elif len(sys.argv) > 1 and sys.argv[1] == "metrics":
         make_metrics()          # only the N3 fixture (the others stay byte-identical)
     elif len(sys.argv) > 1 and sys.argv[1] == "preprocess":
         make_preprocess()       # only the N4 fixture
@@ -265,3 +333,4 @@ if __name__ == "__main__":
         main()
         make_metrics()
         make_preprocess()
+        make_guided_free()

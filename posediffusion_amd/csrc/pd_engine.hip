@@ -331,11 +331,20 @@ extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *nois
         key.has_ggs = has_ggs;
         key.phase = phase;
         key.den_wgs = eng->den_wgs_per_xcd;
-        if (has_ggs) key.cfg = *ggs;
+        if (has_ggs) {
+            key.cfg = *ggs;
+            // the GGS nodes bake the match-derived launch shape in: a re-upload with another item count must not
+            // replay them (and a replay must not skip pd_ggs_launch's state / frame-count checks)
+            if (phase != PD_PHASE_UNGUIDED) {
+                int rc = pd_ggs_plan(eng, B, N, ggs, &key.plan);
+                if (rc) return rc;
+            }
+        }
         hipGraphExec_t exec = nullptr;
         for (auto &g : eng->graphs)
             if (g.first.B == B && g.first.N == N && g.first.cond_start == key.cond_start && g.first.has_ggs == key.has_ggs &&
-                g.first.phase == phase && g.first.den_wgs == key.den_wgs && same_cfg(g.first.cfg, key.cfg))
+                g.first.phase == phase && g.first.den_wgs == key.den_wgs && same_cfg(g.first.cfg, key.cfg) &&
+                memcmp(&g.first.plan, &key.plan, sizeof(PdGgsPlan)) == 0)
                 exec = g.second;
         if (!exec) {
             // capture on a private stream so the caller's stream state is untouched

@@ -58,8 +58,10 @@ __device__ __forceinline__ float wave_allsum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// 1-ulp hardware reciprocal / sqrt for scale factors on the serial per-iteration chain (the Sampson
-// value itself keeps IEEE division: it is compared against the hard sampson_max threshold)
+// 1-ulp hardware reciprocal / sqrt for scale factors on the serial per-iteration chain and for the gradient scales
+// of the match pass.  The hard `sampson < sampson_max` test (geometry_guided_sampling.py:170) is decided on the IEEE
+// quotient top / bottom like torch's: see sampson_step2 (fast pass + exact re-run of an item that has a match inside
+// the band where the 1-ulp quotient could decide differently).
 __device__ __forceinline__ float pd_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float pd_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
@@ -155,9 +157,18 @@ __device__ __forceinline__ v2f pd_fma2(v2f a, v2f b, v2f c) { return __builtin_e
 __device__ __forceinline__ v2f pd_splat(float a) { return (v2f){a, a}; }
 
 // Sampson residual + dL/dF of two matches (geometry_guided_sampling.py:157-170); acc[0..8] dL/dF sums,
-// acc[9] sum(s valid), acc[10] n_valid, acc[11] sum(min(s, max)), each as {match A, match B} partial sums
+// acc[9] sum(s valid), acc[10] n_valid, acc[11] sum(min(s, max)), each as {match A, match B} partial sums.
+//
+// Threshold rule (:170 `sampson < sampson_max` on torch's IEEE quotient top / bottom): EXACT = false computes the
+// quotient as top * v_rcp_f32(bottom) (within 2 ulp of the IEEE quotient) and records in `mind` how close any in-range
+// match came to the threshold; the caller re-runs the whole item with EXACT = true (IEEE divide for the quotient that
+// is compared, clamped and summed) when some match of the wave lies within PD_SAMPSON_BAND_ULPS of sampson_max --
+// outside that band both quotients decide alike, so the valid set is always the one the IEEE quotient gives.  The
+// gradient scales 1/bottom keep the 1-ulp reciprocal in both variants (no threshold hangs on them).
+#define PD_SAMPSON_BAND_ULPS 16.0f
+template <bool EXACT>
 __device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, bool ina, bool inb, const float *F, float smax,
-                                              v2f (&acc)[PD_ITEM_VALS]) {
+                                              v2f (&acc)[PD_ITEM_VALS], float &mind) {
     const v2f u1 = {pa.x, pb.x}, v1 = {pa.y, pb.y}, u2 = {pa.z, pb.z}, v2 = {pa.w, pb.w};
     // left = x1^T F, right = F x2   (:158-159)
     const v2f l0 = pd_fma2(u1, pd_splat(F[0]), pd_fma2(v1, pd_splat(F[3]), pd_splat(F[6])));
@@ -167,10 +178,17 @@ __device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, 
     const v2f r1 = pd_fma2(pd_splat(F[3]), u2, pd_fma2(pd_splat(F[4]), v2, pd_splat(F[5])));
     const v2f ee = pd_fma2(l0, u2, pd_fma2(l1, v2, l2));
     const v2f bottom = l0 * l0 + l1 * l1 + r0 * r0 + r1 * r1;          // :161
-    // 1-ulp reciprocal instead of an IEEE divide: F itself already differs from the reference's by fp32
-    // rounding order, so the threshold test is equally (in)exact
     const v2f inv = {pd_rcp(bottom.x), pd_rcp(bottom.y)};
-    const v2f sam = (ee * ee) * inv;                                    // :162-164
+    const v2f top = ee * ee;
+    v2f sam;                                                            // :162-164
+    if (EXACT) {
+        sam = (v2f){top.x / bottom.x, top.y / bottom.y};                // IEEE, as torch divides
+    } else {
+        sam = top * inv;
+        const v2f d = sam - pd_splat(smax);
+        // lanes past the item's end carry a clamped copy of its last match: harmless (same decision as that match)
+        mind = fminf(mind, fminf(fabsf(d.x), fabsf(d.y)));              // one v_min3_f32 with |.| modifiers
+    }
     const v2f clamped = __builtin_elementwise_min(sam, pd_splat(smax));
     acc[11] += (v2f){ina ? clamped.x : 0.0f, inb ? clamped.y : 0.0f};   // :169
     const bool va = ina && (sam.x < smax), vb = inb && (sam.y < smax);   // :170 (false for NaN)
@@ -178,7 +196,7 @@ __device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, 
     // so invalid / out-of-range matches contribute exact zeros without further masking
     const v2f inv_v = {va ? inv.x : 0.0f, vb ? inv.y : 0.0f};
     const v2f ca = (ee + ee) * inv_v;                 // 2 ee / bottom
-    const v2f sam_v = (ee * ee) * inv_v;              // = sam where valid, else 0
+    const v2f sam_v = EXACT ? (v2f){va ? sam.x : 0.0f, vb ? sam.y : 0.0f} : top * inv_v;   // = sam where valid, else 0
     const v2f cb = (sam_v + sam_v) * inv_v;           // 2 sam / bottom
     acc[9] += sam_v;
     acc[10] += (v2f){va ? 1.0f : 0.0f, vb ? 1.0f : 0.0f};
@@ -298,19 +316,36 @@ __device__ __forceinline__ void decode_all(const Lds &L, const float *xr, int la
 
 // the (<= 4) two-match steps of an item as straight-line code per step count: without the per-step branch the
 // scheduler interleaves the independent steps, which hides the VALU dependency latency two waves per SIMD cannot
-#define PD_P2_STEP(M, j) sampson_step2(M[2 * (j)], M[2 * (j) + 1], (lane + 128 * (j)) < e.y, (lane + 128 * (j) + 64) < e.y, Fm, P.sampson_max, acc2)
-#define PD_P2_STEPS(M)                                                        \
-    do {                                                                      \
-        if (npairs >= 4) {                                                    \
-            PD_P2_STEP(M, 0); PD_P2_STEP(M, 1); PD_P2_STEP(M, 2); PD_P2_STEP(M, 3); \
-        } else if (npairs == 3) {                                             \
-            PD_P2_STEP(M, 0); PD_P2_STEP(M, 1); PD_P2_STEP(M, 2);             \
-        } else if (npairs == 2) {                                             \
-            PD_P2_STEP(M, 0); PD_P2_STEP(M, 1);                               \
-        } else if (npairs == 1) {                                             \
-            PD_P2_STEP(M, 0);                                                 \
-        }                                                                     \
-    } while (0)
+#define PD_P2_STEP(M, j) sampson_step2<EXACT>(M[2 * (j)], M[2 * (j) + 1], (lane + 128 * (j)) < cnt, (lane + 128 * (j) + 64) < cnt, Fm, smax, acc2, mind)
+template <bool EXACT>
+__device__ __forceinline__ void item_steps(const float4 (&M)[8], int cnt, int lane, const float *Fm, float smax,
+                                           v2f (&acc2)[PD_ITEM_VALS], float &mind) {
+    const int npairs = (cnt + 127) >> 7;
+    if (npairs >= 4) {
+        PD_P2_STEP(M, 0); PD_P2_STEP(M, 1); PD_P2_STEP(M, 2); PD_P2_STEP(M, 3);
+    } else if (npairs == 3) {
+        PD_P2_STEP(M, 0); PD_P2_STEP(M, 1); PD_P2_STEP(M, 2);
+    } else if (npairs == 2) {
+        PD_P2_STEP(M, 0); PD_P2_STEP(M, 1);
+    } else if (npairs == 1) {
+        PD_P2_STEP(M, 0);
+    }
+}
+// one work item: the fast pass, and -- when some match of the wave came within the band of the threshold where the
+// 1-ulp quotient could decide differently from the IEEE quotient -- the exact pass over the same registers instead
+__device__ __forceinline__ void item_pass(const float4 (&M)[8], int cnt, int lane, const float *Fm, float smax,
+                                          v2f (&acc2)[PD_ITEM_VALS]) {
+    float mind = __int_as_float(0x7f800000);
+#pragma unroll
+    for (int c = 0; c < PD_ITEM_VALS; ++c) acc2[c] = (v2f){0.0f, 0.0f};
+    item_steps<false>(M, cnt, lane, Fm, smax, acc2, mind);
+    const float band = smax * (PD_SAMPSON_BAND_ULPS * 1.1920929e-7f);
+    if (__builtin_amdgcn_ballot_w64(mind <= band) != 0ull) {   // wave-uniform, rare (P ~ 1e-7 per match)
+#pragma unroll
+        for (int c = 0; c < PD_ITEM_VALS; ++c) acc2[c] = (v2f){0.0f, 0.0f};
+        item_steps<true>(M, cnt, lane, Fm, smax, acc2, mind);
+    }
+}
 
 // --------------------------------------------------------------------------------------------
 // the kernel
@@ -440,11 +475,8 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 for (int c = 0; c < 9; ++c) Fm[c] = L.F[s * 9 + c];
                 // two 64-match steps per pass: lane handles matches lane + 64*(2j) and lane + 64*(2j+1) together
                 v2f acc2[PD_ITEM_VALS];
-#pragma unroll
-                for (int c = 0; c < PD_ITEM_VALS; ++c) acc2[c] = (v2f){0.0f, 0.0f};
-                const int npairs = (e.y + 127) >> 7;
                 if (resident) {   // straight from the resident registers (no copies)
-                    PD_P2_STEPS(mres);
+                    item_pass(mres, e.y, lane, Fm, P.sampson_max, acc2);
                 } else {
                     // stream this item: all (<= 8) lines in flight at once, indices clamped (no
                     // predicated loads), out-of-range lanes are masked in the arithmetic instead
@@ -456,7 +488,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         const int m = lane + 64 * st;
                         mb[st] = pts[m < e.y ? m : last];
                     }
-                    PD_P2_STEPS(mb);
+                    item_pass(mb, e.y, lane, Fm, P.sampson_max, acc2);
                 }
                 float acc[PD_ITEM_VALS];
 #pragma unroll
@@ -826,11 +858,8 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
 #pragma unroll
                     for (int c = 0; c < 9; ++c) Fm[c] = L.F[s * 9 + c];
                     v2f acc2[PD_ITEM_VALS];
-#pragma unroll
-                    for (int c = 0; c < PD_ITEM_VALS; ++c) acc2[c] = (v2f){0.0f, 0.0f};
-                    const int npairs = (e.y + 127) >> 7;
                     if (resident) {
-                        PD_P2_STEPS(mres);
+                        item_pass(mres, e.y, lane, Fm, P.sampson_max, acc2);
                     } else {
                         float4 mb[8];
                         const float4 *pts = D.pts + e.x;
@@ -840,7 +869,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                             const int m = lane + 64 * q;
                             mb[q] = pts[m < e.y ? m : last];
                         }
-                        PD_P2_STEPS(mb);
+                        item_pass(mb, e.y, lane, Fm, P.sampson_max, acc2);
                     }
                     float acc[PD_ITEM_VALS];
 #pragma unroll
@@ -1162,12 +1191,13 @@ int pd_ggs_init() {
     return PD_OK;
 }
 
-int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stages, int n_stages,
-                  const pd_ggs_cfg *cfg, int eval_only, float *stats, float *trace, int trace_iters,
-                  float *loss_out, float *grad_out, hipStream_t s) {
-    if (!eng || !x || !cfg || B <= 0 || B > eng->max_B || N <= 0 || N > eng->max_N || N > PD_MAX_FRAMES ||
-        n_stages <= 0 || n_stages > PD_GGS_MAX_STAGES) {
-        pd_set_error("pd_ggs: invalid arguments (B=%d N=%d stages=%d)", B, N, n_stages);
+// The launch shape of one GGS launch, derived from the uploaded match tables: workgroups per sequence, local item
+// slots, dynamic LDS and which kernel.  Captured hipGraphs bake these in, so pd_sample_phase keys its graph cache on
+// the plan (a re-upload with another item count must never replay the old shape: the kernel would index its LDS
+// tables past their size).  Also validates what pd_ggs_launch validates, so a graph replay cannot skip the checks.
+int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *out) {
+    if (!eng || !cfg || !out || B <= 0 || B > eng->max_B || N <= 0 || N > eng->max_N || N > PD_MAX_FRAMES) {
+        pd_set_error("pd_ggs: invalid arguments (B=%d N=%d)", B, N);
         return PD_ERR_INVALID_ARG;
     }
     int max_items = 0;
@@ -1223,6 +1253,27 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
         pd_set_error("pd_ggs: %d work items need %zu B of LDS per workgroup (> 160 KiB) at B=%d", max_items, lds, B);
         return PD_ERR_UNSUPPORTED;
     }
+    out->k = k;
+    out->n_slots = n_slots;
+    out->lds = (int)lds;
+    out->two_hop = two_hop ? 1 : 0;
+    out->max_items = max_items;
+    return PD_OK;
+}
+
+int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stages, int n_stages,
+                  const pd_ggs_cfg *cfg, int eval_only, float *stats, float *trace, int trace_iters,
+                  float *loss_out, float *grad_out, hipStream_t s) {
+    if (!eng || !x || !cfg || n_stages <= 0 || n_stages > PD_GGS_MAX_STAGES) {
+        pd_set_error("pd_ggs: invalid arguments (B=%d N=%d stages=%d)", B, N, n_stages);
+        return PD_ERR_INVALID_ARG;
+    }
+    PdGgsPlan plan;
+    int prc = pd_ggs_plan(eng, B, N, cfg, &plan);
+    if (prc) return prc;
+    const int k = plan.k, n_slots = plan.n_slots;
+    const size_t lds = (size_t)plan.lds;
+    const bool two_hop = plan.two_hop != 0;
     PdGgsParams P;
     memset(&P, 0, sizeof(P));
     P.seqs = eng->d_seqs;

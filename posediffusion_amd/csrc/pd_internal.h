@@ -76,6 +76,11 @@ struct PdGgsParams {
     int prof_wave;             // which wave of workgroup 0 records them
 };
 
+// launch shape of one GGS launch (pd_ggs_plan): everything a captured graph node bakes in besides its arguments
+struct PdGgsPlan {
+    int k, n_slots, lds, two_hop, max_items;
+};
+
 struct PdSeqHost {
     void *blob = nullptr;      // one hipMalloc holding every array of the PdSeqDesc
     size_t blob_bytes = 0;     // its capacity (re-used by later uploads that fit)
@@ -110,6 +115,7 @@ struct pd_engine {
     struct GraphKey {
         int B, N, cond_start, has_ggs, phase, den_wgs;
         pd_ggs_cfg cfg;
+        PdGgsPlan plan;            // match-derived launch shape baked into the captured GGS nodes
     };
     std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
     hipStream_t own_stream = nullptr;
@@ -131,6 +137,7 @@ int pd_denoiser_xcd_launch(pd_engine *eng, int B, int N, int step_begin, int ste
 
 // pd_ggs.hip
 int pd_ggs_init();
+int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *out);
 int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stages, int n_stages,
                   const pd_ggs_cfg *cfg, int eval_only, float *stats, float *trace, int trace_iters,
                   float *loss_out, float *grad_out, hipStream_t s);

@@ -71,7 +71,9 @@ class GaussianDiffusion(nn.Module):
                 pose, _ = self.p_sample(pose, t, z, cond_fn=cond_fn, cond_start_step=cond_start_step)
                 process.append(pose.unsqueeze(0))
             return pose, torch.cat(process)
-        has_ggs = parsed is not None and cond_start_step > 0
+        # demo.py:79-92: hloc returning no matches (kp1 is None) means sampling without GGS
+        has_ggs = parsed is not None and cond_start_step > 0 and \
+            all(host.has_matches(m) for m in (parsed[0] if isinstance(parsed[0], (list, tuple)) else [parsed[0]]))
         noise = host.draw_noise(tuple(shape), self.num_timesteps, device, cond_start_step, has_ggs)
         cfg = None
         if has_ggs:
@@ -79,6 +81,10 @@ class GaussianDiffusion(nn.Module):
             host.upload_matches(eng, matches, B)
         pose, process, stats = eng.sample(z, noise, cond_start_step if has_ggs else 0, cfg, use_graph=self.use_graph)
         self.last_ggs_stats = stats
+        if has_ggs:
+            # the GGS workgroups of a sequence exchange sums through bounded spins; one that gave up (co-residency lost
+            # to another process) raises here instead of returning garbage poses, and the flag is cleared for the next call
+            eng.check_async()
         if stats is not None and os.environ.get("PD_GGS_VERBOSE"):
             st = stats.cpu()
             for k in range(st.shape[0]):

@@ -35,16 +35,18 @@ def load_and_preprocess_images(folder_path=None, image_size: int = 224, image_pa
     lib = _lib.load()
     out = torch.empty(len(image_paths), 3, image_size, image_size, device=dev, dtype=torch.float32)
     bboxes, scales, min_hw = [], [], None
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    for k, path in enumerate(image_paths):
-        with Image.open(path) as pil_im:
-            im = np.ascontiguousarray(np.array(pil_im.convert("RGB")))                      # :58-60, uint8 HWC
-        h, w = im.shape[:2]
-        bbox, min_hw, scale = _bbox_and_scale(h, w, image_size)
-        src = torch.from_numpy(im).to(dev)
-        _lib.check(lib.pd_preprocess_image(src.data_ptr(), h, w, int(image_size), out[k].data_ptr(), stream), "pd_preprocess_image")
-        bboxes.append(bbox)
-        scales.append(scale)
+    with torch.cuda.device(dev):                       # the launches below target `dev`'s current stream
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        for k, path in enumerate(image_paths):
+            with Image.open(path) as pil_im:
+                im = np.ascontiguousarray(np.array(pil_im.convert("RGB")))                  # :58-60, uint8 HWC
+            h, w = im.shape[:2]
+            bbox, min_hw, scale = _bbox_and_scale(h, w, image_size)
+            src = torch.from_numpy(im).to(dev)
+            _lib.check(lib.pd_preprocess_image(src.data_ptr(), h, w, int(image_size), out[k].data_ptr(), stream),
+                       "pd_preprocess_image")
+            bboxes.append(bbox)
+            scales.append(scale)
     # assume all the images have the same shape for GGS   (:46-47)
     image_info = {"size": (min_hw, min_hw), "bboxes_xyxy": np.stack(bboxes), "resized_scales": np.stack(scales)}
     return out, image_info

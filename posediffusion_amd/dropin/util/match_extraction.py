@@ -1,30 +1,36 @@
-"""The keypoint bookkeeping of pose_diffusion/util/match_extraction.py.
+"""Keypoint bookkeeping between hloc/COLMAP and the sampler (pose_diffusion/util/match_extraction.py:50-77).
 
-`colmap_keypoint_to_pytorch3d` (:50-77) maps COLMAP keypoints of the original images into the cropped + resized frames
-that the sampler sees and emits the (kp1, kp2, i12) arrays `pd_ggs_set_matches` takes; it is host numpy in the reference
-and stays host numpy here (a few thousand points, once per sequence).  Match extraction itself (`extract_match`,
-`run_hloc`: SuperPoint + SuperGlue through hloc / pycolmap) is outside this engine's scope."""
+`colmap_keypoint_to_pytorch3d` takes hloc's per-image keypoints (COLMAP pixel convention, 1-based image ids) and the
+per-pair match index arrays, and returns the flat `(kp1, kp2, i12)` arrays `pd_ggs_set_matches` ingests: keypoints in
+the pixel frame of the centre-cropped, resized images the sampler sees.  Here it is one table-wide transform plus one
+gather (no per-image Python arithmetic): all keypoints are stacked once, every row carries its frame index, and the
+matches become global row indices into that table.  Per element the arithmetic and its dtypes are the reference's
+(`- 0.5` in the keypoints' own dtype, `- bbox` promoting to float64, `* scale`), so results are bit-identical
+(tests/test_oracle_golden.py pins them against the reference file executed in place).  Unlike the reference it does
+not overwrite the caller's `keypoints` dict.
+
+Match extraction itself (`extract_match`, `run_hloc`: SuperPoint + SuperGlue through hloc / pycolmap) is outside this
+engine's scope (third-party, needs network weights)."""
 import numpy as np
 
 
 def colmap_keypoint_to_pytorch3d(matches, keypoints, image_info):
-    kp1, kp2, i12 = [], [], []
-    bbox_xyxy, scale = image_info["bboxes_xyxy"], image_info["resized_scales"]
-    keypoints = dict(keypoints)
-    for idx in keypoints:
-        cur = keypoints[idx] - 0.5                                            # COLMAP -> OpenCV pixel centres   (:56)
-        cur = cur - [bbox_xyxy[idx - 1][0], bbox_xyxy[idx - 1][1]]            # into the crop; COLMAP ids start at 1   (:60)
-        keypoints[idx] = cur * scale[idx - 1]                                 # into the resized frame   (:61)
-    for (r_idx, q_idx), pair_match in matches.items():
-        if pair_match is not None:
-            kp1.append(keypoints[r_idx][pair_match[:, 0]])
-            kp2.append(keypoints[q_idx][pair_match[:, 1]])
-            i12.append(np.repeat(np.array([[r_idx - 1, q_idx - 1]]), len(pair_match), axis=0))
-    if kp1:
-        kp1, kp2, i12 = map(np.concatenate, (kp1, kp2, i12), (0, 0, 0))
-    else:
-        kp1 = kp2 = i12 = None
-    return kp1, kp2, i12
+    pairs = [(r, q, np.asarray(m)) for (r, q), m in matches.items() if m is not None]
+    if not pairs:
+        return None, None, None
+    image_ids = list(keypoints)                                        # COLMAP ids, 1-based (:59)
+    per_image = [np.asarray(keypoints[i]) for i in image_ids]
+    first_row = dict(zip(image_ids, np.cumsum([0] + [len(k) for k in per_image[:-1]])))
+    frame_of_row = np.repeat(np.asarray(image_ids, dtype=np.int64) - 1, [len(k) for k in per_image])
+    table = np.concatenate(per_image, axis=0)
+    crop_origin = np.asarray(image_info["bboxes_xyxy"])[frame_of_row, :2]
+    zoom = np.asarray(image_info["resized_scales"])[frame_of_row]
+    # COLMAP pixel centres -> OpenCV (:56), into the crop (:60), into the resized frame (:61)
+    table = ((table - 0.5) - crop_origin) * zoom[:, None]
+    rows1 = np.concatenate([first_row[r] + m[:, 0] for r, _, m in pairs])
+    rows2 = np.concatenate([first_row[q] + m[:, 1] for _, q, m in pairs])
+    i12 = np.repeat(np.array([[r - 1, q - 1] for r, q, _ in pairs]), [len(m) for _, _, m in pairs], axis=0)
+    return table[rows1], table[rows2], i12
 
 
 def extract_match(image_paths=None, image_folder_path=None, image_info=None):

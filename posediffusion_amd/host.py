@@ -105,17 +105,34 @@ def current_engine(device) -> PoseEngine:
     return eng
 
 
+def _match_fingerprint(md):
+    """Cheap content fingerprint of a matches_dict (shape + three sums): catches in-place edits of arrays the cache
+    still holds a reference to; identity alone is not enough (CPython recycles ids, arrays can be rewritten)."""
+    kp1, kp2, i12 = md["kp1"], md["kp2"], md["i12"]
+    return (tuple(kp1.shape), float(kp1.sum()), float(kp2.sum()), int(i12.sum()), tuple(int(v) for v in md["img_shape"]))
+
+
+def has_matches(md) -> bool:
+    """demo.py:79-92 guards `kp1 is None` (hloc found nothing): such a dict means "sample without GGS"."""
+    return md is not None and md.get("kp1") is not None and len(md["kp1"]) > 0
+
+
 def upload_matches(engine: PoseEngine, matches, B: int):
-    """matches: one reference-style matches_dict (B == 1) or a list of B of them.  Uploads are
-    cached on the engine by object identity so the five calls per guided step upload once."""
+    """matches: one reference-style matches_dict (B == 1) or a list of B of them.  Uploads are cached per slot so
+    the five calls per guided step upload once: a slot is skipped only when it still holds the SAME arrays (the cache
+    keeps references, so their ids cannot be recycled) with the same content fingerprint."""
     lst = list(matches) if isinstance(matches, (list, tuple)) else [matches]
     if len(lst) != B:
         raise ValueError(f"GGS needs one matches_dict per sequence: got {len(lst)} for B={B} "
                          "(the reference defines GGS only for B = 1, geometry_guided_sampling.py:16)")
     cache = engine.__dict__.setdefault("_match_ids", {})
     for b, md in enumerate(lst):
-        key = (id(md), id(md["kp1"]), len(md["kp1"]))
-        if cache.get(b) == key:
+        if not has_matches(md):
+            raise ValueError(f"matches_dict of sequence {b} holds no matches (kp1 is None or empty); "
+                             "call the sampler without cond_fn for such a sequence (demo.py:79-92)")
+        fp = _match_fingerprint(md)
+        ent = cache.get(b)
+        if ent is not None and ent[0] is md["kp1"] and ent[1] is md["kp2"] and ent[2] is md["i12"] and ent[3] == fp:
             continue
         engine.set_matches(b, md["kp1"], md["kp2"], md["i12"], tuple(md["img_shape"]))
-        cache[b] = key
+        cache[b] = (md["kp1"], md["kp2"], md["i12"], fp)

@@ -1,0 +1,225 @@
+"""GPU (-m gpu), round 2: the parity holes VERDICT.md (round 1) lists -- all through the C-ABI, checked by the oracle.
+
+  * BASELINE configs[4] at FULL size (N = 50, 1 225 pairs x 300 = 367 500 matches, 336^2) on the two-hop kernel;
+  * SURVEY.md section 8c's free-running GGS-on criterion against the reference-generated fixture
+    tests/golden/guided_free.npz (oracle/make_golden.py make_guided_free);
+  * the `sampson < sampson_max` rule of geometry_guided_sampling.py:170 around the threshold;
+  * hipGraph replay after a re-upload that changes the GGS launch shape.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import pd_oracle as O
+from posediffusion_amd import synth
+from posediffusion_amd.engine import make_ggs_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 2e-5          # asserted on teacher-forced pieces; the contract is 1e-4 (BASELINE.json north_star)
+
+
+# ------------------------------------------------------------------------------------------------ configs[4], full size
+def test_long_sequence_n50_full_size_m367500(engine):
+    """BASELINE configs[4] exactly: 50 frames, all 1 225 pairs x 300 matches = 367 500, 336 x 336.  Value, exact valid
+    count and analytic gradient against the oracle's autograd; 3 GGS_optimize iterations (x2: all flags, :86-87)
+    against the oracle; two-hop kernel (default for N > 32), single-exchange kernel and k = 1 agree."""
+    N = 50
+    enc = synth.make_cameras(N, seed=50)
+    md = synth.make_matches(enc, 336, 336, per_pair=300, seed=50)
+    assert len(md["kp1"]) == 367500 and len(np.unique(md["i12"][:, 0] * N + md["i12"][:, 1])) == 1225
+    pm = O.prepare_matches(md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+    x0 = synth.perturb_pose(enc, seed=51)
+    engine.set_matches(0, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+    xo = x0.clone().requires_grad_(True)
+    v, pr = O.compute_sampson_distance(xo, pm)
+    (go,) = torch.autograd.grad(v.mean(), xo)
+    ref, _, ref_steps = O.ggs_optimize(x0.clone(), pm, iter_num=3)
+    assert ref_steps == 6
+    outs = {}
+    for label, wgs, flags in (("two_hop", 0, 0), ("two_hop_k64", 64, 0), ("one_hop", 0, 1), ("k1", 1, 0)):
+        cfg = make_ggs_cfg(wgs_per_seq=wgs, reserved=flags)
+        loss, grad = engine.ggs_loss_grad(x0.to(DEV), cfg=cfg)
+        engine.check_async()
+        # hard threshold: exact count unless a match sits within the contract tolerance of sampson_max (see
+        # test_sampson_threshold_rule_around_sampson_max); this scene has none that close
+        assert int(loss[0, 1].item()) == len(v), label
+        assert abs(loss[0, 0].item() - v.mean().item()) < 1e-5 * v.mean().item(), label
+        assert abs(loss[0, 2].item() - pr.item()) < 1e-5 * pr.item(), label
+        assert rel_err(grad, go) < 1e-4, (label, rel_err(grad, go))
+        o, st, _ = engine.ggs_optimize(x0.to(DEV), cfg=make_ggs_cfg(iter_num=3, wgs_per_seq=wgs, reserved=flags))
+        engine.check_async()
+        assert int(st[0, 1].item()) == 6, label
+        assert rel_err(o, ref) < TOL, (label, rel_err(o, ref))
+        outs[label] = o
+    assert torch.equal(outs["k1"], outs["one_hop"])
+    assert rel_err(outs["two_hop"], outs["k1"]) < 1e-5 and rel_err(outs["two_hop_k64"], outs["k1"]) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ free-running GGS-on
+def test_free_running_ggs_on_criterion_vs_reference_fixture(engine, golden):
+    """SURVEY.md section 8c, free-running GGS-on (scaled-down BASELINE configs[2]: N = 8, 28 pairs x 60 matches, 100
+    steps, the last 3 guided with the full 700-iteration schedule; three seeds).  The fixture holds, per seed, the
+    UNMODIFIED reference's fp32 result and the fp64 oracle's on the same z / noise / matches.
+
+    Pass criterion as SURVEY states it: engine-vs-fp64 deviation <= 2 x (reference-fp32-vs-fp64 deviation) -- taken
+    over the three seeds together, because one chaotic trajectory is one sample (the reference's own deviation spans
+    3e-4 .. 7e-4 over these seeds) -- and no seed worse than 4 x its reference deviation.
+    Final mean Sampson error: SURVEY asks for 1 % of the oracle's.  The fixture shows the reference itself misses
+    that by far (fp32 vs fp64: 1.8 %, 21 %, 16 % on these seeds: |pose| ~ 45 with random-init weights, hard
+    threshold, 2 100 iterations), so the bound is max(1 %, 2 x the reference's own relative gap), seeds together."""
+    g = golden["guided_free"]
+    cond_start = int(g["cond_start_step"])
+    shape = tuple(int(v) for v in g["img_shape"])
+    cfg = dict(synth.GGS_CFG)
+    devs, ref_devs, sam_gaps, ref_sam_gaps = [], [], [], []
+    for s in g["seeds"].tolist():
+        kp1, kp2, i12 = g[f"s{s}_kp1"], g[f"s{s}_kp2"], g[f"s{s}_i12"]
+        engine.set_matches(0, kp1, kp2, i12, shape)
+        z, noise = torch.from_numpy(g[f"s{s}_z"]).to(DEV), torch.from_numpy(g[f"s{s}_noise"]).to(DEV)
+        outs = []
+        for use_graph in (True, False):
+            pose, _, stats = engine.sample(z, noise, cond_start, cfg, use_graph=use_graph)
+            engine.check_async()
+            outs.append(pose.cpu())
+        assert torch.equal(outs[0], outs[1]), "hipGraph replay must equal eager launches bit for bit"
+        assert stats[:, 0, :, 1].sum().item() == 700 * cond_start, "every guided step must run its 700 iterations"
+        pose = outs[0]
+        p64, p32 = g[f"s{s}_pose64"], g[f"s{s}_pose32"]
+        devs.append(rel_err(pose, p64))
+        ref_devs.append(rel_err(p32, p64))
+        pm = O.prepare_matches(kp1, kp2, i12, shape)
+        v, _ = O.compute_sampson_distance(pose.double(), pm)
+        s64, s32 = float(g[f"s{s}_sampson64"][0]), float(g[f"s{s}_sampson32"][0])
+        sam_gaps.append(abs(float(v.mean()) - s64) / s64)
+        ref_sam_gaps.append(abs(s32 - s64) / s64)
+    print(f"free-running GGS-on: engine vs fp64 {devs}, reference fp32 vs fp64 {ref_devs}; "
+          f"final mean Sampson gap to fp64: engine {sam_gaps}, reference fp32 {ref_sam_gaps}")
+    assert sum(devs) <= 2.0 * sum(ref_devs), (devs, ref_devs)
+    assert all(d <= 4.0 * r for d, r in zip(devs, ref_devs)), (devs, ref_devs)
+    assert sum(sam_gaps) <= max(0.01 * len(sam_gaps), 2.0 * sum(ref_sam_gaps)), (sam_gaps, ref_sam_gaps)
+
+
+# ------------------------------------------------------------------------------------------------ the hard threshold
+def _all_sampson_fp32(x, pm):
+    s, _ = O.compute_sampson_distance(x, pm, sampson_max=float("inf"))
+    return s.detach()
+
+
+def test_sampson_threshold_rule_around_sampson_max(engine, golden):
+    """geometry_guided_sampling.py:170 keeps `sampson < sampson_max` on torch's IEEE quotient.  The engine decides on the
+    IEEE quotient too (csrc/pd_ggs.hip sampson_step2: fast 1-ulp pass, exact re-run of an item that has a match within
+    16 ulp of the threshold), but ITS top / bottom differ from torch's by fp32 rounding order (F is built in another
+    order), so the documented rule is: the valid set equals the reference's except for matches whose Sampson value lies
+    within the contract tolerance (1e-4 relative) of sampson_max.  Checked with sampson_max placed EXACTLY on oracle
+    Sampson values, one ulp above and one below."""
+    gg = golden["ggs"]
+    shape = tuple(int(v) for v in gg["img_shape"])
+    engine.set_matches(0, gg["kp1"], gg["kp2"], gg["i12"], shape)
+    pm = O.prepare_matches(gg["kp1"], gg["kp2"], gg["i12"], shape)
+    x0 = torch.from_numpy(gg["x0"])
+    s = _all_sampson_fp32(x0, pm)
+    order = torch.argsort(s)
+    picks = [order[int(q * (len(s) - 1))].item() for q in (0.05, 0.3, 0.5, 0.7, 0.9, 0.97)]
+    for m in picks:
+        for smax in (np.nextafter(np.float32(s[m]), np.float32(0)), np.float32(s[m]), np.nextafter(np.float32(s[m]), np.float32(np.inf))):
+            smax = float(smax)
+            lo = int((s < smax * (1 - 1e-4)).sum())
+            hi = int((s < smax * (1 + 1e-4)).sum())
+            for k in (1, 0):
+                loss, _ = engine.ggs_loss_grad(x0.to(DEV), cfg=make_ggs_cfg(sampson_max=smax, wgs_per_seq=k, min_matches=0))
+                engine.check_async()
+                assert lo <= int(loss[0, 1].item()) <= hi, (m, smax, lo, int(loss[0, 1].item()), hi)
+
+
+def test_sampson_threshold_fast_and_exact_paths_agree(engine):
+    """One match replicated 96 times in a pair (identical Sampson value in every copy, whatever the engine's rounding
+    of F).  (a) The engine's switching point -- the smallest sampson_max that makes the copies valid, found by bisection
+    over the float representation -- lies within the contract tolerance of the oracle's Sampson value.  (b) Sweeping
+    sampson_max over the 97 consecutive floats around that point switches the copies exactly ONCE, all together,
+    monotonically.  (c) For an unchanged valid set, loss and gradient just inside the 16-ulp band (exact IEEE path) equal
+    those well outside it (fast 1-ulp path)."""
+    N = 6
+    enc = synth.make_cameras(N, seed=77)
+    md = synth.make_matches(enc, 224, 224, per_pair=20, seed=77)
+    kp1, kp2, i12 = md["kp1"].copy(), md["kp2"].copy(), md["i12"].copy()
+    x0 = synth.perturb_pose(enc, seed=78)
+    s0 = _all_sampson_fp32(x0, O.prepare_matches(kp1, kp2, i12, md["img_shape"]))
+    m = None
+    for c in torch.nonzero((s0 > 0.5) & (s0 < 5.0)).flatten().tolist():      # a match with no neighbour within 1 %
+        if ((s0 - s0[c]).abs() < 0.01 * s0[c]).sum() == 1:
+            m = c
+            break
+    assert m is not None
+    copies = 96
+    kp1 = np.concatenate([kp1, np.repeat(kp1[m:m + 1], copies, 0)])
+    kp2 = np.concatenate([kp2, np.repeat(kp2[m:m + 1], copies, 0)])
+    i12 = np.concatenate([i12, np.repeat(i12[m:m + 1], copies, 0)])
+    engine.set_matches(0, kp1, kp2, i12, md["img_shape"])
+    below = int((s0 < s0[m] * 0.99).sum())                                   # matches certainly below the window
+
+    def probe(bits):
+        smax = float(np.array([bits], dtype=np.int32).view(np.float32)[0])
+        loss, grad = engine.ggs_loss_grad(x0.to(DEV), cfg=make_ggs_cfg(sampson_max=smax, min_matches=0))
+        return int(loss[0, 1].item()), loss[0, 0].item(), grad.cpu()
+
+    as_bits = lambda f: int(np.array([f], dtype=np.float32).view(np.int32)[0])   # noqa: E731  (positive floats order like ints)
+    lo, hi = as_bits(float(s0[m]) * (1 - 5e-3)), as_bits(float(s0[m]) * (1 + 5e-3))
+    assert probe(lo)[0] == below and probe(hi)[0] == below + copies + 1
+    while hi - lo > 1:                                                       # invariant: lo invalid, hi valid
+        mid = (lo + hi) // 2
+        if probe(mid)[0] > below:
+            hi = mid
+        else:
+            lo = mid
+    engine.check_async()
+    s_switch = float(np.array([lo], dtype=np.int32).view(np.float32)[0])     # largest smax with the copies still invalid = the engine's s
+    assert abs(s_switch - float(s0[m])) <= 1e-4 * float(s0[m]), (s_switch, float(s0[m]))
+    res = {d: probe(hi + d) for d in list(range(-48, 49))}
+    counts = np.array([res[d][0] for d in range(-48, 49)])
+    assert (np.diff(counts) >= 0).all() and set(counts.tolist()) == {below, below + copies + 1}
+    assert counts[47] == below and counts[48] == below + copies + 1          # the single jump sits at the bisected point
+    for inside, outside in ((2, 44), (-3, -44)):                             # exact path vs fast path, same valid set
+        assert res[inside][0] == res[outside][0]
+        assert abs(res[inside][1] - res[outside][1]) <= 2e-6 * abs(res[outside][1])
+        assert rel_err(res[inside][2], res[outside][2]) < 2e-6
+    engine.check_async()
+
+
+# ------------------------------------------------------------------------------------------------ graph cache vs re-upload
+def test_graph_replay_after_reupload_with_other_launch_shape(seeded_diffuser):
+    """the captured GGS nodes bake in workgroups per sequence, item slots and LDS size, all derived
+    from the uploaded matches.  Sampling with use_graph, re-uploading matches with MORE work items (demo.py / test.py
+    flow: same model, next sequence) and sampling again must not replay the first launch shape: every replayed result
+    must equal eager launches bit for bit, and going back to the first matches must re-use the first graph."""
+    from posediffusion_amd.engine import PoseEngine
+    from posediffusion_amd.host import denoiser_state
+    dev = torch.device(DEV)
+    diff = seeded_diffuser.to(dev)
+    N = 10
+    eng = PoseEngine(denoiser_state(diff.model), {k: v for k, v in diff.named_buffers(recurse=False)}, device=dev, max_B=1, max_N=N)
+    enc = synth.make_cameras(N, seed=600)
+    small = synth.make_matches(enc, 224, 224, per_pair=30, seed=600)                       # 45 items
+    big = synth.make_matches(enc, 224, 224, per_pair=700, seed=601, ordered_pairs=True)    # 90 pairs x 2 items = 180 items
+    other_n = synth.make_matches(enc[:7], 224, 224, per_pair=30, seed=602)                 # uploaded for 7 frames
+    z = synth.make_z(1, N, seed=9).to(dev)
+    noise = torch.randn(101, 1, N, 9, generator=torch.Generator().manual_seed(5)).to(dev)
+    cfg = make_ggs_cfg(dict(synth.GGS_CFG, iter_num=5), min_matches=0)
+
+    def run(md, use_graph):
+        eng.set_matches(0, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+        pose, _, st = eng.sample(z, noise, 2, cfg, use_graph=use_graph, want_process=False)
+        eng.check_async()
+        return pose.clone(), st.clone()
+
+    for md in (small, big, small, big):
+        pg, sg = run(md, True)
+        pe, se = run(md, False)
+        assert torch.equal(pg, pe) and torch.equal(sg.nan_to_num(-1.0), se.nan_to_num(-1.0))
+        assert torch.isfinite(pg).all()
+    # a replay must not skip pd_ggs_launch's checks either: matches uploaded for another frame count
+    eng.set_matches(0, other_n["kp1"], other_n["kp2"], other_n["i12"], other_n["img_shape"])
+    with pytest.raises(RuntimeError, match="uploaded for 7 frames"):
+        eng.sample(z, noise, 2, cfg, use_graph=True, want_process=False)
+    eng.close()
