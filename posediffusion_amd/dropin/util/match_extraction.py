@@ -33,6 +33,22 @@ def colmap_keypoint_to_pytorch3d(matches, keypoints, image_info):
     return table[rows1], table[rows2], i12
 
 
+PRECOMPUTED_MATCHES = "pd_matches.npz"
+
+
 def extract_match(image_paths=None, image_folder_path=None, image_info=None):
-    raise ImportError("extract_match needs hloc + pycolmap (SuperPoint / SuperGlue), which this engine does not replace; "
-                      "run the reference's util/match_extraction.py for the matches and pass them as matches_dict")
+    """match_extraction.py:28-47 runs SuperPoint + SuperGlue through hloc / pycolmap -- third-party networks this engine
+    does not replace.  Matches extracted elsewhere (the reference's own `extract_match` on any machine that has hloc)
+    can be dropped next to the images as ``pd_matches.npz`` with the arrays demo.py:82-84 puts into matches_dict
+    (kp1 [M,2], kp2 [M,2] pixel coordinates of the cropped + resized frames, i12 [M,2] frame indices); they are returned
+    as extract_match would return them.  Without that file the call raises, as the missing dependency would."""
+    import os
+    if image_folder_path is not None:
+        path = os.path.join(image_folder_path, PRECOMPUTED_MATCHES)
+        if os.path.isfile(path):
+            with np.load(path) as d:
+                return (np.asarray(d["kp1"], dtype=np.float64), np.asarray(d["kp2"], dtype=np.float64),
+                        np.asarray(d["i12"], dtype=np.int64))
+    raise ImportError("extract_match needs hloc + pycolmap (SuperPoint / SuperGlue), which this engine does not replace: run "
+                      "the reference's util/match_extraction.py where hloc is installed and either pass its result as "
+                      f"matches_dict or save it as <image_folder>/{PRECOMPUTED_MATCHES} (kp1, kp2, i12)")
