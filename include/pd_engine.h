@@ -94,6 +94,9 @@ typedef struct pd_ggs_cfg {
                              * two-hop kernel that distributes the backward (testing / comparison) */
 } pd_ggs_cfg;
 #define PD_GGS_CFG_FORCE_ONE_HOP 1
+#define PD_GGS_CFG_NO_LDS_STAGING 2   /* pd_ggs_cfg.reserved: stream match items through registers even where the LDS-DMA double
+                                       * buffer applies (several items per wavefront, every item <= 384 matches); same arithmetic,
+                                       * bitwise the same results -- comparison / testing */
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
 
@@ -134,6 +137,29 @@ int pd_p_finish(pd_engine *eng, const float *mean, const float *noise, int t, in
  * Synchronous (allocates).  M == 0 clears the slot. */
 int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, const double *kp2,
                        const int64_t *i12, int64_t M, int n_frames, int height, int width);
+
+/* Asynchronous, device-resident ingestion of the matches of `n_seqs` consecutive sequence slots (seq_first ..) -- the
+ * batched match container.  The reference re-uploads kp1 / kp2 / i12 from numpy on every
+ * guided step (geometry_guided_sampling.py:19-24); here a batch goes up once, without the host ever waiting:
+ *   seq_offsets  HOST   [n_seqs + 1]  CSR offsets: sequence b owns rows [seq_offsets[b], seq_offsets[b+1]) of the arrays below
+ *   kp1, kp2     DEVICE-ACCESSIBLE float64 [total, 2]  (device memory, or pinned host memory the GPU reads over PCIe)
+ *   i12          DEVICE-ACCESSIBLE int64   [total, 2]  frame indices -- the dtypes demo.py:82-84 holds
+ * The fp64 -> fp32 cast (:167), pair key (:26-27), the STABLE sort by pair and every table the GGS kernels read are built
+ * by kernels on `stream` (csrc/pd_ggs_ingest.hip); results are bitwise those of pd_ggs_set_matches on the same data.  No
+ * host synchronisation and, once a slot's buffer fits, no allocation; GGS launches of this engine issued later on any
+ * stream are ordered after the upload on the device.  The arrays must stay valid until the upload has executed.
+ * Because the host never learns the pair / item counts, launch shapes are planned from capacities: `hints` (may be NULL =
+ * worst case: min(n_frames^2, M) pairs, any number of matches per pair) lets the caller declare tighter ones, e.g.
+ * {190, 512} for hloc's exhaustive i < j pairs of 20 frames with <= 512 matches each; with max_matches_per_pair in
+ * 1..512 sequences of more than 32 frames take the two-hop kernel.  A violated hint empties the slot and, like a frame
+ * index outside [0, n_frames), raises the asynchronous error word (pd_check_async_error). */
+typedef struct pd_match_hints {
+    int32_t max_pairs;               /* 0 = unknown; else an upper bound on the frame pairs that own matches            */
+    int32_t max_matches_per_pair;    /* 0 = unknown; else an upper bound on the matches of one frame pair               */
+} pd_match_hints;
+int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n_seqs, const int64_t *seq_offsets, const double *kp1,
+                                 const double *kp2, const int64_t *i12, int n_frames, int height, int width,
+                                 const pd_match_hints *hints, void *stream);
 
 /* model_mean[B,N,9] (DEVICE, in/out) <- geometry_guided_sampling(model_mean, t, ...) for every
  * sequence b using match slot b: the five GGS_optimize calls (all, FL, R, T, all) of
@@ -278,8 +304,9 @@ int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, int H, int W
 int pd_time_kernel(pd_engine *eng, int what, int B, int N, const pd_ggs_cfg *cfg, int reps,
                    float *ms_out, void *stream);
 
-/* Synchronises the device and reports (PD_ERR_STATE) if a bounded spin of the GGS
- * cross-workgroup exchange gave up since the last check.  PD_OK otherwise. */
+/* Synchronises the device and reports (PD_ERR_STATE) what the kernels flagged asynchronously since the last check: a
+ * bounded spin of the GGS cross-workgroup exchange that gave up (bit 0), an out-of-range frame index (bit 1) or violated
+ * pd_match_hints (bit 2) met by pd_ggs_set_matches_csr_async.  Clears the word.  PD_OK otherwise. */
 int pd_check_async_error(pd_engine *eng);
 
 /* Debug aid: switch the GGS kernel's in-kernel phase cycle counters on/off and (out6 != NULL)

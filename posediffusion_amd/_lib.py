@@ -55,6 +55,10 @@ class pd_ggs_cfg(C.Structure):
                 ("wgs_per_seq", C.c_int32), ("reserved", C.c_int32)]
 
 
+class pd_match_hints(C.Structure):
+    _fields_ = [("max_pairs", C.c_int32), ("max_matches_per_pair", C.c_int32)]
+
+
 # name -> (restype, argtypes); kept in one table so the "exports every declared symbol" test and
 # the binding cannot drift apart.
 _vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
@@ -67,6 +71,7 @@ SIGNATURES = {
     "pd_p_mean": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "pd_p_finish": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "pd_ggs_set_matches": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i]),
+    "pd_ggs_set_matches_csr_async": (_i, [_vp, _i, _i, C.POINTER(_i64), _vp, _vp, _vp, _i, _i, _i, C.POINTER(pd_match_hints), _vp]),
     "pd_ggs_guide": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp]),
     "pd_ggs_optimize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp]),
     "pd_ggs_loss_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp]),

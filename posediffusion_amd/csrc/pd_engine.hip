@@ -70,7 +70,9 @@ extern "C" void pd_engine_destroy(pd_engine *eng) {
     (void)hipDeviceSynchronize();
     for (auto &g : eng->graphs) (void)hipGraphExecDestroy(g.second);
     if (eng->last_use) (void)hipEventDestroy(eng->last_use);
+    if (eng->upload_done) (void)hipEventDestroy(eng->upload_done);
     for (auto &s : eng->seqs) pd_ggs_free_seq(s);
+    for (void *p : eng->retired_blobs) (void)hipFree(p);
     pd_denoiser_destroy(eng);
     void *ptrs[] = {eng->d_seqs, eng->d_xchg, eng->d_err, eng->d_z, eng->d_noise, eng->d_process, eng->d_mean, eng->d_stats};
     for (void *p : ptrs)
@@ -111,6 +113,7 @@ extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_en
         if ((rc = fetch_table(eng->logvar, w->posterior_log_variance_clipped, w->timesteps))) break;
         if ((rc = pd_denoiser_create(eng, w))) break;
         if ((rc = pd_ggs_init())) break;
+        if ((rc = pd_ggs_ingest_init())) break;
         eng->seqs.resize(max_B);
         const int T = w->timesteps;
         const size_t bn9 = (size_t)max_B * max_N * 9;
@@ -317,6 +320,10 @@ extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *nois
         PD_HIP_CHECK(hipMemcpyAsync(eng->d_noise, noise, sizeof(float) * (T + 1) * bn9, hipMemcpyDeviceToDevice, s));
         PD_HIP_CHECK(hipMemcpyAsync(eng->d_process, noise, sizeof(float) * bn9, hipMemcpyDeviceToDevice, s));   // :289
     }
+    if (has_ggs && phase != PD_PHASE_UNGUIDED) {
+        int rc = pd_wait_uploads(eng, s);     // asynchronous match uploads issued on another stream
+        if (rc) return rc;
+    }
     if (step_begin == step_end) {
         // nothing to run in this phase
     } else if (!use_graph) {
@@ -467,7 +474,10 @@ extern "C" int pd_check_async_error(pd_engine *eng) {
     PD_HIP_CHECK(hipDeviceSynchronize());
     PD_HIP_CHECK(hipMemcpy(&v, eng->d_err, sizeof(v), hipMemcpyDeviceToHost));
     if (v) {
-        pd_set_error("GGS cross-workgroup exchange timed out (flag=%u)", v);
+        pd_set_error("asynchronous GGS error (flag=%u):%s%s%s", v,
+                     (v & 1u) ? " a cross-workgroup exchange spin timed out (co-resident workgroups lost?);" : "",
+                     (v & 2u) ? " pd_ggs_set_matches_csr_async met a frame index outside [0, n_frames);" : "",
+                     (v & 4u) ? " pd_ggs_set_matches_csr_async: pd_match_hints violated (more pairs / matches per pair than declared): the slot was emptied;" : "");
         (void)hipMemset(eng->d_err, 0, sizeof(v));
         return PD_ERR_STATE;
     }

@@ -166,9 +166,12 @@ __device__ __forceinline__ v2f pd_splat(float a) { return (v2f){a, a}; }
 // outside that band both quotients decide alike, so the valid set is always the one the IEEE quotient gives.  The
 // gradient scales 1/bottom keep the 1-ulp reciprocal in both variants (no threshold hangs on them).
 #define PD_SAMPSON_BAND_ULPS 16.0f
+// Every fused multiply-add below is written out and contraction is off inside the two step functions, so the packed and the
+// single-match form perform the same roundings: an item's sums do not depend on which form ran its tail.
 template <bool EXACT>
 __device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, bool ina, bool inb, const float *F, float smax,
                                               v2f (&acc)[PD_ITEM_VALS], float &mind) {
+#pragma clang fp contract(off)
     const v2f u1 = {pa.x, pb.x}, v1 = {pa.y, pb.y}, u2 = {pa.z, pb.z}, v2 = {pa.w, pb.w};
     // left = x1^T F, right = F x2   (:158-159)
     const v2f l0 = pd_fma2(u1, pd_splat(F[0]), pd_fma2(v1, pd_splat(F[3]), pd_splat(F[6])));
@@ -177,7 +180,7 @@ __device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, 
     const v2f r0 = pd_fma2(pd_splat(F[0]), u2, pd_fma2(pd_splat(F[1]), v2, pd_splat(F[2])));
     const v2f r1 = pd_fma2(pd_splat(F[3]), u2, pd_fma2(pd_splat(F[4]), v2, pd_splat(F[5])));
     const v2f ee = pd_fma2(l0, u2, pd_fma2(l1, v2, l2));
-    const v2f bottom = l0 * l0 + l1 * l1 + r0 * r0 + r1 * r1;          // :161
+    const v2f bottom = pd_fma2(r1, r1, pd_fma2(r0, r0, pd_fma2(l1, l1, l0 * l0)));   // :161
     const v2f inv = {pd_rcp(bottom.x), pd_rcp(bottom.y)};
     const v2f top = ee * ee;
     v2f sam;                                                            // :162-164
@@ -215,7 +218,7 @@ __device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, 
 }
 
 // LDS carve (floats).  Everything lives in the one dynamic region (guide G17).
-#define PD_GGS_LDS_FIXED (64 * 9 + 64 * 3 + 64 * 2 + 64 * 2 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8 + PD_GGS_PINC_ROWS * 16 + 64 * 16)
+#define PD_GGS_LDS_FIXED (64 * 9 + 64 * 3 + 64 * 2 + 64 * 2 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8 + 64 * 16)   // + pinc_rows * 16
 struct Lds {
     float *Rc;     // [64*9]  R_cv per frame  (opencv_from_cameras_projection)
     float *tc;     // [64*3]
@@ -226,15 +229,17 @@ struct Lds {
     float *gR;     // [64*9]  per-frame dL/dR  (PyTorch3D R, un-normalised)
     float *gA;     // [64*4]  per-frame partial dL/dA {00,02,11,12}
     float *ctl;    // [8]     ctl[0] = stage done flag, ctl[1] = abort
-    float *pinc;   // [1024*16] backward results of the current chunk of pairs, one row per (pair, side), frame-sorted
+    float *pinc;   // [pinc_rows*16] backward results of the current chunk of pairs, one row per (pair, side), frame-sorted
+                   //   (pinc_rows = 2 x pairs per chunk, at most PD_GGS_PINC_ROWS; the two-hop kernel always carves the maximum)
     float *psum;   // [64*16]  per-frame partial sums across chunks (N > 32 only)
     int4 *itab;    // [n_slots] (first match, count, i, j) of the local items
     int *incoff;   // [PD_GGS_MAX_PCHUNKS][68] per chunk of pairs: CSR offsets of its incidences per frame
     float *F;      // [n_slots*9]
     float *item;   // [n_items*12]
+    float *stage;  // [8 waves][2 buffers][STAGE_P KiB] LDS-DMA staging of the match pass (pd_ggs_kernel<STAGE_P > 0>), 1 KiB aligned
 };
 
-__device__ __forceinline__ Lds carve(float *base, int n_slots) {
+__device__ __forceinline__ Lds carve(float *base, int n_slots, int pinc_rows, int n_items_cap) {
     Lds L;
     L.Rc = base;
     L.tc = L.Rc + 64 * 9;
@@ -246,17 +251,21 @@ __device__ __forceinline__ Lds carve(float *base, int n_slots) {
     L.gA = L.gR + 64 * 9;
     L.ctl = L.gA + 64 * 4;
     L.pinc = L.ctl + 8;
-    L.psum = L.pinc + PD_GGS_PINC_ROWS * 16;
+    L.psum = L.pinc + pinc_rows * 16;
     L.itab = (int4 *)(L.psum + 64 * 16);
     L.incoff = (int *)(L.itab + n_slots);
     L.F = (float *)(L.incoff + PD_GGS_MAX_PCHUNKS * 68);
     L.item = L.F + n_slots * 9 + ((4 - ((n_slots * 9) & 3)) & 3);
+    L.stage = base + ((((L.item + n_items_cap * PD_ITEM_VALS) - base) + 255) & ~255);   // 1 KiB aligned (base is the LDS origin)
     return L;
 }
-static size_t ggs_lds_bytes(int n_slots, int n_items) {
+static size_t ggs_lds_bytes(int n_slots, int n_items, int pinc_rows, int stage_p) {
     size_t f9 = (size_t)n_slots * 9;
     f9 += (4 - (f9 & 3)) & 3;
-    return ((size_t)PD_GGS_LDS_FIXED + PD_GGS_MAX_PCHUNKS * 68 + f9 + (size_t)n_items * PD_ITEM_VALS) * 4 + (size_t)n_slots * 16;
+    size_t b = ((size_t)PD_GGS_LDS_FIXED + (size_t)pinc_rows * 16 + PD_GGS_MAX_PCHUNKS * 68 + f9 + (size_t)n_items * PD_ITEM_VALS) * 4 +
+               (size_t)n_slots * 16;
+    if (stage_p > 0) b = ((b + 1023) & ~(size_t)1023) + (size_t)PD_GGS_WAVES * 2 * stage_p * 1024;
+    return b;
 }
 
 // decode one frame's 9-vector into R_cv, t_cv, focal (camera_transform.py:80-97 + pytorch3d
@@ -314,43 +323,132 @@ __device__ __forceinline__ void decode_all(const Lds &L, const float *xr, int la
     }
 }
 
+// The same for ONE match per lane on plain fp32 VALU (half the issue cycles of a packed step): the tail of an item whose
+// last 128-match step would be at most half full (300 matches = 2 packed steps + 44: the third packed step ran 34 % full).
+// It accumulates into the .x halves exactly what the packed step accumulates there when its .y match is masked off
+// (+0 contributions), so an item's sums do not depend on which of the two forms ran its tail.
+template <bool EXACT>
+__device__ __forceinline__ void sampson_step1(const float4 pa, bool ina, const float *F, float smax, v2f (&acc)[PD_ITEM_VALS],
+                                              float &mind) {
+#pragma clang fp contract(off)
+    const float u1 = pa.x, v1 = pa.y, u2 = pa.z, v2 = pa.w;
+    const float l0 = __builtin_fmaf(u1, F[0], __builtin_fmaf(v1, F[3], F[6]));
+    const float l1 = __builtin_fmaf(u1, F[1], __builtin_fmaf(v1, F[4], F[7]));
+    const float l2 = __builtin_fmaf(u1, F[2], __builtin_fmaf(v1, F[5], F[8]));
+    const float r0 = __builtin_fmaf(F[0], u2, __builtin_fmaf(F[1], v2, F[2]));
+    const float r1 = __builtin_fmaf(F[3], u2, __builtin_fmaf(F[4], v2, F[5]));
+    const float ee = __builtin_fmaf(l0, u2, __builtin_fmaf(l1, v2, l2));
+    const float bottom = __builtin_fmaf(r1, r1, __builtin_fmaf(r0, r0, __builtin_fmaf(l1, l1, l0 * l0)));
+    const float inv = pd_rcp(bottom);
+    const float top = ee * ee;
+    float sam;
+    if (EXACT) {
+        sam = top / bottom;
+    } else {
+        sam = top * inv;
+        mind = fminf(mind, fabsf(sam - smax));
+    }
+    const float clamped = fminf(sam, smax);
+    acc[11].x += ina ? clamped : 0.0f;
+    const bool va = ina && (sam < smax);
+    const float inv_v = va ? inv : 0.0f;
+    const float ca = (ee + ee) * inv_v;
+    const float sam_v = EXACT ? (va ? sam : 0.0f) : top * inv_v;
+    const float cb = (sam_v + sam_v) * inv_v;
+    acc[9].x += sam_v;
+    acc[10].x += va ? 1.0f : 0.0f;
+    const float g0 = __builtin_fmaf(ca, u2, -(cb * l0)), g1 = __builtin_fmaf(ca, v2, -(cb * l1));
+    const float nbr0 = -(cb * r0), nbr1 = -(cb * r1);
+    acc[0].x = __builtin_fmaf(nbr0, u2, __builtin_fmaf(u1, g0, acc[0].x));
+    acc[1].x = __builtin_fmaf(nbr0, v2, __builtin_fmaf(u1, g1, acc[1].x));
+    acc[2].x = __builtin_fmaf(u1, ca, acc[2].x) + nbr0;
+    acc[3].x = __builtin_fmaf(nbr1, u2, __builtin_fmaf(v1, g0, acc[3].x));
+    acc[4].x = __builtin_fmaf(nbr1, v2, __builtin_fmaf(v1, g1, acc[4].x));
+    acc[5].x = __builtin_fmaf(v1, ca, acc[5].x) + nbr1;
+    acc[6].x += g0;
+    acc[7].x += g1;
+    acc[8].x += ca;
+}
+
+// where an item's matches come from: registers (resident / streamed through registers) or this wave's LDS staging buffer
+// (lane-linear image written by LDS-DMA: match m at byte 16 m)
+struct MatchRegs {
+    const float4 (&M)[8];
+    __device__ __forceinline__ float4 get(int j, int) const { return M[j]; }
+};
+struct MatchLds {
+    const float4 *B;
+    __device__ __forceinline__ float4 get(int j, int lane) const { return B[lane + 64 * j]; }
+};
+
 // the (<= 4) two-match steps of an item as straight-line code per step count: without the per-step branch the
 // scheduler interleaves the independent steps, which hides the VALU dependency latency two waves per SIMD cannot
-#define PD_P2_STEP(M, j) sampson_step2<EXACT>(M[2 * (j)], M[2 * (j) + 1], (lane + 128 * (j)) < cnt, (lane + 128 * (j) + 64) < cnt, Fm, smax, acc2, mind)
-template <bool EXACT>
-__device__ __forceinline__ void item_steps(const float4 (&M)[8], int cnt, int lane, const float *Fm, float smax,
+#define PD_P2_STEP(j) sampson_step2<EXACT>(src.get(2 * (j), lane), src.get(2 * (j) + 1, lane), (lane + 128 * (j)) < cnt, (lane + 128 * (j) + 64) < cnt, Fm, smax, acc2, mind)
+#define PD_P2_TAIL(j)                                                                                           \
+    do {                                                                                                        \
+        if (rem > 64 || (!TAIL1 && rem > 0)) PD_P2_STEP(j);                                                     \
+        else if (TAIL1 && rem > 0) sampson_step1<EXACT>(src.get(2 * (j), lane), (lane + 128 * (j)) < cnt, Fm, smax, acc2, mind); \
+    } while (0)
+// TAIL1: run a tail of <= 64 matches as a single-match step (same sums; the variants that keep matches in registers leave it
+// off -- they sit at the register limit and are latency-, not issue-bound)
+template <bool EXACT, bool TAIL1, typename Src>
+__device__ __forceinline__ void item_steps(const Src &src, int cnt, int lane, const float *Fm, float smax,
                                            v2f (&acc2)[PD_ITEM_VALS], float &mind) {
-    const int npairs = (cnt + 127) >> 7;
-    if (npairs >= 4) {
-        PD_P2_STEP(M, 0); PD_P2_STEP(M, 1); PD_P2_STEP(M, 2); PD_P2_STEP(M, 3);
-    } else if (npairs == 3) {
-        PD_P2_STEP(M, 0); PD_P2_STEP(M, 1); PD_P2_STEP(M, 2);
-    } else if (npairs == 2) {
-        PD_P2_STEP(M, 0); PD_P2_STEP(M, 1);
-    } else if (npairs == 1) {
-        PD_P2_STEP(M, 0);
+    const int full = cnt >> 7, rem = cnt & 127;       // full packed steps; the rest: a packed step, a single-match step or nothing
+    if (full >= 4) {
+        PD_P2_STEP(0); PD_P2_STEP(1); PD_P2_STEP(2); PD_P2_STEP(3);
+    } else if (full == 3) {
+        PD_P2_STEP(0); PD_P2_STEP(1); PD_P2_STEP(2); PD_P2_TAIL(3);
+    } else if (full == 2) {
+        PD_P2_STEP(0); PD_P2_STEP(1); PD_P2_TAIL(2);
+    } else if (full == 1) {
+        PD_P2_STEP(0); PD_P2_TAIL(1);
+    } else {
+        PD_P2_TAIL(0);
     }
 }
 // one work item: the fast pass, and -- when some match of the wave came within the band of the threshold where the
-// 1-ulp quotient could decide differently from the IEEE quotient -- the exact pass over the same registers instead
-__device__ __forceinline__ void item_pass(const float4 (&M)[8], int cnt, int lane, const float *Fm, float smax,
+// 1-ulp quotient could decide differently from the IEEE quotient -- the exact pass over the same data instead
+template <bool TAIL1, typename Src>
+__device__ __forceinline__ void item_pass(const Src &src, int cnt, int lane, const float *Fm, float smax,
                                           v2f (&acc2)[PD_ITEM_VALS]) {
     float mind = __int_as_float(0x7f800000);
 #pragma unroll
     for (int c = 0; c < PD_ITEM_VALS; ++c) acc2[c] = (v2f){0.0f, 0.0f};
-    item_steps<false>(M, cnt, lane, Fm, smax, acc2, mind);
+    item_steps<false, TAIL1>(src, cnt, lane, Fm, smax, acc2, mind);
     const float band = smax * (PD_SAMPSON_BAND_ULPS * 1.1920929e-7f);
     if (__builtin_amdgcn_ballot_w64(mind <= band) != 0ull) {   // wave-uniform, rare (P ~ 1e-7 per match)
 #pragma unroll
         for (int c = 0; c < PD_ITEM_VALS; ++c) acc2[c] = (v2f){0.0f, 0.0f};
-        item_steps<true>(M, cnt, lane, Fm, smax, acc2, mind);
+        item_steps<true, false>(src, cnt, lane, Fm, smax, acc2, mind);
     }
+}
+
+// LDS-DMA of one 1 KiB piece (64 lanes x 16 B, lane-linear at the wave-uniform LDS byte address `lds_dst`) straight from
+// global memory, no VGPR round trip.  Hand-issued: hipcc neither counts it (so nothing drains it at the next s_barrier and a
+// prefetch can cross the serial phases of an iteration) nor waits for it -- every consumer waits with pd_vmcnt<> itself,
+// and the kernel drains before it exits (an LDS-DMA landing after the workgroup's LDS was handed on would corrupt it).
+__device__ __forceinline__ void pd_glds16(const float4 *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);   // wave-uniform by construction; the "s" constraint needs it provable
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void pd_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // --------------------------------------------------------------------------------------------
 // the kernel
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, int B, int n_slots) {
+// STAGE_P > 0: waves that own several items stream them through a per-wave double buffer in LDS filled by LDS-DMA
+// (STAGE_P pieces of 1 KiB = up to 64 STAGE_P matches per item), the next item in flight while the current one is computed,
+// the first item of the next iteration in flight across the serial phases.  STAGE_P = 0: through registers (any item size).
+// RESIDENT: every wave owns at most one item (n_slots == 8, the k = ceil(items / 8) regime): its matches stay in registers for
+// the whole launch -- a compile-time variant, so the other variants do not carry those 32 registers.
+template <int STAGE_P, bool RESIDENT>
+__global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, int B, int n_slots, int pinc_rows, int items_cap) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x % B, wg = blockIdx.x / B;   // XCD-aware: see header comment
@@ -358,7 +456,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
     const int N = P.N, k = P.k;
     const int nW = k * PD_GGS_WAVES;
     const int n_items = D.n_items;
-    const Lds L = carve(smem, n_slots);
+    const Lds L = carve(smem, n_slots, pinc_rows, items_cap);
     float *xg = P.x + (size_t)b * N * PD_POSE_DIM;
     u64 *xchg = P.xchg ? P.xchg + (size_t)b * 2 * P.xchg_stride : nullptr;
 
@@ -390,18 +488,38 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
     __syncthreads();
     // matches of this wave's first item stay in registers for the whole launch when every wave owns
     // at most one item (the k = ceil(items/8) regime): no per-iteration match traffic at all
-    const bool resident = (n_slots == PD_GGS_WAVES);
-    float4 mres[8];
-    {
+    constexpr bool resident = RESIDENT;
+    float4 mres[RESIDENT ? 8 : 1];
+    if (RESIDENT) {
         const int4 e = L.itab[wave];
         const int last = e.y > 0 ? e.y - 1 : 0;
         const float4 *pts = D.pts + e.x;
 #pragma unroll
-        for (int st = 0; st < 8; ++st) {
+        for (int st = 0; st < (RESIDENT ? 8 : 1); ++st) {
             const int m = lane + 64 * st;
-            mres[st] = (resident && e.y > 0) ? pts[m < e.y ? m : last] : make_float4(0.f, 0.f, 0.f, 0.f);
+            mres[st] = (e.y > 0) ? pts[m < e.y ? m : last] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+
+    // LDS staging of the match pass (STAGE_P > 0, several items per wave): this wave's items, its double buffer, and the
+    // first item already on its way
+    const int my_first = wg * PD_GGS_WAVES + wave;
+    const int my_cnt = my_first < n_items ? (n_items - my_first + nW - 1) / nW : 0;
+    const bool staged = STAGE_P > 0 && !resident && my_cnt > 0;
+    const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(L.stage + wave * (2 * STAGE_P * 256)));
+    const float4 *stage_ptr = (const float4 *)(L.stage + wave * (2 * STAGE_P * 256));
+    int pb = 0;                                   // buffer that holds (or is receiving) the item computed next
+    auto stage_item = [&](int slot, int buf) {
+        const int4 e = L.itab[slot];
+        const float4 *pts = D.pts + e.x;
+        const int last = e.y - 1;
+#pragma unroll
+        for (int q = 0; q < (STAGE_P > 0 ? STAGE_P : 1); ++q) {
+            const int m = lane + 64 * q;
+            pd_glds16(pts + (m < e.y ? m : last), stage_lds + (unsigned)(buf * STAGE_P + q) * 1024u);
+        }
+    };
+    if (staged) stage_item(wave, 0);
 
     // P3b role of this thread, constant for the launch: thread (fb_n, fb_c) sums component fb_c of the
     // incidences of frame fb_n (frames 0..31 in one pass) and owns the matching gradient slot
@@ -475,8 +593,15 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 for (int c = 0; c < 9; ++c) Fm[c] = L.F[s * 9 + c];
                 // two 64-match steps per pass: lane handles matches lane + 64*(2j) and lane + 64*(2j+1) together
                 v2f acc2[PD_ITEM_VALS];
-                if (resident) {   // straight from the resident registers (no copies)
-                    item_pass(mres, e.y, lane, Fm, P.sampson_max, acc2);
+                if constexpr (RESIDENT) {   // straight from the resident registers (no copies)
+                    item_pass<false>(MatchRegs{mres}, e.y, lane, Fm, P.sampson_max, acc2);
+                } else if constexpr (STAGE_P > 0) {
+                    // the next item of this wave (or its first one, for the next iteration: the matches never change)
+                    // goes into the other buffer while this one is computed; STAGE_P pieces stay in flight
+                    stage_item(r + 1 < my_cnt ? s + 8 : wave, pb ^ 1);
+                    pd_vmcnt<STAGE_P>();
+                    item_pass<true>(MatchLds{stage_ptr + pb * (STAGE_P * 64)}, e.y, lane, Fm, P.sampson_max, acc2);
+                    pb ^= 1;
                 } else {
                     // stream this item: all (<= 8) lines in flight at once, indices clamped (no
                     // predicated loads), out-of-range lanes are masked in the arithmetic instead
@@ -488,7 +613,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                         const int m = lane + 64 * st;
                         mb[st] = pts[m < e.y ? m : last];
                     }
-                    item_pass(mb, e.y, lane, Fm, P.sampson_max, acc2);
+                    item_pass<false>(MatchRegs{mb}, e.y, lane, Fm, P.sampson_max, acc2);
                 }
                 float acc[PD_ITEM_VALS];
 #pragma unroll
@@ -559,7 +684,10 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 }
             }
             __syncthreads();
-            if (L.ctl[1] != 0.0f) return;   // a bounded spin gave up: abort the whole workgroup
+            if (L.ctl[1] != 0.0f) {   // a bounded spin gave up: abort the whole workgroup
+                if (STAGE_P > 0) pd_vmcnt<0>();
+                return;
+            }
             PD_PROF(2);
 
             // ---- P3a: pair backward, one (frame, incident pair) per thread, flat over the workgroup ----
@@ -702,6 +830,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
 #pragma unroll
         for (int c = 0; c < 9; ++c) xg[lane * 9 + c] = xr[c];
     }
+    if (STAGE_P > 0) pd_vmcnt<0>();   // the look-ahead LDS-DMA of the last item must land before the LDS is handed on
 }
 
 // --------------------------------------------------------------------------------------------
@@ -761,7 +890,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
     const int nW = k * PD_GGS_WAVES;
     const int n_items = D.n_items;          // == D.n_pairs (one item per pair)
     const int n_inc = 2 * D.n_pairs;
-    const Lds L = carve(smem, n_slots);
+    const Lds L = carve(smem, n_slots, PD_GGS_PINC_ROWS, n_slots);
     float *xg = P.x + (size_t)b * N * PD_POSE_DIM;
     u64 *xbase = P.xchg + (size_t)b * 2 * P.xchg_stride;
     // LDS reuse: L.item holds this workgroup's item sums [n_slots][12]; L.pinc rows [0, 2 n_slots <= 512) the results of
@@ -859,7 +988,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                     for (int c = 0; c < 9; ++c) Fm[c] = L.F[s * 9 + c];
                     v2f acc2[PD_ITEM_VALS];
                     if (resident) {
-                        item_pass(mres, e.y, lane, Fm, P.sampson_max, acc2);
+                        item_pass<false>(MatchRegs{mres}, e.y, lane, Fm, P.sampson_max, acc2);
                     } else {
                         float4 mb[8];
                         const float4 *pts = D.pts + e.x;
@@ -869,7 +998,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                             const int m = lane + 64 * q;
                             mb[q] = pts[m < e.y ? m : last];
                         }
-                        item_pass(mb, e.y, lane, Fm, P.sampson_max, acc2);
+                        item_pass<false>(MatchRegs{mb}, e.y, lane, Fm, P.sampson_max, acc2);
                     }
                     float acc[PD_ITEM_VALS];
 #pragma unroll
@@ -1009,10 +1138,17 @@ int pd_mark_use(pd_engine *eng, hipStream_t s) {
     return PD_OK;
 }
 
-static int upload_seq_table(pd_engine *eng) {
-    std::vector<PdSeqDesc> d(eng->max_B);
-    for (int i = 0; i < eng->max_B; ++i) d[i] = eng->seqs[i].desc;
-    PD_HIP_CHECK(hipMemcpy(eng->d_seqs, d.data(), sizeof(PdSeqDesc) * eng->max_B, hipMemcpyHostToDevice));
+// one slot's descriptor -> device (other slots may hold descriptors the ingestion kernels wrote on the device)
+static int upload_seq_desc(pd_engine *eng, int seq) {
+    PD_HIP_CHECK(hipMemcpy(eng->d_seqs + seq, &eng->seqs[seq].desc, sizeof(PdSeqDesc), hipMemcpyHostToDevice));
+    return PD_OK;
+}
+
+int pd_wait_uploads(pd_engine *eng, hipStream_t s) {
+    if (!eng->upload_done) return PD_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return PD_OK;   // pd_sample_phase waits before the replay
+    PD_HIP_CHECK(hipStreamWaitEvent(s, eng->upload_done, 0));
     return PD_OK;
 }
 
@@ -1026,9 +1162,11 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     // nothing of THIS engine in flight may still read the old tables; other engines (other batches of a pipeline) keep
     // running: no device-wide synchronisation here, and the blob is re-used when the new tables fit
     if (eng->last_use) PD_HIP_CHECK(hipEventSynchronize(eng->last_use));
+    if (eng->upload_done) PD_HIP_CHECK(hipEventSynchronize(eng->upload_done));   // a pending device-side build of this slot
+    eng->seqs[seq].device_built = false;
     if (M == 0) {
         pd_ggs_free_seq(eng->seqs[seq]);
-        return upload_seq_table(eng);
+        return upload_seq_desc(eng, seq);
     }
     if (!kp1 || !kp2 || !i12 || M < 0 || n_frames <= 0 || n_frames > PD_MAX_FRAMES || n_frames > eng->max_N ||
         height <= 0 || width <= 0) {
@@ -1078,6 +1216,8 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     }
     pair_item_off.push_back((int)items.size());
     const int n_pairs = (int)pair_ij.size(), n_items = (int)items.size();
+    int max_item_len = 0;
+    for (const int4 &it : items) max_item_len = std::max(max_item_len, it.z);
     for (int p = 0; p < n_pairs; ++p)
         if (pair_item_off[p + 1] - pair_item_off[p] > 0xffff) {
             pd_set_error("pd_ggs_set_matches: a frame pair holds too many matches");
@@ -1174,7 +1314,8 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     h.desc.sc = (float)std::min(height, width) / 2.0f;   // opencv_from_cameras_projection scale
     h.desc.cx = (float)width / 2.0f;
     h.desc.cy = (float)height / 2.0f;
-    return upload_seq_table(eng);
+    h.max_item_len = max_item_len;
+    return upload_seq_desc(eng, seq);
 }
 
 // Zeroes the exchange granules before every launch (tags restart at 1 per launch).  A KERNEL rather than
@@ -1186,7 +1327,9 @@ __global__ void pd_ggs_zero_kernel(unsigned long long *p, size_t n) {
 }
 
 int pd_ggs_init() {
-    PD_HIP_CHECK(hipFuncSetAttribute((const void *)pd_ggs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const void *variants[] = {(const void *)pd_ggs_kernel<0, true>, (const void *)pd_ggs_kernel<0, false>, (const void *)pd_ggs_kernel<3, false>,
+                              (const void *)pd_ggs_kernel<5, false>, (const void *)pd_ggs_kernel<6, false>};
+    for (const void *f : variants) PD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PD_HIP_CHECK(hipFuncSetAttribute((const void *)pd_ggs2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return PD_OK;
 }
@@ -1226,14 +1369,33 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
         const PdSeqDesc &d = eng->seqs[b].desc;
         two_hop = d.n_pchunks > 1 && d.single_item_pairs;
     }
-    int n_slots = 0;
+    // one-hop kernel: backward rows of one chunk of pairs (both sides); LDS staging of the match pass when every item fits a
+    // staging buffer (<= 384 matches) -- both only shrink / extend the LDS image, the arithmetic is the same
+    int max_pairs = 0, max_len = 0;
+    for (int b = 0; b < B; ++b) {
+        max_pairs = std::max(max_pairs, eng->seqs[b].desc.n_pairs);
+        max_len = std::max(max_len, eng->seqs[b].max_item_len);
+    }
+    const int pinc_one_hop = std::min(PD_GGS_PINC_ROWS, 2 * std::min(PD_GGS_THREADS, std::max(max_pairs, 1)));
+    int stage_want = 0;
+    if (!(cfg->reserved & PD_GGS_CFG_NO_LDS_STAGING) && max_len > 0) {
+        const int pieces = (max_len + 63) / 64;
+        stage_want = pieces <= 3 ? 3 : pieces <= 5 ? 5 : pieces <= 6 ? 6 : 0;
+    }
+    int n_slots = 0, pinc_rows = PD_GGS_PINC_ROWS, stage_p = 0;
     size_t lds = 0;
     for (int pass = 0; pass < 2; ++pass) {
         int kk = k;
         for (;;) {
             const int rounds = (max_items + kk * PD_GGS_WAVES - 1) / (kk * PD_GGS_WAVES);
             n_slots = rounds * PD_GGS_WAVES;
-            lds = ggs_lds_bytes(n_slots, two_hop ? n_slots : max_items);
+            pinc_rows = two_hop ? PD_GGS_PINC_ROWS : pinc_one_hop;
+            stage_p = (!two_hop && rounds > 1) ? stage_want : 0;     // one item per wave: matches are register resident
+            lds = ggs_lds_bytes(n_slots, two_hop ? n_slots : max_items, pinc_rows, stage_p);
+            if (lds > 160 * 1024 && stage_p > 0) {                   // staging is optional: without it first
+                stage_p = 0;
+                lds = ggs_lds_bytes(n_slots, two_hop ? n_slots : max_items, pinc_rows, 0);
+            }
             if (lds <= 160 * 1024 || kk >= device_cus / B) break;
             ++kk;
         }
@@ -1253,6 +1415,8 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
         pd_set_error("pd_ggs: %d work items need %zu B of LDS per workgroup (> 160 KiB) at B=%d", max_items, lds, B);
         return PD_ERR_UNSUPPORTED;
     }
+    out->pinc_rows = pinc_rows;
+    out->stage_p = stage_p;
     out->k = k;
     out->n_slots = n_slots;
     out->lds = (int)lds;
@@ -1271,9 +1435,11 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     PdGgsPlan plan;
     int prc = pd_ggs_plan(eng, B, N, cfg, &plan);
     if (prc) return prc;
+    if ((prc = pd_wait_uploads(eng, s))) return prc;
     const int k = plan.k, n_slots = plan.n_slots;
     const size_t lds = (size_t)plan.lds;
     const bool two_hop = plan.two_hop != 0;
+    const int pinc_rows = plan.pinc_rows, items_cap = plan.max_items;
     PdGgsParams P;
     memset(&P, 0, sizeof(P));
     P.seqs = eng->d_seqs;
@@ -1305,8 +1471,15 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     }
     if (two_hop)
         hipLaunchKernelGGL(pd_ggs2_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots);
-    else
-        hipLaunchKernelGGL(pd_ggs_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots);
+    else {
+        void (*kern)(PdGgsParams, int, int, int, int) =
+            n_slots == PD_GGS_WAVES ? pd_ggs_kernel<0, true>
+            : plan.stage_p == 6 ? pd_ggs_kernel<6, false>
+            : plan.stage_p == 5 ? pd_ggs_kernel<5, false>
+            : plan.stage_p == 3 ? pd_ggs_kernel<3, false>
+                                : pd_ggs_kernel<0, false>;
+        hipLaunchKernelGGL(kern, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots, pinc_rows, items_cap);
+    }
     PD_HIP_CHECK(hipGetLastError());
     return pd_mark_use(eng, s);
 }

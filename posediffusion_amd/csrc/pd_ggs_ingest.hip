@@ -1,0 +1,432 @@
+// pd_ggs_ingest.hip -- asynchronous, device-resident ingestion of pairwise matches (the match container half of
+// SURVEY.md section 8f row N2).
+//
+// Replaces the per-call host prep of util/geometry_guided_sampling.py:16-45 -- the reference re-uploads kp1 / kp2 / i12 on
+// EVERY guided step (:19-24), i.e. on its timed path -- and the synchronous host-side pd_ggs_set_matches for callers that
+// stream batches: inputs are device-accessible arrays (device memory or pinned host memory) in the reference's own format
+// (kp1 / kp2 float64 [M,2], i12 int64 [M,2], demo.py:82-84), CSR-packed over the sequences of a batch; the fp64 -> fp32 cast
+// of :167, the pair key of :26-27, the stable sort by pair and every table pd_ggs_kernel reads are built by four small
+// kernels on the caller's stream.  No host synchronisation, no allocation in steady state, no host threads.
+//
+// Stable counting sort by pair key (the order of the matches inside a pair is the upload order, exactly like the host path,
+// so sums -- and results -- are bitwise those of pd_ggs_set_matches):
+//   ingest_hist     tile of 1024 matches per workgroup: validate, key = i * N + j, LDS histogram -> hist[tile][key]
+//   ingest_tables   one workgroup per sequence: per-key totals and per-(tile, key) bases, scan over the keys, compaction
+//                   of the non-empty pairs, work items (<= 512 matches), incidence positions per chunk / per frame, and
+//                   the sequence descriptor itself (written on the device: the host never learns the counts)
+//   ingest_scatter  one wavefront per tile walks its matches IN ORDER, 64 at a time; rank among equal keys of a round
+//                   by ballot -> pts[base + rank]
+// Because the host never sees the counts, launch shapes are planned from CAPACITIES (pd_match_hints or worst case);
+// kernels read the actual counts from the device descriptor.  A violated hint / out-of-range frame index empties the
+// slot and raises bit 2 / bit 1 of the engine's async error word (pd_check_async_error).
+#include "pd_internal.h"
+
+#include <algorithm>
+#include <string.h>
+
+#define ING_TILE 1024
+#define ING_MAX_SEQS 32          // sequences per launch (kernel-argument table); larger batches go in slices
+#define ING_TABLE_THREADS 512
+
+struct IngestSeq {
+    long long first;             // first row of this sequence in kp1 / kp2 / i12
+    int M, n_tiles;
+    char *blob;                  // slot blob (layout below)
+    PdSeqDesc *desc;             // &eng->d_seqs[slot]
+};
+struct IngestArgs {
+    IngestSeq s[ING_MAX_SEQS];
+    const double *kp1, *kp2;
+    const long long *i12;
+    int N, P_cap, I_cap, C_cap, per_pair_cap;
+    float sc, cx, cy;
+    unsigned int *err_flag;
+};
+
+// blob layout, by capacity (so that it is known before the counts are)
+struct IngestLayout {
+    size_t pts, pij, pio, itm, ptb, pco, gps, gio, cnt, keys, hist, total;
+};
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+__host__ __device__ static inline void ingest_layout(int M, int N, int P_cap, int I_cap, int C_cap, IngestLayout &L) {
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t n_tiles = ((size_t)M + ING_TILE - 1) / ING_TILE;
+    L.pts = 0;
+    L.pij = al(L.pts + sizeof(float4) * (size_t)M);
+    L.pio = al(L.pij + sizeof(int2) * (size_t)P_cap);
+    L.itm = al(L.pio + sizeof(int) * ((size_t)P_cap + 1));
+    L.ptb = al(L.itm + sizeof(int4) * (size_t)I_cap);
+    L.pco = al(L.ptb + sizeof(int4) * (size_t)P_cap);
+    L.gps = al(L.pco + sizeof(int) * (size_t)C_cap * (N + 1));
+    L.gio = al(L.gps + sizeof(int2) * (size_t)P_cap);
+    L.cnt = al(L.gio + sizeof(int) * ((size_t)N + 1));
+    L.keys = al(L.cnt + sizeof(int) * ((size_t)N * N + 1));
+    L.hist = al(L.keys + sizeof(int) * (size_t)M);
+    L.total = al(L.hist + sizeof(int) * n_tiles * (size_t)N * N);
+}
+
+// ---- kernel 1: keys + per-tile histograms ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ingest_hist_kernel(IngestArgs A) {
+    extern __shared__ int sh_hist[];                  // [N * N]
+    const IngestSeq S = A.s[blockIdx.y];
+    const int tile = blockIdx.x;
+    if (tile >= S.n_tiles) return;
+    IngestLayout L;
+    ingest_layout(S.M, A.N, A.P_cap, A.I_cap, A.C_cap, L);
+    const int NN = A.N * A.N;
+    for (int q = threadIdx.x; q < NN; q += 256) sh_hist[q] = 0;
+    __syncthreads();
+    int *keys = (int *)(S.blob + L.keys);
+    const int m0 = tile * ING_TILE, m1 = min(S.M, m0 + ING_TILE);
+    for (int m = m0 + threadIdx.x; m < m1; m += 256) {
+        const long long a = A.i12[2 * (S.first + m)], c = A.i12[2 * (S.first + m) + 1];
+        int key = 0;
+        if (a < 0 || a >= A.N || c < 0 || c >= A.N) atomicOr(A.err_flag, 2u);   // frame index out of range
+        else key = (int)(a * A.N + c);                                           // geometry_guided_sampling.py:26-27
+        keys[m] = key;
+        atomicAdd(&sh_hist[key], 1);
+    }
+    __syncthreads();
+    int *hist = (int *)(S.blob + L.hist) + (size_t)tile * NN;
+    for (int q = threadIdx.x; q < NN; q += 256) hist[q] = sh_hist[q];
+}
+
+// ---- kernel 2: every table of the descriptor ------------------------------------------------------------------------
+// inclusive scan of one int per thread over the workgroup (ING_TABLE_THREADS threads); returns the inclusive value, the
+// total through `total`.  scratch: [ING_TABLE_THREADS / 64 + 1] ints of LDS.
+__device__ __forceinline__ int block_scan_incl(int v, int *scratch, int &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) scratch[wave] = x;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < ING_TABLE_THREADS / 64; ++w) {
+        const int s = scratch[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    total = tot;
+    return x + base;
+}
+
+__global__ __launch_bounds__(ING_TABLE_THREADS) void ingest_tables_kernel(IngestArgs A) {
+    extern __shared__ int sh[];
+    const IngestSeq S = A.s[blockIdx.x];
+    IngestLayout L;
+    ingest_layout(S.M, A.N, A.P_cap, A.I_cap, A.C_cap, L);
+    const int N = A.N, NN = N * N, tid = threadIdx.x;
+    // LDS: totals[NN] | pidx[NN] (pair index of a key, -1 if empty) | pair_ij[P_cap] (i | j << 8) | pos0/pos1[P_cap] (shorts
+    // packed in one int) | deg / offsets [C_cap + 1][N + 1] | scan scratch [16] | flags [4]
+    int *totals = sh;
+    int *pidx = totals + NN;
+    int *pij = pidx + NN;
+    int *ppos = pij + A.P_cap;
+    int *foff = ppos + A.P_cap;                     // [(C_cap + 1)][N + 1]
+    int *scratch = foff + (A.C_cap + 1) * (N + 1);
+    int *flags = scratch + 16;
+    int *hist = (int *)(S.blob + L.hist);
+    int *cnt = (int *)(S.blob + L.cnt);
+    if (tid < 4) flags[tid] = 0;
+    // (1) totals per key; hist[tile][key] becomes the exclusive prefix over tiles
+    for (int key = tid; key < NN; key += ING_TABLE_THREADS) {
+        int run = 0;
+        for (int t = 0; t < S.n_tiles; ++t) {
+            const int h = hist[(size_t)t * NN + key];
+            hist[(size_t)t * NN + key] = run;
+            run += h;
+        }
+        totals[key] = run;
+    }
+    __syncthreads();
+    // (2) scans over the keys, ING_TABLE_THREADS keys per pass: first match of the key, pair index, first work item
+    int off_base = 0, pair_base = 0, item_base = 0, multi = 0;
+    int4 *items = (int4 *)(S.blob + L.itm);
+    int2 *pair_ij_g = (int2 *)(S.blob + L.pij);
+    int *pair_item_off = (int *)(S.blob + L.pio);
+    int4 *ptab = (int4 *)(S.blob + L.ptb);
+    for (int k0 = 0; k0 < NN; k0 += ING_TABLE_THREADS) {
+        const int key = k0 + tid;
+        const int m = key < NN ? totals[key] : 0;
+        const int nch = (m + PD_ITEM_MAX_MATCHES - 1) / PD_ITEM_MAX_MATCHES;
+        int t_off, t_pair, t_item;
+        const int off = block_scan_incl(m, scratch, t_off) - m + off_base;
+        const int p = block_scan_incl(m > 0 ? 1 : 0, scratch, t_pair) - (m > 0 ? 1 : 0) + pair_base;
+        const int it = block_scan_incl(nch, scratch, t_item) - nch + item_base;
+        if (key < NN) {
+            cnt[key] = off;                                   // key_off: first sorted row of the key
+            pidx[key] = m > 0 ? p : -1;
+            if (m > 0 && p < A.P_cap && it + nch <= A.I_cap) {
+                const int i = key / N, j = key - i * N;
+                pij[p] = i | (j << 8);
+                pair_ij_g[p] = make_int2(i, j);
+                pair_item_off[p] = it;
+                ptab[p] = make_int4(i | (j << 8), it, nch, 0);
+                int start = off;
+                for (int c = 0; c < nch; ++c) {               // the host path's split: m / nch (+1 for the first m % nch)
+                    const int len = m / nch + (c < m % nch ? 1 : 0);
+                    items[it + c] = make_int4(p, start, len, 0);
+                    start += len;
+                }
+                if (nch > 1) multi = 1;
+                if (A.per_pair_cap > 0 && m > A.per_pair_cap) atomicOr(&flags[0], 4);
+            }
+        }
+        off_base += t_off;
+        pair_base += t_pair;
+        item_base += t_item;
+    }
+    const int n_pairs = pair_base, n_items = item_base;
+    if (multi) atomicOr(&flags[1], 1);
+    const int n_pchunks = (n_pairs + PD_GGS_THREADS - 1) / PD_GGS_THREADS;
+    if (tid == 0) {
+        if (n_pairs > A.P_cap || n_items > A.I_cap || n_pchunks > A.C_cap || n_pchunks > PD_GGS_MAX_PCHUNKS || off_base != S.M)
+            atomicOr(&flags[0], 4);
+    }
+    __syncthreads();
+    const bool bad = flags[0] != 0;
+    const int np = bad ? 0 : n_pairs;
+    if (!bad && tid == 0) pair_item_off[n_pairs] = n_items;
+    // (3) incidence positions.  Thread (c, n): c < n_pchunks walks chunk c's pairs for frame n (positions among the chunk's
+    // incidences, frame-sorted: ptab.w / pchunk_off); c == C_cap walks ALL pairs (gpos / ginc_off of the two-hop kernel).
+    // Pass 1 counts the frame's incidences, a serial scan over the frames gives the offsets, pass 2 assigns the rows.
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int q = tid; q < (A.C_cap + 1) * N; q += ING_TABLE_THREADS) {
+            const int c = q / N, n = q - c * N;
+            const bool all = c == A.C_cap;
+            if (!all && c >= n_pchunks) {
+                if (pass == 0) foff[c * (N + 1) + n] = 0;
+                continue;
+            }
+            const int p_lo = all ? 0 : c * PD_GGS_THREADS, p_hi = all ? np : min(np, p_lo + PD_GGS_THREADS);
+            int row = pass == 0 ? 0 : foff[c * (N + 1) + n];
+            for (int p = p_lo; p < p_hi; ++p) {
+                const int ij = pij[p];
+                const int hit0 = (ij & 0xff) == n, hit1 = (ij >> 8) == n;
+                if (pass == 1) {
+                    if (all) {
+                        int2 *gpos = (int2 *)(S.blob + L.gps);
+                        if (hit0) gpos[p].x = row;
+                        if (hit1) gpos[p].y = row + hit0;
+                    } else {
+                        // two different threads (frames i and j) write the two halves of ppos[p]: 16-bit stores
+                        unsigned short *pp = (unsigned short *)&ppos[p];
+                        if (hit0) pp[0] = (unsigned short)row;
+                        if (hit1) pp[1] = (unsigned short)(row + hit0);
+                    }
+                }
+                row += hit0 + hit1;
+            }
+            if (pass == 0) foff[c * (N + 1) + n] = row;        // degree
+        }
+        __syncthreads();
+        if (pass == 0) {
+            if (tid <= A.C_cap) {                              // exclusive scan over the frames of chunk `tid`
+                int run = 0;
+                for (int n = 0; n < N; ++n) {
+                    const int d = foff[tid * (N + 1) + n];
+                    foff[tid * (N + 1) + n] = run;
+                    run += d;
+                }
+                foff[tid * (N + 1) + N] = run;
+            }
+            __syncthreads();
+        }
+    }
+    int *pchunk_off = (int *)(S.blob + L.pco);
+    for (int q = tid; q < A.C_cap * (N + 1); q += ING_TABLE_THREADS) pchunk_off[q] = foff[q];
+    int *ginc_off = (int *)(S.blob + L.gio);
+    for (int q = tid; q <= N; q += ING_TABLE_THREADS) ginc_off[q] = foff[A.C_cap * (N + 1) + q];
+    for (int p = tid; p < np; p += ING_TABLE_THREADS) ptab[p].w = ppos[p];
+    // (4) the descriptor (an emptied slot on error: the GGS kernels then find nothing to do)
+    if (tid == 0) {
+        PdSeqDesc D;
+        D.pts = (const float4 *)(S.blob + L.pts);
+        D.pair_ij = (const int2 *)(S.blob + L.pij);
+        D.pair_item_off = (const int *)(S.blob + L.pio);
+        D.items = (const int4 *)(S.blob + L.itm);
+        D.ptab = (const int4 *)(S.blob + L.ptb);
+        D.pchunk_off = (const int *)(S.blob + L.pco);
+        D.n_pchunks = bad ? 0 : n_pchunks;
+        D.gpos = (const int2 *)(S.blob + L.gps);
+        D.ginc_off = (const int *)(S.blob + L.gio);
+        D.single_item_pairs = flags[1] ? 0 : 1;
+        D.M = bad ? 1 : S.M;                 // (M only scales 1 / M; never 0: the kernels divide by it)
+        D.n_pairs = np;
+        D.n_items = bad ? 0 : n_items;
+        D.n_frames = N;
+        D.sc = A.sc;
+        D.cx = A.cx;
+        D.cy = A.cy;
+        D.pad = 0;
+        *S.desc = D;
+        if (bad) atomicOr(A.err_flag, 4u);
+    }
+}
+
+// ---- kernel 3: stable scatter ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ingest_scatter_kernel(IngestArgs A) {
+    extern __shared__ int sh_next[];                  // [N * N] next free sorted row of each key for THIS tile
+    const IngestSeq S = A.s[blockIdx.y];
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    if (tile >= S.n_tiles) return;
+    IngestLayout L;
+    ingest_layout(S.M, A.N, A.P_cap, A.I_cap, A.C_cap, L);
+    const int NN = A.N * A.N;
+    const int *cnt = (const int *)(S.blob + L.cnt);
+    const int *hist = (const int *)(S.blob + L.hist) + (size_t)tile * NN;
+    for (int q = lane; q < NN; q += 64) sh_next[q] = cnt[q] + hist[q];
+    __syncthreads();
+    const int *keys = (const int *)(S.blob + L.keys);
+    float4 *pts = (float4 *)(S.blob + L.pts);
+    const int m0 = tile * ING_TILE, m1 = min(S.M, m0 + ING_TILE);
+    for (int r0 = m0; r0 < m1; r0 += 64) {
+        const int m = r0 + lane;
+        const bool act = m < m1;
+        const int key = act ? keys[m] : -1;
+        int dst = -1;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(act);
+        while (todo) {                                 // one pass per distinct key of the round (1-2 for pair-grouped input)
+            const int leader = __builtin_ctzll(todo);
+            const int k = __builtin_amdgcn_readlane(key, leader);
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(act && key == k);
+            if (act && key == k) dst = sh_next[k] + __builtin_popcountll(same & ((1ull << lane) - 1ull));
+            __builtin_amdgcn_wave_barrier();
+            if (lane == leader) sh_next[k] += __builtin_popcountll(same);
+            __builtin_amdgcn_wave_barrier();
+            todo &= ~same;
+        }
+        if (act) {
+            const long long g = S.first + m;
+            // .float() of geometry_guided_sampling.py:167 (round-to-nearest fp64 -> fp32), as the host path casts
+            pts[dst] = make_float4((float)A.kp1[2 * g], (float)A.kp1[2 * g + 1], (float)A.kp2[2 * g], (float)A.kp2[2 * g + 1]);
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+static size_t tables_lds_bytes(int N, int P_cap, int C_cap) {
+    return sizeof(int) * ((size_t)2 * N * N + 2 * (size_t)P_cap + (size_t)(C_cap + 1) * (N + 1) + 16 + 4);
+}
+
+extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n_seqs, const int64_t *seq_offsets,
+                                            const double *kp1, const double *kp2, const int64_t *i12, int n_frames, int height,
+                                            int width, const pd_match_hints *hints, void *stream) {
+    if (!eng || n_seqs <= 0 || seq_first < 0 || seq_first + n_seqs > eng->max_B || !seq_offsets || !kp1 || !kp2 || !i12) {
+        pd_set_error("pd_ggs_set_matches_csr_async: bad engine, slot range [%d, %d) or NULL pointer", seq_first, seq_first + n_seqs);
+        return PD_ERR_INVALID_ARG;
+    }
+    const int N = n_frames;
+    if (N <= 0 || N > PD_MAX_FRAMES || N > eng->max_N || height <= 0 || width <= 0) {
+        pd_set_error("pd_ggs_set_matches_csr_async: invalid n_frames=%d (<= %d) or image size %dx%d", N, std::min(PD_MAX_FRAMES, eng->max_N),
+                     height, width);
+        return PD_ERR_INVALID_ARG;
+    }
+    PD_HIP_CHECK(hipSetDevice(eng->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int hint_pairs = hints ? hints->max_pairs : 0, hint_per_pair = hints ? hints->max_matches_per_pair : 0;
+    if (hint_pairs < 0 || hint_per_pair < 0) {
+        pd_set_error("pd_ggs_set_matches_csr_async: negative hint");
+        return PD_ERR_INVALID_ARG;
+    }
+    // the engine's own in-flight work may still read the slots' tables: a DEVICE-side wait, the host does not block
+    if (eng->last_use) PD_HIP_CHECK(hipStreamWaitEvent(s, eng->last_use, 0));
+    for (int b0 = 0; b0 < n_seqs; b0 += ING_MAX_SEQS) {
+        const int nb = std::min(ING_MAX_SEQS, n_seqs - b0);
+        IngestArgs A;
+        memset(&A, 0, sizeof(A));
+        A.kp1 = kp1;
+        A.kp2 = kp2;
+        A.i12 = (const long long *)i12;
+        A.N = N;
+        A.per_pair_cap = hint_per_pair;
+        A.sc = (float)std::min(height, width) / 2.0f;   // opencv_from_cameras_projection scale
+        A.cx = (float)width / 2.0f;
+        A.cy = (float)height / 2.0f;
+        A.err_flag = eng->d_err;
+        // one capacity set for the whole slice (the kernels index the layout by it): from the largest sequence
+        long long M_max = 0;
+        for (int b = 0; b < nb; ++b) {
+            const long long M = seq_offsets[b0 + b + 1] - seq_offsets[b0 + b];
+            if (M <= 0 || M > 0x7fffffff) {
+                pd_set_error("pd_ggs_set_matches_csr_async: sequence %d holds %lld matches (need 1 .. 2^31-1; clear a slot with "
+                             "pd_ggs_set_matches(M = 0))", seq_first + b0 + b, M);
+                return PD_ERR_INVALID_ARG;
+            }
+            M_max = std::max(M_max, M);
+        }
+        const int P_cap = hint_pairs > 0 ? hint_pairs : (int)std::min<long long>((long long)N * N, M_max);
+        const bool single = hint_per_pair > 0 && hint_per_pair <= PD_ITEM_MAX_MATCHES;
+        const int I_cap = single ? P_cap : P_cap + (int)(M_max / PD_ITEM_MAX_MATCHES) + 1;
+        const int C_cap = (P_cap + PD_GGS_THREADS - 1) / PD_GGS_THREADS;
+        if (C_cap > PD_GGS_MAX_PCHUNKS) {
+            pd_set_error("pd_ggs_set_matches_csr_async: up to %d frame pairs (max %d): pass pd_match_hints.max_pairs", P_cap,
+                         PD_GGS_MAX_PCHUNKS * PD_GGS_THREADS);
+            return PD_ERR_UNSUPPORTED;
+        }
+        const size_t lds_tab = tables_lds_bytes(N, P_cap, C_cap);
+        if (lds_tab > 160 * 1024) {
+            pd_set_error("pd_ggs_set_matches_csr_async: tables need %zu B of LDS", lds_tab);
+            return PD_ERR_UNSUPPORTED;
+        }
+        A.P_cap = P_cap;
+        A.I_cap = I_cap;
+        A.C_cap = C_cap;
+        int max_tiles = 0;
+        for (int b = 0; b < nb; ++b) {
+            const int slot = seq_first + b0 + b;
+            const int M = (int)(seq_offsets[b0 + b + 1] - seq_offsets[b0 + b]);
+            IngestLayout L;
+            ingest_layout(M, N, P_cap, I_cap, C_cap, L);
+            PdSeqHost &h = eng->seqs[slot];
+            if (h.blob_bytes < L.total) {
+                // first use of the slot at this capacity: the only allocation (synchronous).  The old blob may still be read by
+                // work in flight, so it is parked until the engine is destroyed rather than freed here.
+                if (h.blob) eng->retired_blobs.push_back(h.blob);
+                h.blob = nullptr;
+                h.blob_bytes = 0;
+                PD_HIP_CHECK(hipMalloc(&h.blob, L.total + L.total / 4));   // headroom for ragged batches
+                h.blob_bytes = L.total + L.total / 4;
+            }
+            A.s[b].first = seq_offsets[b0 + b];
+            A.s[b].M = M;
+            A.s[b].n_tiles = (M + ING_TILE - 1) / ING_TILE;
+            A.s[b].blob = (char *)h.blob;
+            A.s[b].desc = eng->d_seqs + slot;
+            max_tiles = std::max(max_tiles, A.s[b].n_tiles);
+            // host shadow = CAPACITIES: launch shapes are planned from these, kernels read the actual counts on the device
+            memset(&h.desc, 0, sizeof(h.desc));
+            h.desc.M = M;
+            h.desc.n_pairs = P_cap;
+            h.desc.n_items = I_cap;
+            h.desc.n_pchunks = C_cap;
+            h.desc.single_item_pairs = single ? 1 : 0;
+            h.desc.n_frames = N;
+            h.desc.sc = A.sc;
+            h.desc.cx = A.cx;
+            h.desc.cy = A.cy;
+            h.max_item_len = single ? hint_per_pair : PD_ITEM_MAX_MATCHES;
+            h.device_built = true;
+        }
+        const size_t lds_hist = sizeof(int) * (size_t)N * N;
+        hipLaunchKernelGGL(ingest_hist_kernel, dim3(max_tiles, nb), dim3(256), lds_hist, s, A);
+        hipLaunchKernelGGL(ingest_tables_kernel, dim3(nb), dim3(ING_TABLE_THREADS), lds_tab, s, A);
+        hipLaunchKernelGGL(ingest_scatter_kernel, dim3(max_tiles, nb), dim3(64), lds_hist, s, A);
+        PD_HIP_CHECK(hipGetLastError());
+    }
+    // later GGS launches on OTHER streams wait for this point (pd_sample_phase / pd_ggs_launch), again on the device
+    if (!eng->upload_done) PD_HIP_CHECK(hipEventCreateWithFlags(&eng->upload_done, hipEventDisableTiming));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone) PD_HIP_CHECK(hipEventRecord(eng->upload_done, s));
+    return PD_OK;
+}
+
+int pd_ggs_ingest_init() {
+    PD_HIP_CHECK(hipFuncSetAttribute((const void *)ingest_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return PD_OK;
+}

@@ -79,13 +79,16 @@ struct PdGgsParams {
 // launch shape of one GGS launch (pd_ggs_plan): everything a captured graph node bakes in besides its arguments
 struct PdGgsPlan {
     int k, n_slots, lds, two_hop, max_items;
+    int pinc_rows, stage_p;    // one-hop kernel: LDS rows of the pair backward; LDS-DMA staging pieces per item (0 = through registers)
 };
 
 struct PdSeqHost {
     void *blob = nullptr;      // one hipMalloc holding every array of the PdSeqDesc
     size_t blob_bytes = 0;     // its capacity (re-used by later uploads that fit)
-    PdSeqDesc desc{};
+    PdSeqDesc desc{};          // host shadow; for device-built slots (pd_ggs_set_matches_csr_async) the counts are CAPACITIES
     int n_local_max_k1 = 0;
+    int max_item_len = 0;      // longest work item (matches); for device-built slots the per-pair hint (or the 512 maximum)
+    bool device_built = false; // tables + descriptor were written by the ingestion kernels; the host never saw the counts
 };
 
 // ---- denoiser -----------------------------------------------------------------------------------
@@ -121,6 +124,9 @@ struct pd_engine {
     hipStream_t own_stream = nullptr;
     // recorded after every enqueue that reads the match tables: pd_ggs_set_matches waits for THIS engine's work only
     hipEvent_t last_use = nullptr;
+    // recorded after the ingestion kernels of pd_ggs_set_matches_csr_async: GGS launches on other streams wait for it (device side)
+    hipEvent_t upload_done = nullptr;
+    std::vector<void *> retired_blobs;   // outgrown slot blobs that in-flight work may still read; freed with the engine
 };
 
 // pd_denoiser.hip
@@ -142,4 +148,6 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
                   const pd_ggs_cfg *cfg, int eval_only, float *stats, float *trace, int trace_iters,
                   float *loss_out, float *grad_out, hipStream_t s);
 void pd_ggs_free_seq(PdSeqHost &h);
+int pd_ggs_ingest_init();   // pd_ggs_ingest.hip
+int pd_wait_uploads(pd_engine *eng, hipStream_t s);   // device-side wait for pending asynchronous match uploads (no-op in a capture)
 int pd_mark_use(pd_engine *eng, hipStream_t s);

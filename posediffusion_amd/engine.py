@@ -162,6 +162,38 @@ class PoseEngine:
             _lib.check(self.lib.pd_ggs_set_matches(self._h, int(seq), kp1.ctypes.data, kp2.ctypes.data, i12.ctypes.data,
                                                    kp1.shape[0], n, h, w), "pd_ggs_set_matches")
 
+    def set_matches_async(self, seq_first: int, kp1: torch.Tensor, kp2: torch.Tensor, i12: torch.Tensor, offsets,
+                          img_shape: Sequence[int], max_pairs: int = 0, max_matches_per_pair: int = 0):
+        """Asynchronous, device-resident upload of the matches of consecutive slots (pd_ggs_set_matches_csr_async).
+
+        kp1 / kp2: float64 [total, 2], i12: int64 [total, 2] -- CUDA tensors on this device or PINNED host tensors (the
+        kernels then read them over PCIe); ``offsets`` [n + 1]: CSR offsets, sequence b = rows offsets[b]:offsets[b+1].
+        Runs on torch's current stream; returns at once.  The engine keeps the tensors alive until the upload has
+        executed.  ``max_pairs`` / ``max_matches_per_pair``: capacity hints (include/pd_engine.h pd_match_hints)."""
+        for name, t, dt in (("kp1", kp1, torch.float64), ("kp2", kp2, torch.float64), ("i12", i12, torch.int64)):
+            if t.dtype != dt or t.dim() != 2 or t.shape[1] != 2 or not t.is_contiguous():
+                raise ValueError(f"{name} must be a contiguous {dt} tensor of shape [total, 2]")
+            if not (t.is_cuda and t.device == self.device) and not (t.device.type == "cpu" and t.is_pinned()):
+                raise ValueError(f"{name} must live on {self.device} or in pinned host memory (got {t.device}, "
+                                 f"pinned={t.device.type == 'cpu' and t.is_pinned()})")
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        if off.ndim != 1 or len(off) < 2 or off[0] < 0 or off[-1] > kp1.shape[0] or kp1.shape != kp2.shape or kp1.shape != i12.shape:
+            raise ValueError("offsets must be [n_seqs + 1] within the rows of kp1 / kp2 / i12 (equal shapes)")
+        n, _, h, w = (int(v) for v in img_shape)
+        hints = _lib.pd_match_hints(int(max_pairs), int(max_matches_per_pair))
+        cache = self.__dict__.setdefault("_match_ids", {})
+        for b in range(len(off) - 1):
+            cache.pop(int(seq_first) + b, None)                    # host.upload_matches' identity cache
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pd_ggs_set_matches_csr_async(
+                self._h, int(seq_first), len(off) - 1, off.ctypes.data_as(C.POINTER(C.c_int64)), kp1.data_ptr(), kp2.data_ptr(),
+                i12.data_ptr(), n, h, w, C.byref(hints), self._stream()), "pd_ggs_set_matches_csr_async")
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+        keep = self.__dict__.setdefault("_upload_keep", [])
+        keep[:] = [(e, ts) for e, ts in keep if not e.query()]
+        keep.append((ev, (kp1, kp2, i12)))
+
     def ggs_guide(self, model_mean: torch.Tensor, t: int, cfg=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """geometry_guided_sampling(model_mean, t, ...) for every sequence b (match slot b)."""
         B, N, _ = model_mean.shape

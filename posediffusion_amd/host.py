@@ -136,3 +136,25 @@ def upload_matches(engine: PoseEngine, matches, B: int):
             continue
         engine.set_matches(b, md["kp1"], md["kp2"], md["i12"], tuple(md["img_shape"]))
         cache[b] = (md["kp1"], md["kp2"], md["i12"], fp)
+
+
+def pack_matches(matches_list, pin: bool = True):
+    """CSR packing of per-sequence matches_dicts for ``PoseEngine.set_matches_async``: -> (kp1 [total,2] float64,
+    kp2, i12 [total,2] int64, offsets [n+1] int64, img_shape).  ``pin``: in pinned host memory, so that the upload
+    (a non_blocking copy, or the ingestion kernels reading it in place) never stages through pageable memory."""
+    import numpy as np
+    shapes = {tuple(int(v) for v in md["img_shape"]) for md in matches_list}
+    if len(shapes) != 1:
+        raise ValueError(f"all sequences of a batch must share img_shape (frame count and image size): {sorted(shapes)}")
+    offsets = np.zeros(len(matches_list) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(md["kp1"]) for md in matches_list])
+    total = int(offsets[-1])
+    kp1 = torch.empty(total, 2, dtype=torch.float64, pin_memory=pin)
+    kp2 = torch.empty(total, 2, dtype=torch.float64, pin_memory=pin)
+    i12 = torch.empty(total, 2, dtype=torch.int64, pin_memory=pin)
+    for b, md in enumerate(matches_list):
+        a, e = int(offsets[b]), int(offsets[b + 1])
+        kp1[a:e] = torch.from_numpy(np.ascontiguousarray(md["kp1"], dtype=np.float64))
+        kp2[a:e] = torch.from_numpy(np.ascontiguousarray(md["kp2"], dtype=np.float64))
+        i12[a:e] = torch.from_numpy(np.ascontiguousarray(md["i12"], dtype=np.int64))
+    return kp1, kp2, i12, offsets, shapes.pop()

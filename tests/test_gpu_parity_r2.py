@@ -223,3 +223,118 @@ def test_graph_replay_after_reupload_with_other_launch_shape(seeded_diffuser):
     with pytest.raises(RuntimeError, match="uploaded for 7 frames"):
         eng.sample(z, noise, 2, cfg, use_graph=True, want_process=False)
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ asynchronous match ingestion
+def _ragged_batch(N, seeds, ordered=False, shuffle=True, per_pair=lambda b: 30 + 17 * b, big_pair=None):
+    rng = np.random.default_rng(4242)
+    mds, x0s = [], []
+    for b, seed in enumerate(seeds):
+        enc = synth.make_cameras(N, seed=seed)
+        md = synth.make_matches(enc, 224, 224, per_pair=per_pair(b), seed=seed, ordered_pairs=ordered)
+        if big_pair is not None and b == 0:              # one pair with > 512 matches -> several work items
+            extra = synth.make_matches(enc[[0, 1]], 224, 224, per_pair=big_pair, seed=seed + 1)
+            sel = extra["i12"][:, 0] == 0
+            md = {"kp1": np.concatenate([md["kp1"], extra["kp1"][sel]]), "kp2": np.concatenate([md["kp2"], extra["kp2"][sel]]),
+                  "i12": np.concatenate([md["i12"], np.tile(np.array([[0, 1]], dtype=np.int64), (int(sel.sum()), 1))]),
+                  "img_shape": md["img_shape"]}
+        if shuffle:
+            perm = rng.permutation(len(md["kp1"]))
+            md = {"kp1": md["kp1"][perm], "kp2": md["kp2"][perm], "i12": md["i12"][perm], "img_shape": md["img_shape"]}
+        mds.append(md)
+        x0s.append(synth.perturb_pose(enc, seed=seed + 9))
+    return mds, torch.cat(x0s)
+
+
+@pytest.mark.parametrize("where", ["device", "pinned"])
+@pytest.mark.parametrize("case", ["n9_ragged_shuffled", "n20_full", "n12_ordered_big_pair", "n40_two_hop"])
+def test_async_match_ingestion_is_bitwise_the_host_upload(seeded_diffuser, case, where):
+    """pd_ggs_set_matches_csr_async (stable counting sort + table build on the device, no host sync) must leave exactly
+    the state pd_ggs_set_matches (host counting sort) leaves: the same batch uploaded both ways into two engines gives
+    bitwise-equal GGS results -- shuffled input (stability of the sort), ragged sizes, pairs split into several items,
+    both orders of a pair, the two-hop kernel with hints, with and without hints."""
+    from posediffusion_amd.engine import PoseEngine
+    from posediffusion_amd.host import denoiser_state, pack_matches
+    dev = torch.device(DEV)
+    diff = seeded_diffuser.to(dev)
+    hints = {}
+    if case == "n9_ragged_shuffled":
+        N, (mds, x0) = 9, _ragged_batch(9, [800, 801, 802, 803, 804])
+    elif case == "n20_full":
+        N, (mds, x0) = 20, _ragged_batch(20, [810, 811], shuffle=False, per_pair=lambda b: 300)
+        hints = dict(max_pairs=190, max_matches_per_pair=512)
+    elif case == "n12_ordered_big_pair":
+        N, (mds, x0) = 12, _ragged_batch(12, [820, 821, 822], ordered=True, big_pair=1300)
+    else:
+        N, (mds, x0) = 40, _ragged_batch(40, [830, 831], shuffle=True, per_pair=lambda b: 6 + b)
+        hints = dict(max_pairs=780, max_matches_per_pair=64)
+    B = len(mds)
+    tables = {k: v for k, v in diff.named_buffers(recurse=False)}
+    e_host = PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=B, max_N=N)
+    e_dev = PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=B, max_N=N)
+    for b, md in enumerate(mds):
+        e_host.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+    kp1, kp2, i12, off, shape = pack_matches(mds, pin=True)
+    if where == "device":
+        kp1, kp2, i12 = kp1.to(dev, non_blocking=True), kp2.to(dev, non_blocking=True), i12.to(dev, non_blocking=True)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):                            # upload on ANOTHER stream than the GGS launches below
+        e_dev.set_matches_async(0, kp1, kp2, i12, off, shape, **hints)
+    del kp1, kp2, i12                                        # the engine keeps them alive until the upload ran
+    x0 = x0.to(dev)
+    for wgs in (0, 1, 3):
+        cfg = make_ggs_cfg(iter_num=4, wgs_per_seq=wgs, min_matches=0)
+        lh, gh = e_host.ggs_loss_grad(x0, cfg=cfg)
+        ld, gd = e_dev.ggs_loss_grad(x0, cfg=cfg)
+        assert torch.equal(lh, ld) and torch.equal(gh, gd), (case, wgs)
+        oh, sh, _ = e_host.ggs_optimize(x0, cfg=cfg)
+        od, sd, _ = e_dev.ggs_optimize(x0, cfg=cfg)
+        e_host.check_async()
+        e_dev.check_async()
+        assert torch.equal(oh, od) and torch.equal(sh.nan_to_num(-1.0), sd.nan_to_num(-1.0)), (case, wgs)
+    # a second upload into the same slots (other data, no allocation) while nothing waits on the host
+    mds2 = list(reversed(mds))
+    for b, md in enumerate(mds2):
+        e_host.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+    e_dev.set_matches_async(0, *pack_matches(mds2, pin=True), **hints)
+    cfg = make_ggs_cfg(iter_num=3, min_matches=0)
+    oh, _, _ = e_host.ggs_optimize(x0, cfg=cfg)
+    od, _, _ = e_dev.ggs_optimize(x0, cfg=cfg)
+    e_dev.check_async()
+    assert torch.equal(oh, od)
+    e_host.close()
+    e_dev.close()
+
+
+def test_async_match_ingestion_flags_bad_input(seeded_diffuser):
+    """Violated hints / out-of-range frame indices cannot raise synchronously (the host never sees the data): they set
+    the asynchronous error word, pd_check_async_error reports which, and the word is cleared."""
+    from posediffusion_amd.engine import PoseEngine
+    from posediffusion_amd.host import denoiser_state, pack_matches
+    dev = torch.device(DEV)
+    diff = seeded_diffuser.to(dev)
+    N = 8
+    eng = PoseEngine(denoiser_state(diff.model), {k: v for k, v in diff.named_buffers(recurse=False)}, device=dev, max_B=2, max_N=N)
+    mds, x0 = _ragged_batch(N, [900, 901], shuffle=False, per_pair=lambda b: 40)
+    packed = pack_matches(mds, pin=True)
+    eng.set_matches_async(0, *packed, max_pairs=10)                       # there are 28 pairs
+    with pytest.raises(RuntimeError, match="pd_match_hints violated"):
+        eng.check_async()
+    eng.check_async()                                                     # cleared
+    eng.set_matches_async(0, *packed, max_matches_per_pair=39)            # 40 per pair
+    with pytest.raises(RuntimeError, match="pd_match_hints violated"):
+        eng.check_async()
+    bad = [dict(md) for md in mds]
+    bad[1]["i12"] = bad[1]["i12"].copy()
+    bad[1]["i12"][5, 1] = N                                               # frame index == n_frames
+    eng.set_matches_async(0, *pack_matches(bad, pin=True))
+    with pytest.raises(RuntimeError, match="frame index outside"):
+        eng.check_async()
+    eng.set_matches_async(0, *packed)                                     # and a good upload works afterwards
+    out, _, _ = eng.ggs_optimize(x0.to(dev), cfg=make_ggs_cfg(iter_num=2))
+    eng.check_async()
+    assert torch.isfinite(out).all()
+    with pytest.raises(ValueError, match="pinned"):
+        eng.set_matches_async(0, torch.zeros(4, 2, dtype=torch.float64), torch.zeros(4, 2, dtype=torch.float64),
+                              torch.zeros(4, 2, dtype=torch.int64), [0, 4], (N, 3, 224, 224))
+    eng.close()
