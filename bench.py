@@ -1,29 +1,39 @@
 #!/usr/bin/env python
 """bench.py -- sequences/sec of the PoseDiffusion sampling hot path on MI355X (BASELINE.json metric).
 
-A "step" = one full pass of the hot path over one batch of synthetic sequences:
-  100 DDPM steps (transformer denoiser + posterior update) and, on the last `cond_start_step`=10
-  steps, Geometry-Guided Sampling (5 optimisations = 700 clipped-momentum-SGD iterations per guided
-  step, 7000 per sequence) over M = 57 000 pairwise matches per 20-frame sequence.
-Workload (config.workload): BASELINE.json configs[3], "batch of 64 independent 20-frame sequences, GGS on"
-  (224^2, 190 pairs x 300 matches each), the whole batch on ONE GPU ("also run 64 on 1/2/4 GPUs"); weak
-  scaling: every GPU runs its own 64-sequence batches (total = 64 x n_gpus per step).  Four batches are in flight per
-  GPU (posediffusion_amd/pipeline.py), i.e. 256 sequences, one GGS workgroup = one CU per sequence; throughput
-  against the number in flight is in DESIGN.md section 5 (`--seqs-per-gpu 8`: 272 sequences/s at 73 ms latency).
-  Inputs are resident in HBM before the timed region.
+A "step" = one full pass of the hot path over ONE batch of 64 independent synthetic sequences (BASELINE.json configs[3]):
+  100 DDPM steps (transformer denoiser + posterior update) and, on the last `cond_start_step` = 10 steps,
+  Geometry-Guided Sampling (5 optimisations = 700 clipped-momentum-SGD iterations per guided step, 7 000 per sequence)
+  over M = 57 000 pairwise matches per 20-frame sequence (190 pairs x 300, 224 x 224).  Inputs (z, noise, matches) are
+  resident in HBM before the timed region.
 
-Launch: `python bench.py --gpus N --steps K --warmup W`; for N > 1 under torch.distributed.run
-(one rank per GPU, RCCL): ranks shard the sequences, no collective on the data path, one final
-all_gather of the [B_local,20,9] poses inside the timed region.
+Scaling (`--scaling`, default strong = what configs[3] names: "batch of 64 ... sharded across 8 x MI355X"):
+  strong  every step's 64 sequences are block-partitioned over the N ranks (64 / N each).  A rank keeps its engine
+          launches at 64 sequences by running the shards of N consecutive steps in one engine pass, `--pipeline-depth`
+          passes in flight -- so the per-GPU launch shape (and efficiency) is the single-GPU one and only the
+          pipeline fill / drain of a short run costs.  Total work is fixed: K x 64 sequences whatever N.
+  weak    every rank runs its own 64-sequence batch per step (64 x N sequences per step).
+There is no collective on the data path; ONE all_gather of the poses of all K steps ends the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      -- dominant kernel (pd_ggs_kernel): algorithmic FLOPs / hipEvent-timed launch
-  cpu_baseline  -- the oracle (torch-CPU restatement of the reference path, kind "port") timed on the
-                   host cores of this box on a bounded sample, extrapolated to sequences/s
+Launch: `python bench.py --gpus N --steps K --warmup W`; for N > 1 under torch.distributed.run (one rank per GPU, RCCL).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with, besides the required keys:
+  roofline        dominant kernel (pd_ggs_kernel<..>): `frac` = algorithmic fp32 FLOPs of ONE launch / its hipEvent-timed
+                  duration / 157.3 TFLOP/s (SURVEY 8d prices it against the fp32 vector ALU); sub-objects `co_resident`
+                  (the `--pipeline-depth` launches that run together, as in the pipe) and `fabric` (match bytes streamed per
+                  iteration -- Infinity-Cache / fabric bandwidth, NOT HBM); `traffic` from the committed PMC summary, only
+                  when that summary was collected with THIS libpd_engine.so (sha256 recorded there)
+  roofline_denoiser
+  per_config      BASELINE configs[1], [2], [3]-shard and [4], each alone on the chip (ms per pass, sequences/s)
+  fresh_inputs    the same pipe with every pass uploading NEW z / noise / matches inside the timed region
+                  (pinned host -> device copies + asynchronous device-side match ingestion)
+  cpu_baseline    the reference files verbatim (kind "reference") when the reference tree is present, else the oracle
+                  port (kind "port"), on the host cores of this box, bounded sample, all five GGS stage types timed
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,14 +42,15 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
 
 from posediffusion_amd import shard, synth  # noqa: E402
 
 N_FRAMES = 20
 IMG = 224
 PER_PAIR = 300
-SEQS_PER_GPU = 64                    # BASELINE configs[3]: one batch of 64 independent sequences
+STEP_SEQS = 64                       # BASELINE configs[3]: one batch of 64 independent sequences
 COND_START = 10                      # cfgs/default.yaml:8
 FLOP_PER_MATCH_ITER = 100.0          # 36 fwd + 64 bwd
 DENOISER_PARAMS = 17_298_697         # fp32 -> 69.19 MB read per denoiser step
@@ -48,125 +59,199 @@ PD_STREAM_MIN_ROWS = 1024            # csrc/pd_gemm_stream.h
 FP32_PEAK_TFLOPS = 157.3             # MI355X fp32 vector ALU = dense fp32 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 MATCH_BYTES = 16                     # kp1, kp2: 2 x float2 per match (pair indices are per work item)
-L2_TOTAL_BYTES = 8 * 4 * 2 ** 20     # 8 XCDs x 4 MiB
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round2_pmc_summary.json")
 
 
-# per-XCD persistent denoiser: workgroups per XCD when [alone on the chip, several batches in flight]; 0 = per-launch kernels
-DEFAULT_DEN_WGS = {False: 0, True: 0}
-
-
-def build_inputs(eng, diff, B, dev, seed0):
-    """Synthetic inputs for B local sequences (global indices seed0 .. seed0+B-1), all resident on the
-    device: z, reference-order noise, and matches that are epipolar-consistent with the engine's own
-    unguided model mean at the first guided step (so every guided step runs its full 700 iterations,
-    as it does with a trained checkpoint and real SuperGlue matches)."""
+# ------------------------------------------------------------------------------------------------------------ inputs
+def make_batch_inputs(eng, diff, B, dev, seed0, n_frames=N_FRAMES, img=IMG, per_pair=PER_PAIR, keep_host=False, upload=True):
+    """Synthetic inputs for B sequences (seeds seed0 .. seed0+B-1): z, reference-order noise, and matches that are
+    epipolar-consistent with the engine's own unguided model mean at the first guided step (so every guided step runs its
+    full 700 iterations, as it does with a trained checkpoint and real SuperGlue matches).  Matches go to the engine's
+    slots; with keep_host the per-sequence matches_dicts are returned too (fresh-inputs mode packs them into pinned memory)."""
     from posediffusion_amd.host import draw_noise
     T = diff.num_timesteps
-    z = torch.cat([synth.make_z(1, N_FRAMES, seed=1000 + seed0 + b) for b in range(B)]).to(dev)
-    noise = torch.empty(T + 1, B, N_FRAMES, 9, device=dev)
+    z = torch.cat([synth.make_z(1, n_frames, seed=1000 + seed0 + b) for b in range(B)]).to(dev)
+    noise = torch.empty(T + 1, B, n_frames, 9, device=dev)
     for b in range(B):
         g = torch.Generator(device=dev).manual_seed(seed0 + b)            # cfg.seed (+ sequence index)
-        noise[:, b] = draw_noise((N_FRAMES, 9), T, dev, COND_START, True, generator=g)
-    # unguided run -> model mean at t = COND_START-1 is what GGS first sees
-    _, process, _ = eng.sample(z, noise, 0, None, use_graph=False)
+        noise[:, b] = draw_noise((n_frames, 9), T, dev, COND_START, True, generator=g)
+    _, process, _ = eng.sample(z, noise, 0, None, use_graph=False)         # unguided run -> what GGS first sees
     x_at = process[T - COND_START]                                         # x_t for t = COND_START-1
     mean, _ = eng.p_mean(x_at, z, COND_START - 1)
     mean = mean.cpu().numpy().astype(np.float64)
-    for b in range(B):
-        md = synth.make_epipolar_matches(mean[b], IMG, IMG, PER_PAIR, seed=2000 + seed0 + b)
-        eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
-    return z, noise
+    mds = []
+    for b in range(B if (upload or keep_host) else 0):
+        md = synth.make_epipolar_matches(mean[b], img, img, per_pair, seed=2000 + seed0 + b)
+        if upload:
+            eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+        if keep_host:
+            mds.append(md)
+    return z, noise, mds
 
 
-def _vit_flops(n, size, sf, D=384, L=12, FF=1536, P=16):
-    hs = size if sf == 1 else int(size * sf)
-    p = (hs // P) ** 2
-    t = p + 1
-    return n * (2 * p * 3 * P * P * D + L * (2 * t * (D * 3 * D + D * D + 2 * D * FF) + 4 * t * t * D))
+def lib_sha256():
+    from posediffusion_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
 
 
-def pmc_traffic():
-    """HBM-side traffic per launch from the committed rocprofv3 PMC summary (bench.py cannot collect counters
-    itself: they need their own `rocprofv3 --pmc` passes).  -> (ggs_bytes, denoiser_step_bytes, provenance) or Nones."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_summary.json")
+def pmc_traffic(which):
+    """Fabric-side traffic per launch from the committed rocprofv3 PMC summary (counters need their own `rocprofv3 --pmc`
+    passes: tools/collect_pmc.sh).  Valid only for the binary it was collected with: the summary records the sha256 of
+    libpd_engine.so and a mismatch voids it LOUDLY (stderr + reason in the JSON) instead of quoting a stale number."""
     try:
-        with open(path) as f:
+        with open(PMC_SUMMARY) as f:
             d = json.load(f)
-        return (d["ggs_launch"]["traffic_bytes_corrected"], d["denoiser_step"]["traffic_bytes_corrected"],
-                "profiles/round1_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, separate --pmc passes, "
-                "gfx950 FETCH_SIZE x2 correction; fabric-side counters (Infinity-Cache hits included); measured on one "
-                f"{SEQS_PER_GPU}-sequence batch, one GGS workgroup per sequence")
-    except Exception:
-        return None, None, None
+    except Exception as e:  # noqa: BLE001
+        return None, f"no PMC summary ({e.__class__.__name__}): run tools/collect_pmc.sh on the GPU box"
+    have, want = d.get("libpd_engine_sha256"), lib_sha256()
+    if have != want:
+        msg = (f"STALE: {os.path.relpath(PMC_SUMMARY, ROOT)} was collected with libpd_engine.so sha256 {str(have)[:12]}..., the "
+               f"running library is {want[:12]}...: traffic not reported (re-run tools/collect_pmc.sh)")
+        print("bench.py: " + msg, file=sys.stderr)
+        return None, msg
+    return d[which]["traffic_bytes_corrected"], (
+        f"{os.path.relpath(PMC_SUMMARY, ROOT)}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, separate --pmc passes, gfx950 "
+        "FETCH_SIZE x2 correction; fabric-side counters (Infinity-Cache hits are counted: an upper bound on HBM bytes); same "
+        "library hash as this run")
 
 
+# ------------------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(budget_s: float):
-    """Oracle (torch-CPU port of the reference path) on a bounded sample -> sequences/s."""
+    """The reference's own files executed in place (kind "reference") when the reference tree is present
+    (PD_REFERENCE_ROOT or /root/reference), otherwise the oracle port (kind "port") -- on a bounded sample: denoiser steps
+    at B = 1, N = 20 and GGS iterations at M = 57 000 for each of the four stage types (all / FL / R / T), extrapolated to
+    100 steps + 10 x (400 all + 100 FL + 100 R + 100 T) iterations per sequence."""
+    import contextlib
+    import io
     from oracle import pd_oracle as O
-    # tiny GEMMs oversubscribe badly on a many-core host (128 threads: 80 ms/step vs 24 ms on 8): probe a few
-    # thread counts on the denoiser and keep the fastest for the whole sample
+    from oracle import ref_stubs as RS
+    use_ref = RS.available()
     diff = synth.make_diffuser(seed=0)
     sd = O.cast_state_dict(diff.model.state_dict(), torch.float32)
     z = synth.make_z(1, N_FRAMES)
     x = torch.randn(1, N_FRAMES, 9, generator=torch.Generator().manual_seed(0))
     tt = torch.full((1,), 50, dtype=torch.long)
+    if use_ref:
+        ref = RS.load_reference()
+        rdiff = RS.build_reference_diffuser(seed=0)
+        den = lambda: rdiff.model(x, tt, z)                                           # noqa: E731  models/denoiser.py verbatim
+    else:
+        den = lambda: O.denoiser_forward(sd, x, tt, z)                                # noqa: E731
+    host_cores = os.cpu_count()
     max_threads = torch.get_num_threads()
+    # tiny GEMMs oversubscribe badly on a many-core host: probe a few thread counts on the denoiser, keep the fastest
     best = (float("inf"), max_threads)
     with torch.no_grad():
         for n in sorted({min(max_threads, c) for c in (4, 8, 16, 32, max_threads)}):
             torch.set_num_threads(n)
-            O.denoiser_forward(sd, x, tt, z)
+            den()
             t0 = time.time()
             for _ in range(3):
-                O.denoiser_forward(sd, x, tt, z)
+                den()
             best = min(best, ((time.time() - t0) / 3, n))
     threads = best[1]
     torch.set_num_threads(threads)
     with torch.no_grad():
-        O.denoiser_forward(sd, x, tt, z)                                   # warm-up
+        den()
         n_den, t0 = 0, time.time()
-        while n_den < 3 or (time.time() - t0 < 0.25 * budget_s and n_den < 50):
-            O.denoiser_forward(sd, x, tt, z)
+        while n_den < 3 or (time.time() - t0 < 0.2 * budget_s and n_den < 50):
+            den()
             n_den += 1
         t_den = (time.time() - t0) / n_den
     enc = synth.make_cameras(N_FRAMES, seed=2000)
     md = synth.make_matches(enc, IMG, IMG, per_pair=PER_PAIR, seed=2000)
     pm = O.prepare_matches(md["kp1"], md["kp2"], md["i12"], md["img_shape"])
     x0 = synth.perturb_pose(enc, seed=7)
-    O.ggs_optimize(x0.clone(), pm, iter_num=1)                             # warm-up (2 iterations)
-    n_it = max(4, min(200, int(0.75 * budget_s / 0.04)))
-    t0 = time.time()
-    _, _, steps = O.ggs_optimize(x0.clone(), pm, update_R=True, update_T=False, update_FL=False, iter_num=n_it)
-    t_it = (time.time() - t0) / max(steps, 1)
-    t_seq = 100 * t_den + 7000 * t_it
+    stage_iters = {"all": 400, "fl": 100, "r": 100, "t": 100}                          # per guided step (:48-63, :86-87)
+    flags = {"all": (True, True, True), "fl": (False, False, True), "r": (True, False, False), "t": (False, True, False)}
+    t_stage, n_stage = {}, {}
+    per_stage_budget = 0.8 * budget_s / 4
+    for name, (uR, uT, uF) in flags.items():
+        n_it = 2
+        if use_ref:
+            pmr = {"kp1_homo": pm["kp1_homo"], "kp2_homo": pm["kp2_homo"], "i1": pm["i1"], "i2": pm["i2"], "h": IMG, "w": IMG,
+                   "pair_idx": pm["pair_idx"]}
+            run = lambda n: ref.GGS_optimize(x0.clone(), 0, pmr, update_R=uR, update_T=uT, update_FL=uF,          # noqa: E731
+                                             **dict(synth.GGS_CFG, iter_num=(n // 2 if name == "all" else n)))
+        else:
+            run = lambda n: O.ggs_optimize(x0.clone(), pm, update_R=uR, update_T=uT, update_FL=uF,                # noqa: E731
+                                           iter_num=(n // 2 if name == "all" else n))
+        with contextlib.redirect_stdout(io.StringIO()):
+            run(2)                                                                     # warm-up
+            t0 = time.time()
+            run(n_it)
+            dt = time.time() - t0
+            n_it = int(max(2, min(60, per_stage_budget / max(dt / n_it, 1e-4)))) // 2 * 2
+            t0 = time.time()
+            run(n_it)
+            dt = time.time() - t0
+        t_stage[name], n_stage[name] = dt / n_it, n_it
+    t_guided_step = sum(stage_iters[k] * t_stage[k] for k in stage_iters)
+    t_seq = 100 * t_den + COND_START * t_guided_step
     torch.set_num_threads(max_threads)
-    return {"value": 1.0 / t_seq, "unit": "sequences/s", "cores": threads, "kind": "port",
-            "sample": f"{n_den} denoiser steps (B=1,N=20) + {steps} GGS iterations (M=57000) of oracle/pd_oracle.py "
-                      f"(torch {torch.__version__} CPU, {threads} threads): {t_den * 1e3:.1f} ms/step, {t_it * 1e3:.1f} ms/iter; "
-                      f"extrapolated to 100 steps + 7000 iterations per sequence"}
+    what = ("the reference files executed in place (models/denoiser.py, util/geometry_guided_sampling.py + restated pytorch3d "
+            "helpers, oracle/ref_stubs.py)" if use_ref else "oracle/pd_oracle.py (torch-CPU restatement of the reference path)")
+    return {"value": 1.0 / t_seq, "unit": "sequences/s", "cores": threads, "host_cores": host_cores,
+            "kind": "reference" if use_ref else "port",
+            "sample": f"{what}, torch {torch.__version__} CPU, {threads} threads (fastest of 4/8/16/32/all on the denoiser; the host "
+                      f"has {host_cores} cores): {n_den} denoiser steps (B=1, N=20): {t_den * 1e3:.1f} ms/step; GGS iterations at "
+                      f"M=57000: " + ", ".join(f"{k} x{n_stage[k]}: {t_stage[k] * 1e3:.1f} ms/it" for k in stage_iters) +
+                      "; extrapolated to 100 steps + 10 x (400 all + 100 FL + 100 R + 100 T) iterations per sequence"}
 
 
+# ------------------------------------------------------------------------------------------------------------ per-config
+def measure_config(diff, dev, B, n_frames, img, ggs_on, reps=3):
+    """One BASELINE config alone on the chip: ms per pass (hipGraph replay, inputs resident), sequences/s."""
+    from posediffusion_amd.engine import PoseEngine, make_ggs_cfg
+    from posediffusion_amd.host import denoiser_state
+    eng = PoseEngine(denoiser_state(diff.model), {k: v for k, v in diff.named_buffers(recurse=False)}, device=dev, max_B=B,
+                     max_N=n_frames)
+    z, noise, _ = make_batch_inputs(eng, diff, B, dev, seed0=7000, n_frames=n_frames, img=img, upload=ggs_on)
+    cfg = make_ggs_cfg(synth.GGS_CFG) if ggs_on else None
+    cs = COND_START if ggs_on else 0
+    eng.sample(z, noise, cs, cfg, use_graph=True, want_process=False)              # captures
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        _, _, st = eng.sample(z, noise, cs, cfg, use_graph=True, want_process=False)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    eng.check_async()
+    iters = float(st[:, :, :, 1].sum(dim=(0, 2)).min().item()) if ggs_on else 0.0
+    ms = min(times) * 1e3
+    out = {"B": B, "frames": n_frames, "image": img, "ggs": ggs_on, "matches_per_sequence": n_frames * (n_frames - 1) // 2 * PER_PAIR if ggs_on else 0,
+           "ms_per_pass": ms, "sequences_per_s": B / (ms * 1e-3), "ggs_iterations_per_sequence_run": iters}
+    if ggs_on:
+        g = eng.time_kernel(1, B, n_frames, cfg, reps=2)
+        out["ggs_guided_step_ms"] = g
+        out["ggs_iteration_us"] = g * 1e3 / 700
+    out["denoiser_step_us"] = eng.time_kernel(0, B, n_frames, cfg if ggs_on else make_ggs_cfg(synth.GGS_CFG), reps=20) * 1e3
+    eng.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--seqs-per-gpu", type=int, default=SEQS_PER_GPU)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--seqs-per-step", type=int, default=STEP_SEQS, help="sequences per step: in total (strong) / per GPU (weak)")
+    ap.add_argument("--engine-batch", type=int, default=64, help="sequences per engine pass (a rank groups the shards of consecutive steps up to this)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--ggs-slots", type=int, default=4,
-                    help="how many of the batches in flight may be in their guided (GGS) half at once")
-    ap.add_argument("--unguided-streams", type=int, default=0,
-                    help="0: every stream runs whole passes; u > 0: two-stage pipeline with u streams for the unguided halves")
-    ap.add_argument("--ggs-wgs", type=int, default=0, help="override GGS workgroups per sequence (0 = from the slot count)")
+    ap.add_argument("--ggs-wgs", type=int, default=0, help="override GGS workgroups per sequence (0 = from the pipeline shape)")
     ap.add_argument("--pipeline-depth", type=int, default=4,
-                    help="engine contexts / HIP streams per GPU; consecutive passes (different batches) overlap: the next "
-                         "batch's unguided denoiser steps run on the CUs the persistent GGS kernel leaves free. 1 = serial")
-    ap.add_argument("--denoiser-wgs-per-xcd", type=int, default=-1,
-                    help="per-XCD persistent denoiser kernel: workgroups per XCD (0 = per-launch kernels, -1 = default)")
-    ap.add_argument("--trace", action="store_true", help="print the pipeline timeline (per-batch phase times) to stderr")
-    ap.add_argument("--no-image-features", action="store_true",
-                    help="skip the extra (untimed for `value`) images -> features -> poses measurement")
-    ap.add_argument("--cpu-budget-s", type=float, default=15.0, help="CPU seconds for the cpu_baseline sample (0 = skip)")
+                    help="engine contexts / HIP streams per GPU (engine passes in flight); 1 = serial")
+    ap.add_argument("--trace", action="store_true", help="print the pipeline timeline (per-pass phase times) to stderr")
+    ap.add_argument("--no-per-config", action="store_true", help="skip the per-BASELINE-config measurements")
+    ap.add_argument("--no-fresh-inputs", action="store_true", help="skip the fresh-inputs (upload inside the timed region) measurement")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="CPU seconds for the cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
 
     rank, world, local = shard.init_distributed()
@@ -180,60 +265,65 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from posediffusion_amd.engine import make_ggs_cfg
-    from posediffusion_amd.host import get_engine
-
-    B = args.seqs_per_gpu
-    total = B * world
-    g0, g1 = shard.partition(total, world, rank)
-    assert g1 - g0 == B
-    diff = synth.make_diffuser(seed=0).to(dev)
-    depth = max(1, args.pipeline_depth)
-    slots = min(depth, max(1, args.ggs_slots))
-    from posediffusion_amd.engine import PoseEngine
-    from posediffusion_amd.host import denoiser_state
+    from posediffusion_amd.engine import PoseEngine, make_ggs_cfg
+    from posediffusion_amd.host import denoiser_state, get_engine, pack_matches
     from posediffusion_amd.pipeline import SamplingPipeline
-    eng = get_engine(diff.model, diff, B, N_FRAMES)
+
+    K = args.steps
+    strong = args.scaling == "strong"
+    step_total = args.seqs_per_step * (1 if strong else world)                  # sequences of one step over all ranks
+    g0, g1 = shard.partition(step_total, world, rank) if strong else (rank * args.seqs_per_step, (rank + 1) * args.seqs_per_step)
+    B_step = g1 - g0                                                            # this rank's sequences of one step
+    if B_step <= 0:
+        raise SystemExit(f"rank {rank} has no sequences: {step_total} per step over {world} ranks")
+    group = max(1, args.engine_batch // B_step)                                 # steps per engine pass
+    EB = B_step * group                                                         # sequences per engine pass
+    depth = max(1, args.pipeline_depth)
+
+    diff = synth.make_diffuser(seed=0).to(dev)
     tables = {k: v for k, v in diff.named_buffers(recurse=False)}
-    engines = [eng] + [PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=B, max_N=N_FRAMES) for _ in range(depth - 1)]
-    den_wgs = args.denoiser_wgs_per_xcd if args.denoiser_wgs_per_xcd >= 0 else DEFAULT_DEN_WGS[depth > 1]
-    for e in engines:
-        e.set_denoiser_wgs_per_xcd(den_wgs)
-    pipe = SamplingPipeline(engines, slots, dev, unguided_streams=args.unguided_streams, trace=args.trace)
-    # one resident batch per context (different sequences: seeds offset by the global batch size)
-    inputs = [build_inputs(engines[j], diff, B, dev, seed0=g0 + j * total) for j in range(depth)]
-    z, noise = inputs[0]
-    # GGS workgroups per sequence: alone on the chip -> one work item per wave (24 WGs/sequence, lowest latency);
-    # pipelined -> sized so that the persistent kernels of ALL batches that may be in their guided half are
-    # co-resident (4 batches x 8 sequences x 8 workgroups = 256 CUs; see posediffusion_amd/pipeline.py)
-    wgs = args.ggs_wgs if args.ggs_wgs > 0 else pipe.wgs_per_seq(B)
-    cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=wgs)
+    eng = get_engine(diff.model, diff, EB, N_FRAMES)
+    engines = [eng] + [PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=EB, max_N=N_FRAMES) for _ in range(depth - 1)]
+    pipe = SamplingPipeline(engines, depth, dev, unguided_streams=0, trace=args.trace)
+    # one resident engine batch per context (different sequences: seeds offset per context and rank)
+    want_fresh = not args.no_fresh_inputs
+    inputs = [make_batch_inputs(engines[j], diff, EB, dev, seed0=100_000 * rank + j * EB, keep_host=want_fresh) for j in range(depth)]
+    wgs = args.ggs_wgs if args.ggs_wgs > 0 else pipe.wgs_per_seq(EB)
+    cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=wgs, reserved=int(os.environ.get("PD_GGS_RESERVED", "0")))   # A/B switch, pd_engine.h
     use_graph = not args.no_graph
     torch.cuda.synchronize()
 
-    last_pose = {}
+    # the passes of a K-step run: pass p covers steps [p*group, min(K, (p+1)*group)) -> that many shards of B_step sequences
+    def passes_for(k_steps):
+        return [min(group, k_steps - s0) * B_step for s0 in range(0, k_steps, group)]
 
-    def one_step(i):
+    # setup: every context captures its hipGraphs (full engine batch, and the tail batch of a K that is no multiple of `group`)
+    shapes = sorted(set(passes_for(K)) | set(passes_for(max(args.warmup, 1))) | {EB})
+    sliced = {b: [(inputs[j][0][:b].contiguous(), inputs[j][1][:, :b].contiguous()) for j in range(depth)] for b in shapes if b != EB}
+
+    def submit(b_seqs):                                                         # resident tensors per shape: no copies in the timed region
         j = pipe.next_context()
-        pend = pipe.submit(inputs[j][0], inputs[j][1], COND_START, cfg, use_graph=use_graph, want_process=False)
-        last_pose[j] = pend.pose
-        return pend.pose, pend.stats
+        z, noise = (inputs[j][0], inputs[j][1]) if b_seqs == EB else sliced[b_seqs][j]
+        return pipe.submit(z, noise, COND_START, cfg, use_graph=use_graph, want_process=False)
 
-    for j in range(depth):          # setup: every context captures its hipGraphs before anything is timed
-        with torch.cuda.stream(pipe.u_stream):
-            out = engines[j].sample(inputs[j][0], inputs[j][1], COND_START, cfg, use_graph=use_graph, want_process=False, phase=1)
-            engines[j].sample(inputs[j][0], inputs[j][1], COND_START, cfg, use_graph=use_graph, want_process=False, phase=2, out=out)
-        torch.cuda.synchronize()
-    for i in range(args.warmup):
-        one_step(i)
+    for j in range(depth):
+        for b in shapes:
+            z, noise = (inputs[j][0], inputs[j][1]) if b == EB else sliced[b][j]
+            with torch.cuda.stream(pipe.u_stream):
+                out = engines[j].sample(z, noise, COND_START, cfg, use_graph=use_graph, want_process=False, phase=1)
+                engines[j].sample(z, noise, COND_START, cfg, use_graph=use_graph, want_process=False, phase=2, out=out)
+            torch.cuda.synchronize()
+    for b in passes_for(args.warmup):
+        submit(b)
     torch.cuda.synchronize()
     shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    results = [one_step(i) for i in range(args.steps)]
+    pend = [submit(b) for b in passes_for(K)]
     torch.cuda.synchronize()
-    # the one data-path collective: every rank's poses of all K passes in ONE all_gather over xGMI (still timed)
-    gathered = shard.gather_poses(torch.stack([r[0] for r in results], dim=1).contiguous(), total)   # [total, K, N, 9]
+    # poses of step s = rows [(s % group) * B_step, +B_step) of pass s // group; ONE all_gather of all K steps (still timed)
+    per_step = [pend[s // group].pose[(s % group) * B_step:(s % group + 1) * B_step] for s in range(K)]
+    gathered = shard.gather_poses(torch.stack(per_step, dim=1).contiguous(), step_total)     # [step_total, K, N, 9]
     torch.cuda.synchronize()
     shard.barrier()
     torch.cuda.synchronize()
@@ -243,73 +333,73 @@ def main():
     if args.trace and rank == 0:
         for i, (a, b2, c, d) in enumerate(pipe.timeline()):
             print(f"  sub {i:2d}: U {a:7.1f} -> {b2:7.1f} ({b2 - a:5.1f})   G {c:7.1f} -> {d:7.1f} ({d - c:5.1f})", file=sys.stderr)
-    assert gathered.shape[0] == total and gathered.shape[1] == args.steps
-    # un-overlapped latency of one pass (outside the timed region, reported next to the throughput)
+    assert gathered.shape[0] == step_total and gathered.shape[1] == K
+    ms_per_step = dt / K * 1e3
+    value = step_total * K / dt
+    # every guided step must have run its full 700 iterations (no data-dependent early exit skipped work)
+    iters = torch.cat([p.stats[:, :, :, 1].sum(dim=(0, 2)).cpu() for p in pend])
+    finite = bool(torch.isfinite(gathered).all().item())
+
+    # un-overlapped latency of one engine pass and of ONE sequence (outside the timed region, reported next to the throughput)
+    z, noise, _ = inputs[0]
     for rep in range(2):        # the first call captures the whole-loop graph
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         with torch.cuda.stream(pipe.u_stream):
-            engines[0].sample(z, noise, COND_START, cfg, use_graph=use_graph, want_process=False)
+            full_pose = engines[0].sample(z, noise, COND_START, cfg, use_graph=use_graph, want_process=False)[0]
         torch.cuda.synchronize()
         pass_latency_ms = (time.perf_counter() - t1) * 1e3
-    ms_per_step = dt / args.steps * 1e3
-    value = total * args.steps / dt
 
-    # ---- extra, outside the timed region of `value`: the same pipe fed from images (DINO ViT-S/16 at three
-    # scales on every frame, csrc/pd_vit.hip) -- each batch's features are computed on its context's stream right before its pass
-    feat = None
-    if not args.no_image_features and pipe.whole_pass_streams:
-        from posediffusion_amd.vit import VitEngine, vit_state
-        torch.manual_seed(1)
-        ext = synth._dropin().MultiScaleImageFeatureExtractor().to(dev)              # random-init DINO-shaped parameters
-        vits = [VitEngine(vit_state(ext._net), dev) for _ in range(depth)]
-        images = [torch.rand(B * N_FRAMES, 3, IMG, IMG, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + j))
-                  for j in range(depth)]
-        scales = (1, 1 / 2, 1 / 3)
+    # ---- fresh inputs: every pass brings NEW z / noise / matches from pinned host memory inside the timed region
+    fresh = None
+    if want_fresh:
+        sets = []
+        for j in range(min(2, depth)):
+            zc, nc, mds = inputs[j]
+            kp1, kp2, i12, off, shape = pack_matches(mds, pin=True)
+            sets.append((zc.cpu().pin_memory(), nc.cpu().pin_memory(), kp1, kp2, i12, off, shape))
+        hints = dict(max_pairs=N_FRAMES * (N_FRAMES - 1) // 2, max_matches_per_pair=PER_PAIR)
+        staging = [tuple(torch.empty_like(t, device=dev) for t in sets[0][:5]) for _ in range(depth)]
+        up_bytes = sum(t.numel() * t.element_size() for t in sets[0][:5])
 
-        def one_step_images():
+        def submit_fresh(i):
             j = pipe.next_context()
+            src = sets[i % len(sets)]
             with torch.cuda.stream(pipe.next_stream()):
-                zj = vits[j].multiscale(images[j], scales).reshape(B, N_FRAMES, -1)
-            return pipe.submit(zj, inputs[j][1], COND_START, cfg, use_graph=use_graph, want_process=False)
+                for dst, s_ in zip(staging[j], src[:5]):
+                    dst.copy_(s_, non_blocking=True)                            # pinned host -> device on the pass's stream
+                engines[j].set_matches_async(0, staging[j][2], staging[j][3], staging[j][4], src[5], src[6], **hints)
+            return pipe.submit(staging[j][0], staging[j][1], COND_START, cfg, use_graph=use_graph, want_process=False)
 
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(pipe.u_stream):
-            for rep in range(3):
-                if rep == 1:
-                    e0.record()
-                vits[0].multiscale(images[0], scales)
-            e1.record()
+        for i in range(depth):
+            submit_fresh(i)                                                     # warm-up (allocates the slot buffers, captures the graph of the device-built plan)
         torch.cuda.synchronize()
-        feat_ms = e0.elapsed_time(e1) / 2
-        for _ in range(depth):
-            one_step_images()
-        torch.cuda.synchronize()
+        n_fresh = max(depth, min(len(passes_for(K)), 3 * depth))
         t2 = time.perf_counter()
-        pend = [one_step_images() for _ in range(args.steps)]
+        pf = [submit_fresh(i) for i in range(n_fresh)]
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t2
         for e in engines:
             e.check_async()
-        feat_flops = sum(_vit_flops(B * N_FRAMES, IMG, sf) for sf in scales)
-        feat = {"value": B * args.steps / dt2, "unit": "sequences/s on this GPU, images resident in HBM", "steps": args.steps,
-                "features_ms_per_batch_alone": feat_ms, "features_tflops_alone": feat_flops / (feat_ms * 1e-3) / 1e12,
-                "features_gflop_per_batch": feat_flops / 1e9, "frames_per_batch": B * N_FRAMES, "scales": "1, 1/2, 1/3",
-                "outputs_finite": bool(all(torch.isfinite(p.pose).all().item() for p in pend[-depth:])),
-                "precision": "split (bf16 hi + lo, three bf16 MFMA products, fp32 accumulate; z within 1e-5 of the fp32 network)",
-                "note": "ViT-S/16 with random-init weights (no checkpoint offline); TFLOP/s are fp32-equivalent; not part of `value`"}
-        for v in vits:
-            v.close()
-
-    # every guided step must have run its full 700 iterations (no data-dependent early exit skipped work)
-    iters = torch.stack([r[1][:, :, :, 1].sum(dim=(0, 2)).cpu() for r in results])    # [pass, local sequence]
-    finite = bool(torch.isfinite(gathered).all().item())
+        it2 = torch.cat([p.stats[:, :, :, 1].sum(dim=(0, 2)).cpu() for p in pf])
+        # pass 0 of the fresh run carries the data of context 0's resident batch: same bits expected (same plan, same graph)
+        same = bool(torch.equal(pf[0].pose, full_pose)) if pf[0].context == 0 else None
+        fresh = {"value": EB * n_fresh / dt2, "unit": "sequences/s on this GPU", "passes": n_fresh, "sequences_per_pass": EB,
+                 "uploaded_bytes_per_pass": up_bytes, "upload": "pinned host -> device copy of z, noise, kp1, kp2 (fp64), i12 (int64) on the pass's "
+                 "stream + pd_ggs_set_matches_csr_async (device-side stable sort and table build, no host synchronisation)",
+                 "ggs_iterations_per_sequence_run": float(it2.min().item()),
+                 "first_pass_bitwise_equals_resident_pass": same,
+                 "note": "two distinct pre-packed input sets alternate; packing into pinned memory (the data producer's side) is outside the timed region"}
+        # back to each context's own resident batch (host-built tables) for the roofline legs below
+        for j in range(depth):
+            for b, md in enumerate(inputs[j][2]):
+                engines[j].set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
 
     # ---- roofline of the dominant kernel + the denoiser step, timed with hipEvents on the launch stream
-    ggs_ms = eng.time_kernel(1, B, N_FRAMES, cfg, reps=3)
-    den_ms = eng.time_kernel(2 if den_wgs > 0 else 0, B, N_FRAMES, cfg, reps=20)
+    ggs_ms = eng.time_kernel(1, EB, N_FRAMES, cfg, reps=3)
+    den_ms = eng.time_kernel(0, EB, N_FRAMES, cfg, reps=20)
     M = N_FRAMES * (N_FRAMES - 1) // 2 * PER_PAIR
-    ggs_flops = B * M * FLOP_PER_MATCH_ITER * 7 * cfg.iter_num             # one pd_ggs_guide launch = 700 iterations
+    ggs_flops = EB * M * FLOP_PER_MATCH_ITER * 7 * cfg.iter_num              # one pd_ggs_guide launch = 700 iterations
     ggs_tflops = ggs_flops / (ggs_ms * 1e-3) / 1e12
     # all contexts' GGS kernels together, as they run in the pipe: `depth` co-resident launches, wall time of the set
     evs = []
@@ -321,61 +411,37 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with torch.cuda.stream(st):
                 e0.record(st)
-                engines[j].ggs_guide(last_pose.get(j, results[-1][0]), 0, cfg)
+                engines[j].ggs_guide(full_pose, 0, cfg)
                 e1.record(st)
             evs.append((e0, e1))
         torch.cuda.synchronize()
     ggs_set_ms = max(evs[0][0].elapsed_time(e1) for _, e1 in evs)
     ggs_set_tflops = depth * ggs_flops / (ggs_set_ms * 1e-3) / 1e12
-    den_gbs = DENOISER_PARAMS * 4 / (den_ms * 1e-3) / 1e9
-    # the weight stream (69 MB per step, HBM) bounds the denoiser up to ~50 tokens, the exact-fp32 matrix pipe above
-    tokens = B * N_FRAMES
-    den_flops = tokens * DENOISER_MFLOP_PER_TOKEN * 1e6
-    den_tflops = den_flops / (den_ms * 1e-3) / 1e12
-    if tokens >= PD_STREAM_MIN_ROWS:
-        den_kernels = "one denoiser step = 59 launches (pd_gemm_stream_kernel x32, pd_ln_rows_kernel x16, pd_gemm_kernel x2, pd_attn_kernel x8, pd_tail_kernel)"
-    else:
-        den_kernels = "one denoiser step = 43 launches (pd_gemm_kernel x34, pd_attn_kernel x8, pd_tail_kernel)"
-
-    ggs_traffic, den_traffic, traffic_src = pmc_traffic() if B == SEQS_PER_GPU else (None, None, None)
-    # Which roof: with few sequences in flight the matches of a sequence stay in registers (24 workgroups per sequence) or in
-    # the L2s and the kernel is priced against the fp32 vector ALU.  With the default 256 in flight (one workgroup
-    # = one CU per sequence) their 16 B per match (kp1, kp2 as 2 x float2; the pair index is per work item) total
-    # 233 MB and are streamed from the fabric EVERY iteration -- the PMC traffic equals these algorithmic bytes -- so the
-    # kernel is priced against HBM.
-    match_bytes = float(B) * M * MATCH_BYTES * 7 * cfg.iter_num                 # one launch = 700 iterations
-    streams_matches = B * depth * M * MATCH_BYTES > L2_TOTAL_BYTES and (wgs or 24) < 24
-    alu = {"achieved": ggs_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ggs_tflops / FP32_PEAK_TFLOPS,
-           "achieved_all_launches": ggs_set_tflops, "frac_all_launches": ggs_set_tflops / FP32_PEAK_TFLOPS,
-           "algorithmic_flops_per_launch": ggs_flops}
+    match_bytes = float(EB) * M * MATCH_BYTES * 7 * cfg.iter_num             # streamed once per iteration at one workgroup per sequence
+    ggs_traffic, traffic_src = pmc_traffic("ggs_launch") if (EB == 64 and (wgs or 24) == 1) else (None, "PMC summary is for 64 sequences, one workgroup each")
+    k_eff = wgs or 24
     roofline = {
-        "kernel": "pd_ggs_kernel (one launch = one guided step = 700 iterations x %d sequences)" % B,
-        "traffic": ggs_traffic, "traffic_source": traffic_src, "launch_ms": ggs_ms,
-        "co_resident_launches": depth, "all_launches_ms": ggs_set_ms,
+        "kernel": f"pd_ggs_kernel (one launch = one guided diffusion step = 700 iterations x {EB} sequences, {k_eff} workgroup(s) per sequence)",
+        "bound": "mfma", "bound_detail": "fp32 vector ALU (SURVEY 8d names the arithmetic roofline for the Sampson kernel); its peak "
+                                         "equals the dense fp32 MFMA peak, 157.3 TFLOP/s",
+        "achieved": ggs_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ggs_tflops / FP32_PEAK_TFLOPS,
+        "algorithmic_flops_per_launch": ggs_flops, "algorithmic_flop_per_match_iteration": FLOP_PER_MATCH_ITER,
+        "launch_ms": ggs_ms, "launch_timing": "hipEvents around the launch on its stream (pd_time_kernel), one launch alone on the chip: "
+                                              f"its {EB * k_eff} workgroups occupy {EB * k_eff} of the 256 CUs",
+        "traffic": ggs_traffic, "traffic_source": traffic_src,
+        "co_resident": {"launches": depth, "wall_ms": ggs_set_ms, "achieved": ggs_set_tflops, "frac": ggs_set_tflops / FP32_PEAK_TFLOPS,
+                        "note": f"the {depth} contexts' launches issued together on their streams, as in the pipe; reproducible from "
+                                "profiles/ with tools/coresident_from_trace.py (union of the kernel's intervals in a rocprofv3 kernel trace)"},
+        "fabric": {"algorithmic_bytes_per_launch": match_bytes, "achieved_GBps_one_launch": match_bytes / (ggs_ms * 1e-3) / 1e9,
+                   "achieved_GBps_co_resident": depth * match_bytes / (ggs_set_ms * 1e-3) / 1e9,
+                   "note": f"{EB * depth} sequences in flight x {M * MATCH_BYTES / 1e6:.2f} MB of matches = {EB * depth * M * MATCH_BYTES / 1e6:.0f} MB, "
+                           "re-read every iteration at one workgroup per sequence (a chosen trade: no replicated serial phase); the set fits the "
+                           "256 MiB Infinity Cache, so this is fabric / Infinity-Cache bandwidth, not an HBM measurement"},
     }
-    if streams_matches:
-        gbs, set_gbs = match_bytes / (ggs_ms * 1e-3) / 1e9, depth * match_bytes / (ggs_set_ms * 1e-3) / 1e9
-        roofline.update({
-            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "achieved_all_launches": set_gbs, "frac_all_launches": set_gbs / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_launch": match_bytes, "fp32_alu": alu,
-            "note": f"{B * depth} sequences in flight: their matches ({B * depth * M * MATCH_BYTES / 1e6:.0f} MB) exceed the L2s "
-                    "and stream from Infinity Cache / HBM every iteration, 16 B per match. `achieved` is ONE launch alone on the "
-                    "chip (its workgroups cover a quarter of the CUs); `achieved_all_launches` is the set of co-resident "
-                    "launches of all contexts, as they run in the pipe. `fp32_alu` prices the same launches against the "
-                    "vector ALU (100 FLOP per match and iteration, SURVEY 8d)"})
-    else:
-        roofline.update(dict(alu, bound="mfma", bound_detail="fp32 vector ALU; its peak equals the dense fp32 MFMA peak (157.3 TFLOP/s)",
-                             note=("matches stay in registers for the whole launch" if (wgs or 24) >= 24 else
-                                   "matches are re-read from L2 every iteration (more than one work item per wave)") +
-                                  "; the fabric traffic is the per-iteration cross-workgroup exchange, not match streaming. "
-                                  "`achieved` is ONE launch; `achieved_all_launches` is the set of co-resident launches of all "
-                                  "contexts, as in the pipe"))
-    # the same step on all contexts at once, as in the unguided halves of the pipe: `reps` steps per context, each on its stream
     den_set_ms = None
     if depth > 1:
         reps = 10
-        xs = [torch.randn(B, N_FRAMES, 9, device=dev) for _ in range(depth)]
+        xs = [torch.randn(EB, N_FRAMES, 9, device=dev) for _ in range(depth)]
         for rep in range(2):
             evs = []
             for j in range(depth):
@@ -389,50 +455,75 @@ def main():
                 evs.append((e0, e1))
             torch.cuda.synchronize()
         den_set_ms = max(evs[0][0].elapsed_time(e1) for _, e1 in evs) / reps
-    if tokens > 50:
-        roofline_den = {"kernel": den_kernels, "bound": "mfma", "bound_detail": "exact-fp32 matrix instruction (157.3 TFLOP/s)",
+    tokens = EB * N_FRAMES
+    den_flops = tokens * DENOISER_MFLOP_PER_TOKEN * 1e6
+    den_tflops = den_flops / (den_ms * 1e-3) / 1e12
+    den_gbs = DENOISER_PARAMS * 4 / (den_ms * 1e-3) / 1e9
+    den_traffic, den_src = pmc_traffic("denoiser_step") if EB == 64 else (None, None)
+    if tokens > 50:      # the weight stream bounds the denoiser up to ~50 tokens, the exact-fp32 matrix pipe above
+        roofline_den = {"kernel": f"one denoiser step at {tokens} token rows (pd_gemm_stream_kernel / pd_gemm_kernel / pd_attn_kernel / pd_tail_kernel launches)",
+                        "bound": "mfma", "bound_detail": "exact-fp32 matrix instruction (157.3 TFLOP/s)",
                         "achieved": den_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": den_tflops / FP32_PEAK_TFLOPS,
-                        "traffic": den_traffic, "step_us": den_ms * 1e3, "algorithmic_flops_per_step": den_flops,
+                        "traffic": den_traffic, "traffic_source": den_src, "step_us": den_ms * 1e3, "algorithmic_flops_per_step": den_flops,
                         "weights_GBps": den_gbs, "all_contexts_step_us": None if den_set_ms is None else den_set_ms * 1e3,
                         "achieved_all_contexts": None if den_set_ms is None else depth * den_flops / (den_set_ms * 1e-3) / 1e12,
-                        "frac_all_contexts": None if den_set_ms is None else depth * den_flops / (den_set_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                        "note": f"{tokens} token rows per step; `achieved` is one context alone, `achieved_all_contexts` the "
-                                f"{depth} contexts' steps running together as in the unguided halves of the pipe"}
+                        "frac_all_contexts": None if den_set_ms is None else depth * den_flops / (den_set_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
     else:
-        roofline_den = {"kernel": den_kernels, "bound": "hbm", "achieved": den_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": den_gbs / HBM_PEAK_GBS, "traffic": den_traffic, "step_us": den_ms * 1e3,
-                        "algorithmic_bytes_per_step": DENOISER_PARAMS * 4}
+        roofline_den = {"kernel": "one denoiser step", "bound": "hbm", "achieved": den_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": den_gbs / HBM_PEAK_GBS, "traffic": den_traffic, "step_us": den_ms * 1e3, "algorithmic_bytes_per_step": DENOISER_PARAMS * 4}
+
+    # ---- the other BASELINE configs, each alone on the chip (driver-visible)
+    per_config = None
+    if not args.no_per_config and rank == 0:
+        for e in engines[1:]:
+            e.close()
+        per_config = {}
+        for name, (b_, n_, img_, ggs_) in {"configs[1] B=1 N=20 GGS off": (1, 20, 224, False), "configs[2] B=1 N=20 GGS on": (1, 20, 224, True),
+                                           "configs[3] shard: 8 sequences N=20 GGS on": (8, 20, 224, True),
+                                           "configs[4] B=1 N=50 M=367500 336x336 GGS on": (1, 50, 336, True)}.items():
+            try:
+                per_config[name] = measure_config(diff, dev, b_, n_, img_, ggs_)
+                if b_ <= 8 and n_ == 20:
+                    per_config[name]["denoiser_hbm_roofline_frac"] = DENOISER_PARAMS * 4 / (per_config[name]["denoiser_step_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            except Exception as e:  # noqa: BLE001  (the headline must still be reported)
+                per_config[name] = {"error": repr(e)}
+
     out = {
         "metric": "sequences/sec (20-frame, GGS on)", "value": value, "unit": "sequences/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "steps": K, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[3]: batches of {B} independent 20-frame sequences, one batch per step and GPU "
-                        f"({total} sequences per step in total), {depth} batches in flight per GPU; 100 DDPM steps, GGS on for the last {COND_START} steps "
-                        f"(7000 iterations/sequence), M={M} matches/sequence (190 pairs x {PER_PAIR}), {IMG}x{IMG}; "
-                        "random-init reference-rule weights, matches epipolar-consistent with the engine's own "
-                        "unguided model mean at t=9",
-            "sequences_per_gpu": B, "sequences_in_flight_per_gpu": B * depth, "frames": N_FRAMES, "matches_per_sequence": M, "diffusion_steps": 100,
-            "ggs_iterations_per_sequence_run": float(iters.min().item()), "hip_graph": use_graph,
-            "denoiser_wgs_per_xcd": den_wgs, "pipeline_depth": depth, "ggs_slots": slots, "unguided_streams": 0 if pipe.whole_pass_streams else len(pipe.u_streams), "pass_latency_ms_unpipelined": pass_latency_ms, "ggs_workgroups_per_sequence": wgs or 24,
+            "workload": f"BASELINE configs[3]: one step = one batch of {step_total} independent 20-frame sequences"
+                        + (f" block-partitioned over {world} GPU(s) ({B_step} per GPU and step; a GPU runs the shards of {group} consecutive "
+                           f"steps as one engine pass of {EB} sequences)" if strong else f" ({args.seqs_per_step} per GPU)")
+                        + f", {depth} engine passes in flight per GPU; 100 DDPM steps, GGS on for the last {COND_START} steps "
+                        f"(7000 iterations/sequence), M={M} matches/sequence (190 pairs x {PER_PAIR}), {IMG}x{IMG}; random-init reference-rule "
+                        "weights, matches epipolar-consistent with the engine's own unguided model mean at t=9; inputs resident in HBM",
+            "sequences_per_step": step_total, "sequences_per_gpu_per_step": B_step, "steps_per_engine_pass": group, "sequences_per_engine_pass": EB,
+            "engine_passes_in_timed_region": len(pend), "sequences_in_flight_per_gpu": EB * depth, "frames": N_FRAMES,
+            "matches_per_sequence": M, "diffusion_steps": 100, "ggs_iterations_per_sequence_run": float(iters.min().item()),
+            "hip_graph": use_graph, "pipeline_depth": depth, "ggs_workgroups_per_sequence": k_eff,
+            "engine_pass_latency_ms_unpipelined": pass_latency_ms,
             "parallelism": f"dp{world} (independent sequences, one final all_gather)", "outputs_finite": finite,
         },
         "roofline": roofline,
         "roofline_denoiser": roofline_den,
         "per_step_ms": {"denoiser_step": den_ms, "ggs_guided_step": ggs_ms, "ggs_iteration_us": ggs_ms * 1e3 / (7 * cfg.iter_num)},
     }
-    if feat is not None:
-        out["from_images"] = feat
+    if fresh is not None:
+        out["fresh_inputs"] = fresh
+    if per_config is not None:
+        out["per_config"] = per_config
     if rank == 0:
         if args.cpu_budget_s > 0 and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_budget_s)
-            except Exception as e:  # the GPU number must still be reported
-                out["cpu_baseline"] = {"value": None, "unit": "sequences/s", "cores": torch.get_num_threads(), "kind": "port",
-                                       "sample": f"failed: {e!r}"}
+            except Exception as e:  # noqa: BLE001  (the GPU number must still be reported)
+                out["cpu_baseline"] = {"value": None, "unit": "sequences/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
+                                       "kind": "port", "sample": f"failed: {e!r}"}
         else:
-            out["cpu_baseline"] = {"value": None, "unit": "sequences/s", "cores": torch.get_num_threads(), "kind": "port",
-                                   "sample": "skipped (measured on rank 0 at N=1 only)"}
+            out["cpu_baseline"] = {"value": None, "unit": "sequences/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
+                                   "kind": "port", "sample": "skipped (measured on rank 0 at N=1 only)"}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

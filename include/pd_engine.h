@@ -311,7 +311,7 @@ int pd_check_async_error(pd_engine *eng);
 
 /* Debug aid: switch the GGS kernel's in-kernel phase cycle counters on/off and (out6 != NULL)
  * read them: {P1 pair F, P2 matches, exchange, P3 backward, P4 update, iterations} of workgroup 0. */
-int pd_debug_ggs_prof(pd_engine *eng, int enable, long long *out6);   /* enable = 1 + wave index to record; out6 holds 10 values */
+int pd_debug_ggs_prof(pd_engine *eng, int enable, long long *out6);   /* enable = 1 + wave index to record; out6 holds 16 values */
 
 #ifdef __cplusplus
 }

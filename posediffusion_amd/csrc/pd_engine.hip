@@ -491,7 +491,7 @@ extern "C" int pd_debug_ggs_prof(pd_engine *eng, int enable, long long *out6) {
     eng->ggs_prof_on = enable;
     if (out6) {
         PD_HIP_CHECK(hipDeviceSynchronize());
-        PD_HIP_CHECK(hipMemcpy(out6, eng->d_err + 2, sizeof(long long) * 10, hipMemcpyDeviceToHost));
+        PD_HIP_CHECK(hipMemcpy(out6, eng->d_err + 2, sizeof(long long) * 16, hipMemcpyDeviceToHost));
     }
     return PD_OK;
 }

@@ -32,6 +32,15 @@
 #include <math.h>
 #include <string.h>
 
+// Floating-point contraction is decided per source expression in this file (not by the backend across statements, as
+// -ffp-contract=fast allows): the GGS kernel exists in several template variants (resident / LDS-staged / register-streamed
+// match pass, two-hop) whose results must agree BIT FOR BIT for the same sequence whatever the launch shape -- a backend
+// that fuses a*b+c differently in two instantiations of the same source line would break that.
+#pragma clang fp contract(on)
+
+#ifndef PD_GGS_MIN_WAVES_PER_SIMD
+#define PD_GGS_MIN_WAVES_PER_SIMD 2      // one 512-thread workgroup per CU; 4 = experiment: two workgroups per CU (<= 128 VGPRs)
+#endif
 typedef unsigned long long u64;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define PD_XCHG_LINE 16   // granules per item record in the exchange buffer (one 128-byte line)
@@ -67,17 +76,34 @@ __device__ __forceinline__ float pd_sqrt(float x) { return __builtin_amdgcn_sqrt
 
 // Transposing butterfly over the 12 per-item sums: at every step a lane KEEPS half of its values and SENDS the
 // other half to the partner that differs in exactly ONE lane bit (who keeps exactly those), so the live values
-// go 16 -> 8 -> 4 -> 2 -> 1 per lane over bits 0..3 (xor-1 / xor-2 as DPP quad permutes, xor-4 / xor-8 / xor-16 as
-// ds_swizzle bit-mode, xor-32 as a bpermute), ~55 instructions instead of 12 full 64-lane reductions (~200 incl.
+// go 16 -> 8 -> 4 -> 2 -> 1 per lane over bits 0..3 (xor-1 / xor-2 as DPP quad permutes, xor-4 / xor-8 as DPP row shifts,
+// xor-16 / xor-32 as permlane swaps), ~55 instructions instead of 12 full 64-lane reductions (~200 incl.
 // s_nop / readlane / select chains).  Value `slot` ends up in every lane whose low four bits encode that slot,
 // ready to be stored from there.  Fixed tree -> bitwise reproducible; every lane of the wave must be active.
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
+// Partner exchanges of the butterfly, all on the VALU cross-lane paths (no LDS crossbar round trips: ds_swizzle / ds_bpermute
+// cost ~100+ cycles each on a chain that runs once per work item):
+//   lane ^ 4, lane ^ 8   two DPP row shifts each (up for the lanes whose bit is clear, down for the others, picked by bank_mask)
+//   lane ^ 16, lane ^ 32 gfx950's v_permlane16_swap / v_permlane32_swap: swapping the odd rows (upper half) of one copy with
+//                        the even rows (lower half) of another leaves {x[lane & ~b], x[lane | b]} in the two copies
 template <int XOR>
-__device__ __forceinline__ float swz_xor(float v) {   // partner lane ^ XOR (XOR < 32): and_mask 0x1f, xor_mask XOR
-    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (XOR << 10) | 0x1f));
+__device__ __forceinline__ float dpp_xor(float v) {
+    static_assert(XOR == 4 || XOR == 8, "row shifts cover lane ^ 4 and lane ^ 8");
+    const int x = __float_as_int(v);
+    int t = __builtin_amdgcn_update_dpp(0, x, 0x100 + XOR, 0xf, XOR == 4 ? 0x5 : 0x3, false);    // row_shl: lane <- lane + XOR
+    t = __builtin_amdgcn_update_dpp(t, x, 0x110 + XOR, 0xf, XOR == 4 ? 0xa : 0xc, false);        // row_shr: lane <- lane - XOR
+    return __int_as_float(t);
+}
+__device__ __forceinline__ float add_xor16(float v) {    // v[lane] + v[lane ^ 16]
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+__device__ __forceinline__ float add_xor32(float v) {    // v[lane] + v[lane ^ 32]
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return __int_as_float(r[0]) + __int_as_float(r[1]);
 }
 __device__ __forceinline__ float wave_reduce12_transpose(const float (&a)[PD_ITEM_VALS], int lane, int &slot) {
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
@@ -90,10 +116,10 @@ __device__ __forceinline__ float wave_reduce12_transpose(const float (&a)[PD_ITE
 #pragma unroll
     for (int j = 0; j < 4; ++j) w4[j] = (b1 ? w8[j + 4] : w8[j]) + dpp_mov<0x4E>(b1 ? w8[j] : w8[j + 4]);   // lane ^ 2
 #pragma unroll
-    for (int j = 0; j < 2; ++j) w2[j] = (b2 ? w4[j + 2] : w4[j]) + swz_xor<4>(b2 ? w4[j] : w4[j + 2]);      // lane ^ 4
-    float v = (b3 ? w2[1] : w2[0]) + swz_xor<8>(b3 ? w2[0] : w2[1]);                                         // lane ^ 8
-    v += swz_xor<16>(v);
-    v += __shfl_xor(v, 32, 64);
+    for (int j = 0; j < 2; ++j) w2[j] = (b2 ? w4[j + 2] : w4[j]) + dpp_xor<4>(b2 ? w4[j] : w4[j + 2]);      // lane ^ 4
+    float v = (b3 ? w2[1] : w2[0]) + dpp_xor<8>(b3 ? w2[0] : w2[1]);                                         // lane ^ 8
+    v = add_xor16(v);
+    v = add_xor32(v);
     slot = (b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0);
     return v;
 }
@@ -448,7 +474,7 @@ __device__ __forceinline__ void pd_vmcnt() {
 // RESIDENT: every wave owns at most one item (n_slots == 8, the k = ceil(items / 8) regime): its matches stay in registers for
 // the whole launch -- a compile-time variant, so the other variants do not carry those 32 registers.
 template <int STAGE_P, bool RESIDENT>
-__global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, int B, int n_slots, int pinc_rows, int items_cap) {
+__global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_ggs_kernel(PdGgsParams P, int B, int n_slots, int pinc_rows, int items_cap) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x % B, wg = blockIdx.x / B;   // XCD-aware: see header comment
@@ -503,14 +529,30 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
 
     // LDS staging of the match pass (STAGE_P > 0, several items per wave): this wave's items, its double buffer, and the
     // first item already on its way
-    const int my_first = wg * PD_GGS_WAVES + wave;
-    const int my_cnt = my_first < n_items ? (n_items - my_first + nW - 1) / nW : 0;
-    const bool staged = STAGE_P > 0 && !resident && my_cnt > 0;
+    // Items of this workgroup are slots 0 .. n_local-1 (slot q <-> item wg*8 + (q & 7) + (q >> 3) * nW, increasing in q).
+    // A wave starts every iteration with its own slot `wave` and then PULLS further slots from a workgroup-wide counter:
+    // the two waves that share a SIMD do not issue at the same rate (the older one gets the VALU first), and a static
+    // round-robin leaves the faster half idle for the last quarter of the match pass.  Which wave computes an item does
+    // not enter its sums, so results stay bitwise reproducible.
+    int n_local = 0;
+    if (n_items > wg * PD_GGS_WAVES) {
+        const int d = n_items - wg * PD_GGS_WAVES, r0 = d / nW;
+        n_local = r0 * PD_GGS_WAVES + min(d - r0 * nW, PD_GGS_WAVES);
+    }
+    int *q_ctr = (int *)&L.ctl[4];
+#ifdef PD_GGS_PROF2
+    if (P.prof_wave & 0x100) {                   // experiment: only one wave per SIMD works in the match pass
+        if (wave >= 4) n_local = 0;
+    }
+#endif
+    const bool staged = STAGE_P > 0 && !resident && wave < n_local;
     const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(L.stage + wave * (2 * STAGE_P * 256)));
     const float4 *stage_ptr = (const float4 *)(L.stage + wave * (2 * STAGE_P * 256));
     int pb = 0;                                   // buffer that holds (or is receiving) the item computed next
     auto stage_item = [&](int slot, int buf) {
-        const int4 e = L.itab[slot];
+        int4 e = L.itab[slot];
+        e.x = __builtin_amdgcn_readfirstlane(e.x);
+        e.y = __builtin_amdgcn_readfirstlane(e.y);
         const float4 *pts = D.pts + e.x;
         const int last = e.y - 1;
 #pragma unroll
@@ -544,8 +586,12 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
     const int4 my_pair = (tid < D.n_pairs) ? D.ptab[tid] : make_int4(0, 0, 0, 0);
     unsigned epoch = 0;
     int trace_row = 0;
-    const bool prof = P.prof != nullptr && blockIdx.x == 0 && wave == P.prof_wave;   // one wave of WG 0
+    const bool prof = P.prof != nullptr && blockIdx.x == 0 && wave == (P.prof_wave & 7);   // one wave of WG 0
+    #ifdef PD_GGS_PROF2   // build with -DPD_GGS_PROF2 for the timers INSIDE the match pass (claim / DMA issue / wait / pass / reduce)
+    long long pt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pc = 0, pq = 0;
+#else
     long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pc = 0, pq = 0;
+#endif
 #define PD_PROF(i) do { if (prof) { const long long _n = __builtin_readcyclecounter(); pt[i] += _n - pc; pc = _n; } } while (0)
     const float inv_M = 1.0f / (float)D.M;
     for (int st = 0; st < P.n_stages; ++st) {
@@ -556,6 +602,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
             if (prof) pc = __builtin_readcyclecounter();
             // ---- P1: F for the pairs of this workgroup's items -------------------------------
             const Cam cam = {L.cam[0], L.cam[1], L.cam[2], L.cam[3]};
+            if (tid == 0) *q_ctr = PD_GGS_WAVES;          // first slot the match pass hands out dynamically
             for (int s = tid; s < n_slots; s += PD_GGS_THREADS) {
                 const int4 e = L.itab[s];
                 if (e.y > 0) {
@@ -583,11 +630,30 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
 
             // ---- P2: per-match Sampson residual + dL/dF, one (pair, chunk) item per wave ------
             ++epoch;
-            for (int r = 0;; ++r) {
-                const int item = wg * PD_GGS_WAVES + wave + r * nW;
-                if (item >= n_items) break;
-                const int s = wave + 8 * r;
-                const int4 e = L.itab[s];
+            // slot claims run one item ahead: the LDS atomic for the item after the next one is issued before the pass and
+            // consumed after it, so its latency is never exposed (a wave over-claims one slot per iteration: harmless)
+            int s_next = n_local;
+            if constexpr (!RESIDENT) {
+                int t0 = 0;
+                if (lane == 0 && wave < n_local) t0 = atomicAdd(q_ctr, 1);
+                s_next = __builtin_amdgcn_readfirstlane(t0);
+            }
+            for (int s = wave; s < n_local;) {
+                const int item = wg * PD_GGS_WAVES + (s & 7) + (s >> 3) * nW;
+#ifdef PD_GGS_PROF2
+#define PD_PROF2(i) do { if (prof) { const long long _n = __builtin_readcyclecounter(); pt[i] += _n - pq; pq = _n; } } while (0)
+                if (prof) pq = __builtin_readcyclecounter();
+#else
+#define PD_PROF2(i) do { } while (0)
+#endif
+                int t_claim = 0;
+                if constexpr (!RESIDENT) {
+                    if (lane == 0) t_claim = atomicAdd(q_ctr, 1);
+                }
+                PD_PROF2(10);
+                int4 e = L.itab[s];
+                e.x = __builtin_amdgcn_readfirstlane(e.x);      // wave-uniform by construction: lets the step-count branches be scalar
+                e.y = __builtin_amdgcn_readfirstlane(e.y);
                 float Fm[9];
 #pragma unroll
                 for (int c = 0; c < 9; ++c) Fm[c] = L.F[s * 9 + c];
@@ -596,11 +662,20 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                 if constexpr (RESIDENT) {   // straight from the resident registers (no copies)
                     item_pass<false>(MatchRegs{mres}, e.y, lane, Fm, P.sampson_max, acc2);
                 } else if constexpr (STAGE_P > 0) {
-                    // the next item of this wave (or its first one, for the next iteration: the matches never change)
-                    // goes into the other buffer while this one is computed; STAGE_P pieces stay in flight
-                    stage_item(r + 1 < my_cnt ? s + 8 : wave, pb ^ 1);
+                    // the slot this wave computes next (or its own first one, for the next iteration: the matches never
+                    // change) goes into the other buffer while this one is computed; STAGE_P pieces stay in flight
+                    stage_item(s_next < n_local ? s_next : wave, pb ^ 1);
+                    PD_PROF2(11);
                     pd_vmcnt<STAGE_P>();
-                    item_pass<true>(MatchLds{stage_ptr + pb * (STAGE_P * 64)}, e.y, lane, Fm, P.sampson_max, acc2);
+                    PD_PROF2(12);
+                    // the whole item out of LDS at once (one exposed LDS latency instead of one per step)
+                    float4 mb[8];
+                    {
+                        const float4 *Bp = stage_ptr + pb * (STAGE_P * 64) + lane;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) mb[q] = q < STAGE_P ? Bp[64 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    item_pass<true>(MatchRegs{mb}, e.y, lane, Fm, P.sampson_max, acc2);
                     pb ^= 1;
                 } else {
                     // stream this item: all (<= 8) lines in flight at once, indices clamped (no
@@ -615,6 +690,10 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                     }
                     item_pass<false>(MatchRegs{mb}, e.y, lane, Fm, P.sampson_max, acc2);
                 }
+#ifdef PD_GGS_PROF2
+                if (prof) { acc2[0].x += 0.0f * (float)__builtin_amdgcn_readfirstlane(__float_as_int(acc2[11].y)); }   // (keeps the pass before the timer)
+#endif
+                PD_PROF2(13);
                 float acc[PD_ITEM_VALS];
 #pragma unroll
                 for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = acc2[c].x + acc2[c].y;
@@ -629,6 +708,9 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
                                            __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
+                PD_PROF2(14);
+                s = s_next;
+                s_next = RESIDENT ? n_local : __builtin_amdgcn_readfirstlane(t_claim);
             }
             PD_PROF(1);
             if (k > 1) {
@@ -824,7 +906,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs_kernel(PdGgsParams P, i
         if (P.eval_only) break;
     }
     if (prof && lane == 0) {
-        for (int i = 0; i < 10; ++i) P.prof[i] = pt[i];
+        for (int i = 0; i < (int)(sizeof(pt) / sizeof(pt[0])); ++i) P.prof[i] = pt[i];
     }
     if (own && wg == 0 && !P.eval_only) {
 #pragma unroll
@@ -1463,7 +1545,7 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     P.xchg_stride = (int)eng->xchg_granules;
     P.err_flag = eng->d_err;
     P.prof = eng->ggs_prof_on ? (long long *)(eng->d_err + 2) : nullptr;
-    P.prof_wave = eng->ggs_prof_on > 0 ? (eng->ggs_prof_on - 1) & 7 : 1;
+    P.prof_wave = eng->ggs_prof_on > 0 ? (eng->ggs_prof_on - 1) & 0x107 : 1;
     if (k > 1) {
         // tags restart at 1 every launch: zero every polled word first (guide G16 "re-initialise every call")
         const size_t n_zero = 2 * eng->xchg_granules * B;

@@ -279,9 +279,11 @@ class PoseEngine:
 
     def ggs_prof(self, enable=True):
         """Debug: enable the GGS phase counters / read them -> dict of cycles per iteration."""
-        buf = (C.c_longlong * 10)()
+        buf = (C.c_longlong * 16)()
         _lib.check(self.lib.pd_debug_ggs_prof(self._h, int(enable), buf), "pd_debug_ggs_prof")
         v = list(buf)
         it = max(v[5], 1)
         return {"P1": v[0] / it, "P2": v[1] / it, "xchg": v[2] / it, "P3": v[3] / it, "P4": v[4] / it, "iters": v[5],
-                "P3a": v[6] / it, "P3_wait1": v[7] / it, "P3b": v[8] / it}
+                "P3a": v[6] / it, "P3_wait1": v[7] / it, "P3b": v[8] / it,
+                # inside the match pass, per iteration: slot claim, LDS-DMA issue, wait for the staged item, the item pass, reduction + store
+                "P2_claim": v[10] / it, "P2_issue": v[11] / it, "P2_wait": v[12] / it, "P2_pass": v[13] / it, "P2_reduce": v[14] / it}

@@ -217,9 +217,19 @@ def test_sampson_loss_and_gradient_vs_reference_fixture(engine, golden, fname, s
         loss, grad = engine.ggs_loss_grad(x, *FLAGS[fname], cfg=make_ggs_cfg(sampson_max=smax, wgs_per_seq=k))
         engine.check_async()
         assert int(loss[0, 1].item()) == int(g[tag + "_nvalid"])                      # exact count
-        assert abs(loss[0, 0].item() - float(g[tag + "_loss"])) < 1e-5 * abs(float(g[tag + "_loss"]))
-        assert abs(loss[0, 2].item() - float(g[tag + "_print"])) < 1e-5 * abs(float(g[tag + "_print"]))
-        assert rel_err(grad, g[tag + "_grad"]) < 1e-4
+        assert abs(loss[0, 0].item() - float(g[tag + "_loss"])) < TOL * abs(float(g[tag + "_loss"]))
+        assert abs(loss[0, 2].item() - float(g[tag + "_print"])) < TOL * abs(float(g[tag + "_print"]))
+        # gradient: 1e-4 of the reference's fp32 autograd -- or, where cancellation in the sum amplifies fp32 rounding (the
+        # 0.3 threshold cuts through the bulk of the distribution), no further from the fp64 gradient than twice the
+        # reference's own fp32 distance from it
+        err = rel_err(grad, g[tag + "_grad"])
+        if err >= 1e-4:
+            xd = torch.from_numpy(g["x0"]).double().requires_grad_(True)
+            pm = O.prepare_matches(g["kp1"], g["kp2"], g["i12"], tuple(int(v) for v in g["img_shape"]))
+            v64, _ = O.compute_sampson_distance(xd, pm, *FLAGS[fname], sampson_max=smax)
+            (g64,) = torch.autograd.grad(v64.mean(), xd)
+            assert len(v64) == int(g[tag + "_nvalid"])
+            assert rel_err(grad, g64) <= 2.0 * rel_err(g[tag + "_grad"], g64), (err, rel_err(grad, g64), rel_err(g[tag + "_grad"], g64))
         if fname == "fl":
             assert (grad[0, :, :7] == 0).all()
         if fname == "r":

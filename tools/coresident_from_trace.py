@@ -1,0 +1,45 @@
+"""Co-resident GGS launches from a rocprofv3 kernel trace (rocpd sqlite):  python tools/coresident_from_trace.py results.db [flops_per_launch]
+
+bench.py runs `--pipeline-depth` engine contexts, each on its own HIP stream; their persistent pd_ggs_kernel launches
+(one per guided diffusion step) are meant to be resident TOGETHER (64 workgroups each on a 256-CU chip).  This reads the
+kernel dispatch timestamps of a trace of the bench command, merges overlapping pd_ggs_kernel intervals into sets and
+reports, per set size, the wall time of a set (union of its intervals) and the fp32-ALU rate it implies
+(n launches x flops_per_launch / wall) -- the `roofline.co_resident` figure of bench.py, recomputed from profiles/.
+If the tracer serialised the streams every set has size 1 and the tool says so."""
+import sqlite3
+import sys
+from collections import defaultdict
+
+db = sqlite3.connect(sys.argv[1])
+flops = float(sys.argv[2]) if len(sys.argv) > 2 else 64 * 57000 * 100.0 * 700
+tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
+kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+rows = db.execute(f"select d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id where s.kernel_name like '%pd_ggs_kernel%' order by d.start").fetchall()
+if not rows:
+    raise SystemExit("no pd_ggs_kernel dispatches in the trace")
+sets, cur = [], [rows[0]]
+cur_end = rows[0][1]
+for st, en in rows[1:]:
+    if st < cur_end:                      # overlaps the running set
+        cur.append((st, en))
+        cur_end = max(cur_end, en)
+    else:
+        sets.append(cur)
+        cur, cur_end = [(st, en)], en
+sets.append(cur)
+by_size = defaultdict(list)
+for s in sets:
+    by_size[len(s)].append(s)
+durs = [(en - st) / 1e6 for st, en in rows]
+print(f"pd_ggs_kernel: {len(rows)} launches, average duration {sum(durs) / len(durs):.3f} ms (min {min(durs):.3f}, max {max(durs):.3f})")
+print(f"one launch alone: {flops / (sum(durs) / len(durs) * 1e-3) / 1e12:.2f} TFLOP/s = {flops / (sum(durs) / len(durs) * 1e-3) / 1e12 / 157.3 * 100:.1f} % of 157.3 (fp32 vector ALU), "
+      f"{flops / 1e9:.2f} GFLOP per launch")
+for n in sorted(by_size):
+    walls = [(max(e for _, e in s) - min(b for b, _ in s)) / 1e6 for s in by_size[n]]
+    w = sum(walls) / len(walls)
+    print(f"sets of {n} overlapping launch(es): {len(walls)} sets, wall {w:.3f} ms per set -> {n * flops / (w * 1e-3) / 1e12:.2f} TFLOP/s = "
+          f"{n * flops / (w * 1e-3) / 1e12 / 157.3 * 100:.1f} % of the fp32 vector ALU peak")
+if max(by_size) == 1:
+    print("NOTE: no two launches overlap in this trace: the tracer serialised the streams; the co-resident figure cannot be read from it "
+          "(see the single 256-sequence launch of tools/pmc_target.py 256 1 instead: one launch that fills the chip)")

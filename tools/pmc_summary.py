@@ -41,7 +41,7 @@ def main():
         }
 
     def corrected(prefix):
-        return sum(v["traffic_bytes_per_dispatch_corrected"] for k, v in kernels.items() if k.startswith(prefix))
+        return sum(v["traffic_bytes_per_dispatch_corrected"] for k, v in kernels.items() if prefix in k)
 
     # one denoiser step = 34 GEMM launches of 7 kinds + 8 attention + 1 tail (+ 16 LayerNorm launches on the streamed path);
     # weight per kind by its launches per step (kinds that did not run in the profiled process contribute nothing)
@@ -55,7 +55,12 @@ def main():
         for pre, n in per_step.items():
             if k.replace("void ", "").startswith(pre):
                 den += n * v["traffic_bytes_per_dispatch_corrected"]
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "posediffusion_amd", "lib", "libpd_engine.so")
+    with open(lib, "rb") as fh:
+        lib_hash = hashlib.sha256(fh.read()).hexdigest()
     out = {
+        "libpd_engine_sha256": lib_hash,   # bench.py quotes these figures only for the binary they were measured on
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `{cmd}` "
                   "(one batch of the default size, N=20, GGS on, GGS workgroups per sequence as in the default 4-batch pipeline), 1x MI355X; tools/collect_pmc.sh + tools/pmc_summary.py",
         "units": "KB per dispatch as reported by rocprofv3 (FETCH_SIZE / WRITE_SIZE); bytes = KB * 1024",

@@ -16,11 +16,12 @@ N, H, W = 20, 224, 224
 dev = torch.device("cuda:0")
 diff = synth.make_diffuser(seed=0)
 eng = PoseEngine(denoiser_state(diff.model), {n: v for n, v in diff.named_buffers(recurse=False)}, device=dev, max_B=B, max_N=N)
+cams = [synth.make_cameras(N, seed=2000 + b) for b in range(min(B, 16))]     # 16 distinct scenes, repeated over the slots
+mds = [synth.make_matches(c, H, W, per_pair=300, seed=2000 + b) for b, c in enumerate(cams)]
 for b in range(B):
-    enc = synth.make_cameras(N, seed=2000 + b)
-    md = synth.make_matches(enc, H, W, per_pair=300, seed=2000 + b)
+    md = mds[b % len(mds)]
     eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
-x0 = torch.cat([synth.perturb_pose(synth.make_cameras(N, seed=2000 + b), seed=7 + b) for b in range(B)]).to(dev)
+x0 = torch.cat([synth.perturb_pose(cams[b % len(cams)], seed=7 + b) for b in range(B)]).to(dev)
 cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=k)
 for _ in range(2):
     eng.ggs_guide(x0, 0, cfg)
