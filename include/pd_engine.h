@@ -184,17 +184,6 @@ int pd_ggs_loss_grad(pd_engine *eng, const float *x, int B, int N, int update_R,
 
 /* ---- whole sampler ------------------------------------------------------------------------ */
 
-/* Engine options (no reference counterpart; they select between schedules of the same arithmetic).
- *   PD_OPT_DENOISER_WGS_PER_XCD  0 (default): every denoiser step is 43 dependent launches that use the whole chip;
- *        w in 1..32: pd_sample / pd_sample_phase run the denoiser steps on the per-XCD persistent kernel
- *        (posediffusion_amd/csrc/pd_denoiser_xcd.hip) with w workgroups (= CUs) on each of the 8 XCDs: one launch per
- *        run of unguided steps, no kernel boundaries inside.  32 = lowest latency for one batch alone; 8 leaves
- *        room for three more batches in flight.  Shapes the kernel does not cover (more than 64 token rows per
- *        XCD) silently keep the per-launch path; results agree to rounding order.
- * Changing an option drops the engine's captured hipGraphs. */
-#define PD_OPT_DENOISER_WGS_PER_XCD 1
-int pd_engine_set_option(pd_engine *eng, int option, int value);
-
 /* GaussianDiffusion.sample / p_sample_loop (gaussian_diffuser.py:284-306).
  *   z      [B,N,z_dim]                      DEVICE
  *   noise  [T+1,B,N,9]                      DEVICE  noise[0] = the randn(shape) of :289;

@@ -541,9 +541,7 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(dev_copy(d, &d->last_ln_b, w->last_ln_b, HID));
     PD_TRY(dev_copy(d, &d->last3_w, w->last3_w, 9 * HID));
     PD_TRY(dev_copy(d, &d->last3_b, w->last3_b, 9));
-    // the per-XCD kernel partitions the activation rows by XCD (sequence s -> XCD s % 8)
-    d->cap_x = (((eng->max_B + 7) / 8) * eng->max_N + 31) / 32 * 32;
-    const size_t rows = (size_t)std::max(d->m_cap, 8 * d->cap_x);
+    const size_t rows = (size_t)d->m_cap;
     PD_TRY(dev_alloc(d, &d->h, rows * DM));
     PD_TRY(dev_alloc(d, &d->qkv, rows * 3 * DM));
     PD_TRY(dev_alloc(d, &d->ctx, rows * DM));
@@ -561,11 +559,6 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
         }
         PD_TRY(dev_alloc(d, &d->sched, sc.size()));
         PD_HIP_CHECK(hipMemcpy(d->sched, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
-        float *bar = nullptr;
-        PD_TRY(dev_alloc(d, &bar, 8 * 32));
-        PD_HIP_CHECK(hipMemset(bar, 0, 8 * 32 * sizeof(float)));
-        d->xcd_bar = (unsigned *)bar;
-        PD_TRY(pd_denoiser_xcd_init());
     }
     PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0, 32>, 32 * (KFIRST_PAD + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0, 16>, 32 * (KFIRST_PAD + 4) * 4));

@@ -1,5 +1,5 @@
 // pd_denoiser_dev.h -- shapes, device-side weight tables and small wave helpers shared by the
-// per-launch denoiser kernels (pd_denoiser.hip) and the per-XCD persistent kernel (pd_denoiser_xcd.hip).
+// denoiser kernels (pd_denoiser.hip, pd_gemm_stream.h).
 #pragma once
 #include "pd_internal.h"
 
@@ -44,10 +44,7 @@ struct PdDenoiserDev {
     float *last3_w = nullptr, *last3_b = nullptr;   // [9,128] plain
     float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ff = nullptr, *hid = nullptr;   // activations [rows, .]
     float *hn = nullptr;               // LayerNorm(h) without affine, streamed path only
-    // per-XCD persistent kernel (pd_denoiser_xcd.hip): XCD x owns activation rows [x * cap_x, (x + 1) * cap_x)
-    int cap_x = 0;
     float *sched = nullptr;            // [T,8]: c_recip, c_recipm1, coef1, coef2, sigma per step
-    unsigned *xcd_bar = nullptr;       // [8][32] words: per-XCD arrival counter + its value at launch start
     std::vector<void *> allocs;
 };
 

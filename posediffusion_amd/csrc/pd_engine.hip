@@ -256,8 +256,6 @@ static int issue_loop(pd_engine *eng, int B, int N, int cond_start, const pd_ggs
     const int T = eng->timesteps;
     const size_t bn9 = (size_t)B * N * 9;
     float *proc = eng->d_process;
-    // per-XCD persistent denoiser (pd_engine_set_option): consecutive unguided steps are ONE launch
-    const bool xcd = pd_denoiser_xcd_applicable(eng, B, N);
     for (int step = step_begin; step < step_end; ++step) {
         const int t = T - 1 - step;                               // reversed(range(T))  :296
         const float *x = proc + (size_t)step * bn9;
@@ -266,16 +264,10 @@ static int issue_loop(pd_engine *eng, int B, int N, int cond_start, const pd_ggs
         int rc;
         if (guided) {
             // mean -> next slot, GGS refines it in place, noise = 0  (:272-276)
-            if (xcd) rc = pd_denoiser_xcd_launch(eng, B, N, step, step + 1, 0, s);
-            else rc = pd_denoiser_launch(eng, x, eng->d_z, t, B, N, nullptr, nullptr, nullptr, nullptr, xn, s);
+            rc = pd_denoiser_launch(eng, x, eng->d_z, t, B, N, nullptr, nullptr, nullptr, nullptr, xn, s);
             if (rc) return rc;
             float *st = want_stats ? eng->d_stats + (size_t)(cond_start - 1 - t) * B * 5 * 4 : nullptr;
             rc = pd_ggs_guide(eng, xn, B, N, t, ggs, st, s);
-        } else if (xcd) {
-            int last = step + 1;                                  // extend over the following unguided steps
-            while (last < step_end && !(ggs && T - 1 - last < cond_start)) ++last;
-            rc = pd_denoiser_xcd_launch(eng, B, N, step, last, 1, s);
-            step = last - 1;
         } else {
             const float *nz = (t > 0) ? eng->d_noise + (size_t)(step + 1) * bn9 : nullptr;   // :278
             rc = pd_denoiser_launch(eng, x, eng->d_z, t, B, N, nullptr, nullptr, nullptr, nz, xn, s);
@@ -337,7 +329,6 @@ extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *nois
         key.cond_start = has_ggs ? cond_start_step : 0;
         key.has_ggs = has_ggs;
         key.phase = phase;
-        key.den_wgs = eng->den_wgs_per_xcd;
         if (has_ggs) {
             key.cfg = *ggs;
             // the GGS nodes bake the match-derived launch shape in: a re-upload with another item count must not
@@ -350,7 +341,7 @@ extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *nois
         hipGraphExec_t exec = nullptr;
         for (auto &g : eng->graphs)
             if (g.first.B == B && g.first.N == N && g.first.cond_start == key.cond_start && g.first.has_ggs == key.has_ggs &&
-                g.first.phase == phase && g.first.den_wgs == key.den_wgs && same_cfg(g.first.cfg, key.cfg) &&
+                g.first.phase == phase && same_cfg(g.first.cfg, key.cfg) &&
                 memcmp(&g.first.plan, &key.plan, sizeof(PdGgsPlan)) == 0)
                 exec = g.second;
         if (!exec) {
@@ -392,30 +383,6 @@ extern "C" int pd_sample(pd_engine *eng, const float *z, const float *noise, int
                            stream);
 }
 
-// ---- options ------------------------------------------------------------------------------------
-extern "C" int pd_engine_set_option(pd_engine *eng, int option, int value) {
-    if (!eng) {
-        pd_set_error("pd_engine_set_option: NULL engine");
-        return PD_ERR_INVALID_ARG;
-    }
-    switch (option) {
-    case PD_OPT_DENOISER_WGS_PER_XCD:
-        if (value < 0 || value > 32) {
-            pd_set_error("pd_engine_set_option: PD_OPT_DENOISER_WGS_PER_XCD must be in [0, 32] (got %d)", value);
-            return PD_ERR_INVALID_ARG;
-        }
-        eng->den_wgs_per_xcd = value;
-        break;
-    default:
-        pd_set_error("pd_engine_set_option: unknown option %d", option);
-        return PD_ERR_INVALID_ARG;
-    }
-    // captured graphs bake the launch shapes in: drop them, the next pd_sample call captures again
-    for (auto &g : eng->graphs) (void)hipGraphExecDestroy(g.second);
-    eng->graphs.clear();
-    return PD_OK;
-}
-
 // ---- measurement helper -------------------------------------------------------------------------
 extern "C" int pd_time_kernel(pd_engine *eng, int what, int B, int N, const pd_ggs_cfg *cfg, int reps, float *ms_out,
                               void *stream) {
@@ -435,16 +402,6 @@ extern "C" int pd_time_kernel(pd_engine *eng, int what, int B, int N, const pd_g
         PD_HIP_CHECK(hipEventRecord(e0, s));
         for (int i = 0; i < reps && !rc; ++i)
             rc = pd_denoiser_launch(eng, eng->d_process, eng->d_z, 50, B, N, nullptr, eng->d_mean, nullptr, nullptr, nullptr, s);
-        PD_HIP_CHECK(hipEventRecord(e1, s));
-    } else if (what == 2) {
-        // the per-XCD persistent denoiser: `reps` consecutive steps in ONE launch (as the sampler uses it)
-        if (!pd_denoiser_xcd_applicable(eng, B, N) || reps > eng->timesteps - 1) {
-            pd_set_error("pd_time_kernel: per-XCD denoiser not enabled / not applicable (B=%d N=%d reps=%d)", B, N, reps);
-            return PD_ERR_STATE;
-        }
-        rc = pd_denoiser_xcd_launch(eng, B, N, 0, 1, 1, s);
-        PD_HIP_CHECK(hipEventRecord(e0, s));
-        if (!rc) rc = pd_denoiser_xcd_launch(eng, B, N, 0, reps, 1, s);
         PD_HIP_CHECK(hipEventRecord(e1, s));
     } else {
         if ((rc = check_cfg(cfg, "pd_time_kernel"))) return rc;

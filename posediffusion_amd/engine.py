@@ -255,11 +255,6 @@ class PoseEngine:
                    "pd_sample_phase")
         return pose, process, stats
 
-    def set_denoiser_wgs_per_xcd(self, w: int):
-        """0: per-launch denoiser kernels; 1..32: the per-XCD persistent kernel with w workgroups per XCD
-        for the sampler loop (include/pd_engine.h PD_OPT_DENOISER_WGS_PER_XCD)."""
-        _lib.check(self.lib.pd_engine_set_option(self._h, 1, int(w)), "pd_engine_set_option")
-
     def pose_to_camera(self, enc: torch.Tensor):
         enc = self._f32(enc).reshape(-1, 9)
         n = enc.shape[0]

@@ -585,72 +585,6 @@ def test_pipeline_gated_phases_match_whole_loop(seeded_diffuser):
 
 
 # ------------------------------------------------------------------------------------------------ per-XCD persistent denoiser
-@pytest.mark.parametrize("wgs", [32, 8, 3])
-def test_xcd_denoiser_free_running_vs_fp64_oracle(engine, golden, wgs):
-    """The per-XCD persistent kernel (one launch for all 100 steps) under the same criteria as the per-launch path."""
-    tr = golden["trajectory"]
-    z, noise = torch.from_numpy(tr["z"]).to(DEV), torch.from_numpy(tr["noise"]).to(DEV)
-    base = engine.sample(z, noise, 0, None, use_graph=True)[1].cpu()
-    engine.set_denoiser_wgs_per_xcd(wgs)
-    try:
-        outs = {}
-        for use_graph in (False, True):
-            pose, process, _ = engine.sample(z, noise, 0, None, use_graph=use_graph)
-            engine.check_async()
-            outs[use_graph] = process.cpu()
-            assert torch.equal(pose.cpu(), outs[use_graph][-1])
-    finally:
-        engine.set_denoiser_wgs_per_xcd(0)
-    assert torch.equal(outs[False], outs[True])
-    assert torch.equal(outs[True][0], torch.from_numpy(tr["noise"][0]))
-    assert rel_err(outs[True][1], base[1]) < TOL                 # one step: the same arithmetic up to the tile shape
-    p64 = tr["process64"]
-    ours, ref32 = rel_err(outs[True][-1], p64[-1]), rel_err(tr["process"][-1], p64[-1])
-    assert ours <= max(4.0 * ref32, 1e-4), (ours, ref32)     # chaotic tail: see test_sampler_free_running_vs_fp64_oracle
-    assert rel_err(outs[True][30], p64[30]) < 1e-4
-
-
-@pytest.mark.parametrize("B,N", [(1, 7), (8, 20), (11, 5), (3, 33), (16, 20), (5, 64)])
-def test_xcd_denoiser_shapes_vs_per_launch_path(seeded_diffuser, B, N):
-    """ragged shapes: one sequence on one XCD only, two sequences on some XCDs, 2 M-tiles per XCD, N = 64."""
-    from posediffusion_amd.engine import PoseEngine
-    from posediffusion_amd.host import denoiser_state, draw_noise
-    dev = torch.device(DEV)
-    diff = seeded_diffuser.to(dev)
-    tables = {k: v for k, v in diff.named_buffers(recurse=False)}
-    eng = PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=B, max_N=N)
-    z = synth.make_z(B, N, seed=900 + B).to(dev)
-    noise = torch.stack([draw_noise((N, 9), 100, dev, generator=torch.Generator(device=dev).manual_seed(31 * B + b))
-                         for b in range(B)], dim=1)
-    ref = eng.sample(z, noise, 0, None, use_graph=False)[1].cpu()
-    for wgs in (32, 5):
-        eng.set_denoiser_wgs_per_xcd(wgs)
-        out = eng.sample(z, noise, 0, None, use_graph=False)[1].cpu()
-        eng.check_async()
-        assert rel_err(out[1], ref[1]) < TOL and rel_err(out[5], ref[5]) < 1e-4
-        assert bool(torch.isfinite(out).all())
-    eng.close()
-
-
-def test_xcd_denoiser_guided_end_to_end_vs_reference_fixture(engine, golden):
-    """guided steps use single-step launches of the persistent kernel (mean only, no noise) before each GGS launch."""
-    g, gg = golden["guided"], golden["ggs"]
-    _upload(engine, gg)
-    z, noise = torch.from_numpy(g["z"]).to(DEV), torch.from_numpy(g["noise"]).to(DEV)
-    cfg = dict(synth.GGS_CFG, iter_num=int(g["iter_num"]))
-    base = engine.sample(z, noise, int(g["cond_start_step"]), cfg, use_graph=True)[1].cpu()
-    engine.set_denoiser_wgs_per_xcd(32)
-    try:
-        pose, process, stats = engine.sample(z, noise, int(g["cond_start_step"]), cfg, use_graph=True)
-        engine.check_async()
-    finally:
-        engine.set_denoiser_wgs_per_xcd(0)
-    ref = torch.from_numpy(g["process"])
-    assert rel_err(process[20], ref[20]) < 1e-4
-    # the whole guided trajectory stays as close to the per-launch engine path as that path is to the reference
-    assert rel_err(process[-1].cpu(), base[-1]) <= max(2.0 * rel_err(base[-1], ref[-1]), 1e-4)
-
-
 def test_pipeline_with_fresh_matches_per_batch(seeded_diffuser):
     """Streaming use: every submission uploads its own matches into its context first.  pd_ggs_set_matches waits
     for that engine's own work only (no device-wide synchronisation) and re-uses the slot's device blob; results are
