@@ -618,17 +618,16 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     launch_gemm<KFIRST_PAD, 2, 0>(g, d->first_wp, MT, eng->gemm_wide_min_tiles, s);
     // >= 1024 token rows (52 sequences of 20 frames): the encoder GEMMs are large enough for 64 x 64 tiles streamed through LDS
     // (pd_gemm_stream.h; same sums in another order than the 32-row split-K tiles below, i.e. rounding-level differences
-    // between small and large batches).  LayerNorm runs as its own kernel there (affine folded into the weights, as below).
+    // between small and large batches).  LayerNorm is fused into the A staging there too (pre-pass per workgroup; affine folded
+    // into the weights, as below).
     const bool streamed = M >= PD_STREAM_MIN_ROWS && d->hn;
     for (int l = 0; l < d->num_layers; ++l) {
         const PdLayerDev &L = d->layers[l];
         if (streamed) {
-            hipLaunchKernelGGL((pd_ln_rows_kernel<DM, false>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f);
-            pd_gemm_stream<0>(d->hn, DM, L.qkv_wf, DM, L.qkv_b, d->qkv, M, 3 * DM, s);
+            pd_gemm_stream<0, true>(d->h, DM, L.qkv_wf, DM, L.qkv_b, d->qkv, M, 3 * DM, s, 1e-5f);     // LayerNorm-1 in the A staging
             hipLaunchKernelGGL(pd_attn_kernel, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
             pd_gemm_stream<2>(d->ctx, DM, L.out_wf, DM, L.out_b, d->h, M, DM, s);
-            hipLaunchKernelGGL((pd_ln_rows_kernel<DM, false>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f);
-            pd_gemm_stream<1>(d->hn, DM, L.ff1_wf, DM, L.ff1_b, d->ff, M, DFF, s);
+            pd_gemm_stream<1, true>(d->h, DM, L.ff1_wf, DM, L.ff1_b, d->ff, M, DFF, s, 1e-5f);         // LayerNorm-2 likewise
             pd_gemm_stream<2>(d->ff, DFF, L.ff2_wf, DFF, L.ff2_b, d->h, M, DM, s);
             continue;
         }

@@ -13,6 +13,18 @@ __device__ __forceinline__ unsigned pd_split_word(float v) {
     return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
 }
 
+// sum over the 8 consecutive lanes that share an activation row in the staging of pd_gemm_stream_kernel (DPP: xor-1, xor-2
+// quad permutes + half-row mirror; every lane of the group ends with the total)
+template <int CTRL>
+__device__ __forceinline__ float pd_stream_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float pd_stream_sum8(float v) {
+    v = pd_stream_dpp_add<0xB1>(v);
+    v = pd_stream_dpp_add<0x4E>(v);
+    return pd_stream_dpp_add<0x141>(v);
+}
+
 // LayerNorm without affine (folded into the next weight): x [M, D] -> xn; one wave per row, D / 64 values per lane
 template <int D, bool SPLIT>
 __global__ __launch_bounds__(256) void pd_ln_rows_kernel(const float *__restrict__ x, float *__restrict__ xn, int M, float eps) {
@@ -59,13 +71,19 @@ struct PdStreamArgs {
     const float *A, *W, *bias;
     float *C;
     int M, Nout, K, lda, ldw;
+    float ln_eps;          // ALN only
 };
 #define PD_STREAM_KC 32
 #define PD_STREAM_LR (PD_STREAM_KC + 4)      // LDS row stride: fragment reads and staging writes both conflict free
 // staging registers are named scalars (arrays of float4 held across the K loop end up in scratch)
 #define VS_EACH(X) X(0) X(1) X(2) X(3)
 
-template <int EPI, int WM, int WN>
+// ALN: A' = LayerNorm(A) without affine (gamma / beta folded into W / bias), K = the normalised width.  Every thread stages the
+// same two rows (sr, sr + 32) in every chunk, 8 threads per row: a two-pass pre-pass over those rows (L2 reads; mean, then
+// variance, summed over the row's 8 threads on the DPP network) leaves mean / rstd in registers and the staging stores apply
+// them -- no separate LayerNorm launch and no normalised copy of the activations in memory.  Every column tile repeats the
+// pre-pass of its rows (24 x for the 1536-wide QKV): ~1 us of L2 reads per workgroup against ~6 us of launch it replaces.
+template <int EPI, int WM, int WN, bool ALN = false>
 __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
     constexpr int KC = PD_STREAM_KC, LR = PD_STREAM_LR, TM = 64 * WM, TN = 64 * WN, PA = 2 * WM, PW = 2 * WN, GROUP = 2048 / TM;
     static_assert(KC == 32 && PA <= 4 && PW <= 4, "staging: 8 float4 per row, passes of 32 rows");
@@ -95,10 +113,44 @@ __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
 #define VS_LOAD(j)                       \
     if constexpr (j < PA) ra##j = ap##j[nx]; \
     if constexpr (j < PW) rw##j = wp##j[nx];
-#define VS_STORE(j)                                                    \
-    if constexpr (j < PA) *(float4 *)(da + st + j * 32 * LR) = ra##j; \
+#define VS_STORE(j)                                                                                          \
+    if constexpr (j < PA) {                                                                                   \
+        float4 t_ = ra##j;                                                                                    \
+        if constexpr (ALN) {                                                                                  \
+            t_.x = (t_.x - ln_mu[j < PA ? j : 0]) * ln_rs[j < PA ? j : 0];                                    \
+            t_.y = (t_.y - ln_mu[j < PA ? j : 0]) * ln_rs[j < PA ? j : 0];                                    \
+            t_.z = (t_.z - ln_mu[j < PA ? j : 0]) * ln_rs[j < PA ? j : 0];                                    \
+            t_.w = (t_.w - ln_mu[j < PA ? j : 0]) * ln_rs[j < PA ? j : 0];                                    \
+        }                                                                                                     \
+        *(float4 *)(da + st + j * 32 * LR) = t_;                                                              \
+    }                                                                                                         \
     if constexpr (j < PW) *(float4 *)(dw + st + j * 32 * LR) = rw##j;
     VS_EACH(VS_DECL)
+    float ln_mu[PA], ln_rs[PA];
+    if constexpr (ALN) {
+        static_assert(!ALN || PA == 2, "LayerNorm pre-pass is written for 64-row tiles");
+        const float inv_k = 1.0f / (float)g.K;
+        const int n4 = g.K / 32;                      // float4 per thread and row (8 threads per row)
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const float4 *row = (j == 0 ? ap0 : ap1);    // + sc already applied; stride 8 float4 between this thread's pieces
+            float s_ = 0.0f;
+            for (int i = 0; i < n4; i += 4) {
+                const float4 a = row[8 * i], b = row[8 * (i + 1)], c = row[8 * (i + 2)], d = row[8 * (i + 3)];
+                s_ += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w));
+            }
+            const float mu = pd_stream_sum8(s_) * inv_k;
+            float q_ = 0.0f;
+            for (int i = 0; i < n4; i += 4) {
+                const float4 a = row[8 * i], b = row[8 * (i + 1)], c = row[8 * (i + 2)], d = row[8 * (i + 3)];
+#define PD_SQ4(v) (((v.x - mu) * (v.x - mu) + (v.y - mu) * (v.y - mu)) + ((v.z - mu) * (v.z - mu) + (v.w - mu) * (v.w - mu)))
+                q_ += (PD_SQ4(a) + PD_SQ4(b)) + (PD_SQ4(c) + PD_SQ4(d));
+#undef PD_SQ4
+            }
+            ln_mu[j] = mu;
+            ln_rs[j] = 1.0f / sqrtf(pd_stream_sum8(q_) * inv_k + g.ln_eps);
+        }
+    }
     {
         const int nx = 0;
         float *da = As, *dw = Ws;
@@ -174,9 +226,10 @@ __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
 #define PD_STREAM_MIN_ROWS 1024
 // 64 x 64 tiles: 128 x 64 and 128 x 128 (WM / WN = 2) measured no faster at 31 520 rows and slower at 3 940
 // (profiles/round1_j_vit_notes.md), so only <EPI, 1, 1> is instantiated
-template <int EPI>
-static inline void pd_gemm_stream(const float *A, int lda, const float *W, int K, const float *bias, float *C, int M, int Nout, hipStream_t s) {
-    PdStreamArgs g{A, W, bias, C, M, Nout, K, lda, K};
+template <int EPI, bool ALN = false>
+static inline void pd_gemm_stream(const float *A, int lda, const float *W, int K, const float *bias, float *C, int M, int Nout, hipStream_t s,
+                                  float ln_eps = 0.0f) {
+    PdStreamArgs g{A, W, bias, C, M, Nout, K, lda, K, ln_eps};
     const size_t lds = (size_t)2 * 128 * PD_STREAM_LR * sizeof(float);
-    hipLaunchKernelGGL((pd_gemm_stream_kernel<EPI, 1, 1>), dim3(((M + 63) / 64) * (Nout / 64)), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((pd_gemm_stream_kernel<EPI, 1, 1, ALN>), dim3(((M + 63) / 64) * (Nout / 64)), dim3(256), lds, s, g);
 }
