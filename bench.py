@@ -262,6 +262,8 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (the sampling path has no CPU fallback)")
+    if os.environ.get("PD_DIST_BACKEND") == "gloo":
+        local = 0                      # functional check: several ranks share the one GPU of the box (shard.init_distributed)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -272,11 +274,13 @@ def main():
     K = args.steps
     strong = args.scaling == "strong"
     step_total = args.seqs_per_step * (1 if strong else world)                  # sequences of one step over all ranks
-    g0, g1 = shard.partition(step_total, world, rank) if strong else (rank * args.seqs_per_step, (rank + 1) * args.seqs_per_step)
+    if strong:
+        g0, g1, group, _ = shard.strong_schedule(K, step_total, world, rank, args.engine_batch)
+    else:
+        g0, g1, group = rank * args.seqs_per_step, (rank + 1) * args.seqs_per_step, max(1, args.engine_batch // args.seqs_per_step)
     B_step = g1 - g0                                                            # this rank's sequences of one step
     if B_step <= 0:
         raise SystemExit(f"rank {rank} has no sequences: {step_total} per step over {world} ranks")
-    group = max(1, args.engine_batch // B_step)                                 # steps per engine pass
     EB = B_step * group                                                         # sequences per engine pass
     depth = max(1, args.pipeline_depth)
 
@@ -322,7 +326,10 @@ def main():
     pend = [submit(b) for b in passes_for(K)]
     torch.cuda.synchronize()
     # poses of step s = rows [(s % group) * B_step, +B_step) of pass s // group; ONE all_gather of all K steps (still timed)
-    per_step = [pend[s // group].pose[(s % group) * B_step:(s % group + 1) * B_step] for s in range(K)]
+    per_step = []
+    for s_ in range(K):
+        p_, r0, r1 = shard.step_rows(s_, group, B_step)
+        per_step.append(pend[p_].pose[r0:r1])
     gathered = shard.gather_poses(torch.stack(per_step, dim=1).contiguous(), step_total)     # [step_total, K, N, 9]
     torch.cuda.synchronize()
     shard.barrier()

@@ -31,7 +31,9 @@ def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # PD_DIST_BACKEND=gloo: several ranks on ONE GPU (functional check of the N > 1 path on a 1-GPU box; RCCL needs
+            # a device per rank)
+            backend = os.environ.get("PD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         if backend == "nccl":
@@ -48,17 +50,20 @@ def gather_poses(local: torch.Tensor, n_total: int) -> torch.Tensor:
     world = dist.get_world_size()
     sizes = [partition(n_total, world, r) for r in range(world)]
     cap = max(b - a for a, b in sizes)
+    dev = local.device
+    if dist.get_backend() == "gloo" and local.is_cuda:      # gloo gathers host tensors only
+        local = local.cpu()
     pad = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     bufs: List[torch.Tensor] = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
-    return torch.cat([bufs[r][: b - a] for r, (a, b) in enumerate(sizes)], dim=0)
+    return torch.cat([bufs[r][: b - a] for r, (a, b) in enumerate(sizes)], dim=0).to(dev)
 
 
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -66,3 +71,22 @@ def max_over_ranks(value: float, device) -> float:
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def strong_schedule(n_steps: int, step_seqs: int, world: int, rank: int, engine_batch: int):
+    """Strong scaling of `n_steps` steps of `step_seqs` independent sequences each over `world` ranks (bench.py):
+    every step is block-partitioned, rank r owning rows [g0, g1) of each; a rank runs the shards of `group` consecutive
+    steps as ONE engine pass so that its launches keep `engine_batch` sequences.  -> (g0, g1, group, passes) where
+    passes[p] = number of this rank's sequences in pass p (group * (g1 - g0), the last pass possibly fewer)."""
+    g0, g1 = partition(step_seqs, world, rank)
+    b_step = g1 - g0
+    if b_step <= 0:
+        return g0, g1, 1, []
+    group = max(1, engine_batch // b_step)
+    passes = [min(group, n_steps - s0) * b_step for s0 in range(0, n_steps, group)]
+    return g0, g1, group, passes
+
+
+def step_rows(step: int, group: int, b_step: int):
+    """Where step `step`'s shard sits: (pass index, first row, end row) inside that pass's [passes[p], N, 9] result."""
+    return step // group, (step % group) * b_step, (step % group + 1) * b_step

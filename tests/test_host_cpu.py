@@ -181,3 +181,26 @@ def test_colmap_keypoint_bookkeeping_vs_reference_fixture(golden):
     assert np.array_equal(keypoints[1], g["colmap_kp_1"])                     # the caller's dict is not modified
     with pytest.raises(ImportError):
         me.extract_match(image_folder_path="x")
+
+
+def test_strong_scaling_schedule_covers_every_sequence_once():
+    """bench.py's strong-scaling plan (posediffusion_amd/shard.py): K steps x 64 sequences over 1/2/4/8 (and an uneven 3)
+    ranks -- every (step, sequence) lands on exactly one rank, in one pass, at the rows `step_rows` says, and a rank's
+    engine passes hold `engine_batch` sequences except the last."""
+    from posediffusion_amd import shard
+    for world in (1, 2, 3, 4, 8):
+        for K in (1, 5, 20, 24):
+            seen = {}
+            for rank in range(world):
+                g0, g1, group, passes = shard.strong_schedule(K, 64, world, rank, 64)
+                b = g1 - g0
+                assert sum(passes) == K * b and all(p == group * b for p in passes[:-1]) and 0 < passes[-1] <= group * b
+                assert group * b <= 64
+                for step in range(K):
+                    p, r0, r1 = shard.step_rows(step, group, b)
+                    assert r1 - r0 == b and r1 <= passes[p]
+                    for q in range(b):
+                        key = (step, g0 + q)
+                        assert key not in seen
+                        seen[key] = (rank, p, r0 + q)
+            assert len(seen) == K * 64
