@@ -450,15 +450,43 @@ __device__ __forceinline__ void item_pass(const Src &src, int cnt, int lane, con
     }
 }
 
-// LDS-DMA of one 1 KiB piece (64 lanes x 16 B, lane-linear at the wave-uniform LDS byte address `lds_dst`) straight from
+// LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land lane-linear at the wave-uniform LDS byte address in M0) straight from
 // global memory, no VGPR round trip.  Hand-issued: hipcc neither counts it (so nothing drains it at the next s_barrier and a
 // prefetch can cross the serial phases of an iteration) nor waits for it -- every consumer waits with pd_vmcnt<> itself,
 // and the kernel drains before it exits (an LDS-DMA landing after the workgroup's LDS was handed on would corrupt it).
-__device__ __forceinline__ void pd_glds16(const float4 *gsrc, unsigned lds_dst) {
+// A whole staged item (P pieces of 1 KiB) in ONE statement: wave-uniform 64-bit base in SGPRs, a 32-bit byte offset per lane
+// and piece, M0 stepped by 1 KiB between the pieces -- ~3 instructions per piece instead of ~12 (64-bit address arithmetic,
+// M0 save / restore and readfirstlane per piece): the match pass is bound by how fast a wave ISSUES instructions.
+template <int P>
+__device__ __forceinline__ void pd_glds_item(const float4 *base, const unsigned (&off)[6], unsigned lds_dst) {
+    static_assert(P == 3 || P == 5 || P == 6, "staging pieces");
     unsigned keep;
-    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);   // wave-uniform by construction; the "s" constraint needs it provable
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    if constexpr (P == 3)
+        asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o0], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o1], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o2], %[b]\n\ts_mov_b32 m0, %[k]"
+                     : [k] "=&s"(keep) : [d] "s"(lds_dst), [b] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]) : "memory");
+    else if constexpr (P == 5)
+        asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o0], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o1], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o2], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o3], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o4], %[b]\n\ts_mov_b32 m0, %[k]"
+                     : [k] "=&s"(keep) : [d] "s"(lds_dst), [b] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]),
+                       [o3] "v"(off[3]), [o4] "v"(off[4]) : "memory");
+    else
+        asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o0], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o1], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o2], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o3], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o4], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o5], %[b]\n\ts_mov_b32 m0, %[k]"
+                     : [k] "=&s"(keep) : [d] "s"(lds_dst), [b] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]),
+                       [o3] "v"(off[3]), [o4] "v"(off[4]), [o5] "v"(off[5]) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void pd_vmcnt() {
@@ -549,16 +577,19 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
     const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(L.stage + wave * (2 * STAGE_P * 256)));
     const float4 *stage_ptr = (const float4 *)(L.stage + wave * (2 * STAGE_P * 256));
     int pb = 0;                                   // buffer that holds (or is receiving) the item computed next
+    // byte offsets of this lane's match in each piece (lane + 64 q), clamped per item to its last match
+    unsigned lane_off[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) lane_off[q] = (unsigned)(lane + 64 * q) * 16u;
     auto stage_item = [&](int slot, int buf) {
         int4 e = L.itab[slot];
-        e.x = __builtin_amdgcn_readfirstlane(e.x);
-        e.y = __builtin_amdgcn_readfirstlane(e.y);
-        const float4 *pts = D.pts + e.x;
-        const int last = e.y - 1;
+        const int first = __builtin_amdgcn_readfirstlane(e.x);
+        const unsigned last16 = (unsigned)(__builtin_amdgcn_readfirstlane(e.y) - 1) * 16u;
+        if constexpr (STAGE_P > 0) {
+            unsigned off[6];
 #pragma unroll
-        for (int q = 0; q < (STAGE_P > 0 ? STAGE_P : 1); ++q) {
-            const int m = lane + 64 * q;
-            pd_glds16(pts + (m < e.y ? m : last), stage_lds + (unsigned)(buf * STAGE_P + q) * 1024u);
+            for (int q = 0; q < 6; ++q) off[q] = min(lane_off[q], last16);     // no predicated loads: a clamped copy of the last match
+            pd_glds_item<STAGE_P>(D.pts + first, off, stage_lds + (unsigned)(buf * STAGE_P) * 1024u);
         }
     };
     if (staged) stage_item(wave, 0);
