@@ -44,6 +44,7 @@
 typedef unsigned long long u64;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define PD_XCHG_LINE 16   // granules per item record in the exchange buffer (one 128-byte line)
+#define PD_F_STRIDE 12    // floats per slot of the per-item F in LDS (9 used; 16-byte aligned rows)
 
 // --------------------------------------------------------------------------------------------
 // device helpers
@@ -260,7 +261,7 @@ struct Lds {
     float *psum;   // [64*16]  per-frame partial sums across chunks (N > 32 only)
     int4 *itab;    // [n_slots] (first match, count, i, j) of the local items
     int *incoff;   // [PD_GGS_MAX_PCHUNKS][68] per chunk of pairs: CSR offsets of its incidences per frame
-    float *F;      // [n_slots*9]
+    float *F;      // [n_slots*PD_F_STRIDE]
     float *item;   // [n_items*12]
     float *stage;  // [8 waves][2 buffers][STAGE_P KiB] LDS-DMA staging of the match pass (pd_ggs_kernel<STAGE_P > 0>), 1 KiB aligned
 };
@@ -281,13 +282,12 @@ __device__ __forceinline__ Lds carve(float *base, int n_slots, int pinc_rows, in
     L.itab = (int4 *)(L.psum + 64 * 16);
     L.incoff = (int *)(L.itab + n_slots);
     L.F = (float *)(L.incoff + PD_GGS_MAX_PCHUNKS * 68);
-    L.item = L.F + n_slots * 9 + ((4 - ((n_slots * 9) & 3)) & 3);
+    L.item = L.F + n_slots * PD_F_STRIDE;
     L.stage = base + ((((L.item + n_items_cap * PD_ITEM_VALS) - base) + 255) & ~255);   // 1 KiB aligned (base is the LDS origin)
     return L;
 }
 static size_t ggs_lds_bytes(int n_slots, int n_items, int pinc_rows, int stage_p) {
-    size_t f9 = (size_t)n_slots * 9;
-    f9 += (4 - (f9 & 3)) & 3;
+    const size_t f9 = (size_t)n_slots * PD_F_STRIDE;
     size_t b = ((size_t)PD_GGS_LDS_FIXED + (size_t)pinc_rows * 16 + PD_GGS_MAX_PCHUNKS * 68 + f9 + (size_t)n_items * PD_ITEM_VALS) * 4 +
                (size_t)n_slots * 16;
     if (stage_p > 0) b = ((b + 1023) & ~(size_t)1023) + (size_t)PD_GGS_WAVES * 2 * stage_p * 1024;
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
                     float F[9];
                     fundamental_from_E(f.E, cam, F);
 #pragma unroll
-                    for (int c = 0; c < 9; ++c) L.F[s * 9 + c] = F[c];
+                    for (int c = 0; c < 9; ++c) L.F[s * PD_F_STRIDE + c] = F[c];
                 }
             }
             __syncthreads();
@@ -686,8 +686,12 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
                 e.x = __builtin_amdgcn_readfirstlane(e.x);      // wave-uniform by construction: lets the step-count branches be scalar
                 e.y = __builtin_amdgcn_readfirstlane(e.y);
                 float Fm[9];
-#pragma unroll
-                for (int c = 0; c < 9; ++c) Fm[c] = L.F[s * 9 + c];
+                {   // three LDS reads (slot stride 12 floats, 16-byte aligned) instead of nine 4-byte ones
+                    const float4 f0 = *(const float4 *)(L.F + s * PD_F_STRIDE), f1 = *(const float4 *)(L.F + s * PD_F_STRIDE + 4);
+                    Fm[0] = f0.x; Fm[1] = f0.y; Fm[2] = f0.z; Fm[3] = f0.w;
+                    Fm[4] = f1.x; Fm[5] = f1.y; Fm[6] = f1.z; Fm[7] = f1.w;
+                    Fm[8] = L.F[s * PD_F_STRIDE + 8];
+                }
                 // two 64-match steps per pass: lane handles matches lane + 64*(2j) and lane + 64*(2j+1) together
                 v2f acc2[PD_ITEM_VALS];
                 if constexpr (RESIDENT) {   // straight from the resident registers (no copies)
@@ -1085,7 +1089,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                     float F[9];
                     fundamental_from_E(f.E, cam, F);
 #pragma unroll
-                    for (int c = 0; c < 9; ++c) L.F[s * 9 + c] = F[c];
+                    for (int c = 0; c < 9; ++c) L.F[s * PD_F_STRIDE + c] = F[c];
                 }
             }
             __syncthreads();
@@ -1097,8 +1101,12 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                 const int4 e = L.itab[s];
                 if (e.y > 0) {
                     float Fm[9];
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) Fm[c] = L.F[s * 9 + c];
+                    {   // three LDS reads (slot stride 12 floats, 16-byte aligned) instead of nine 4-byte ones
+                    const float4 f0 = *(const float4 *)(L.F + s * PD_F_STRIDE), f1 = *(const float4 *)(L.F + s * PD_F_STRIDE + 4);
+                    Fm[0] = f0.x; Fm[1] = f0.y; Fm[2] = f0.z; Fm[3] = f0.w;
+                    Fm[4] = f1.x; Fm[5] = f1.y; Fm[6] = f1.z; Fm[7] = f1.w;
+                    Fm[8] = L.F[s * PD_F_STRIDE + 8];
+                }
                     v2f acc2[PD_ITEM_VALS];
                     if (resident) {
                         item_pass<false>(MatchRegs{mres}, e.y, lane, Fm, P.sampson_max, acc2);
