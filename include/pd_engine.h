@@ -184,6 +184,16 @@ int pd_ggs_loss_grad(pd_engine *eng, const float *x, int B, int N, int update_R,
 
 /* ---- whole sampler ------------------------------------------------------------------------ */
 
+/* Engine options (no reference counterpart).
+ *   PD_OPT_DENOISER_SPLIT  0 (default): every GEMM of the denoiser on the exact-fp32 matrix instruction.
+ *        1: FAST MODE for batches of >= 1024 token rows: the four Linear layers of every encoder layer run in split precision
+ *        on the bf16 matrix pipe (each fp32 operand as bf16 hi + bf16 lo, three products, fp32 accumulation: ~16 mantissa
+ *        bits per operand); LayerNorm, softmax, residuals, `_first`, `_last` and the DDPM update stay fp32.  Narrower
+ *        arithmetic than the reference's: a separately reported mode, never the default (deviation measured in
+ *        tests/test_gpu_parity_r2.py and profiles/round2_denoiser_precision_study.json).  Smaller batches ignore it. */
+#define PD_OPT_DENOISER_SPLIT 2
+int pd_engine_set_option(pd_engine *eng, int option, int value);
+
 /* GaussianDiffusion.sample / p_sample_loop (gaussian_diffuser.py:284-306).
  *   z      [B,N,z_dim]                      DEVICE
  *   noise  [T+1,B,N,9]                      DEVICE  noise[0] = the randn(shape) of :289;

@@ -22,6 +22,7 @@
 //   * bias / ReLU / residual are fused into the epilogue.
 #include "pd_denoiser_dev.h"
 #include "pd_gemm_stream.h"
+#include "pd_gemm_split.h"
 
 #include <algorithm>
 #include <math.h>
@@ -314,6 +315,8 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
 // workgroup stages K and V of its (sequence, head) and each of its 4 waves owns ONE query row:
 // lane j scores key j, softmax is a wave reduction, lanes then own 2 of the 128 output dims.
 // --------------------------------------------------------------------------------------------
+// SPLIT_OUT: ctx is written as split words {bf16 hi | bf16 lo << 16} for pd_gemm_split (the fast mode)
+template <bool SPLIT_OUT>
 __global__ __launch_bounds__(256) void pd_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int N) {
     constexpr int LD = DH + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -361,8 +364,13 @@ __global__ __launch_bounds__(256) void pd_attn_kernel(const float *__restrict__ 
             o1 = fmaf(pj, V[j * LD + 64 + lane], o1);
         }
         float *out = ctx + (size_t)(b * N + i) * DM + h * DH;
-        out[lane] = o0;
-        out[64 + lane] = o1;
+        if constexpr (SPLIT_OUT) {
+            ((unsigned *)out)[lane] = pd_split_word(o0);
+            ((unsigned *)out)[64 + lane] = pd_split_word(o1);
+        } else {
+            out[lane] = o0;
+            out[64 + lane] = o1;
+        }
     }
 }
 
@@ -572,8 +580,41 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(set_lds(pd_gemm_kernel<DFF, 0, 2, 16>, 32 * (DFF + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DM, 0, 0, 32>, 32 * (DM + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DM, 0, 0, 16>, 32 * (DM + 4) * 4));
-    PD_TRY(set_lds(pd_attn_kernel, ((2 * 64 + 4) * (DH + 4) + 4 * 64) * 4));
+    PD_TRY(set_lds(pd_attn_kernel<false>, ((2 * 64 + 4) * (DH + 4) + 4 * 64) * 4));
+    PD_TRY(set_lds(pd_attn_kernel<true>, ((2 * 64 + 4) * (DH + 4) + 4 * 64) * 4));
     PD_HIP_CHECK(hipDeviceSynchronize());
+    return PD_OK;
+}
+
+// The fast mode's weights: every encoder Linear split into bf16 hi / lo in MFMA fragment order (LayerNorm scale folded as for
+// the other packings).  Built when the mode is first switched on, from the row-major fp32 copies kept for the streamed GEMMs.
+int pd_denoiser_build_split(pd_engine *eng) {
+    PdDenoiserDev *d = eng->den;
+    if (d->split_ready) return PD_OK;
+    if (!d->hn) {
+        pd_set_error("split-precision denoiser: the engine was created for fewer than %d token rows (max_B x max_N); the mode "
+                     "applies to the streamed large-batch path only", PD_STREAM_MIN_ROWS);
+        return PD_ERR_UNSUPPORTED;
+    }
+    auto split = [&](unsigned **dst, const float *Wf, int Nout, int K) -> int {
+        float *p = nullptr;
+        int rc = dev_alloc(d, &p, (size_t)Nout * K);
+        if (rc) return rc;
+        *dst = (unsigned *)p;
+        const size_t total = (size_t)(Nout / 32) * (K / 16) * 64;
+        hipLaunchKernelGGL(vit_frag_split_kernel, dim3(512), dim3(256), 0, 0, Wf, (const float *)nullptr, K, total, (uint4 *)p);   // gamma is already folded into Wf
+        PD_HIP_CHECK(hipGetLastError());
+        return PD_OK;
+    };
+    for (int l = 0; l < d->num_layers; ++l) {
+        PdLayerDev &L = d->layers[l];
+        PD_TRY(split(&L.qkv_ws, L.qkv_wf, 3 * DM, DM));
+        PD_TRY(split(&L.out_ws, L.out_wf, DM, DM));
+        PD_TRY(split(&L.ff1_ws, L.ff1_wf, DFF, DM));
+        PD_TRY(split(&L.ff2_ws, L.ff2_wf, DM, DFF));
+    }
+    PD_HIP_CHECK(hipDeviceSynchronize());
+    d->split_ready = true;
     return PD_OK;
 }
 
@@ -623,9 +664,21 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     const bool streamed = M >= PD_STREAM_MIN_ROWS && d->hn;
     for (int l = 0; l < d->num_layers; ++l) {
         const PdLayerDev &L = d->layers[l];
+        if (streamed && eng->den_split && d->split_ready) {
+            // fast mode: the four encoder GEMMs on the bf16 matrix pipe in split precision (pd_gemm_split.h); activations
+            // between them as split words -- LayerNorm, attention and the FF1 epilogue write them in place of fp32
+            hipLaunchKernelGGL((pd_ln_rows_kernel<DM, true>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f);
+            pd_gemm_split<0, 1, 2>((const unsigned *)d->hn, DM, L.qkv_ws, DM, L.qkv_b, d->qkv, M, 3 * DM, s);
+            hipLaunchKernelGGL(pd_attn_kernel<true>, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
+            pd_gemm_split<2, 1, 1>((const unsigned *)d->ctx, DM, L.out_ws, DM, L.out_b, d->h, M, DM, s);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<DM, true>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f);
+            pd_gemm_split<4, 1, 2>((const unsigned *)d->hn, DM, L.ff1_ws, DM, L.ff1_b, d->ff, M, DFF, s);
+            pd_gemm_split<2, 1, 1>((const unsigned *)d->ff, DFF, L.ff2_ws, DFF, L.ff2_b, d->h, M, DM, s);
+            continue;
+        }
         if (streamed) {
             pd_gemm_stream<0, true>(d->h, DM, L.qkv_wf, DM, L.qkv_b, d->qkv, M, 3 * DM, s, 1e-5f);     // LayerNorm-1 in the A staging
-            hipLaunchKernelGGL(pd_attn_kernel, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
+            hipLaunchKernelGGL(pd_attn_kernel<false>, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
             pd_gemm_stream<2>(d->ctx, DM, L.out_wf, DM, L.out_b, d->h, M, DM, s);
             pd_gemm_stream<1, true>(d->h, DM, L.ff1_wf, DM, L.ff1_b, d->ff, M, DFF, s, 1e-5f);         // LayerNorm-2 likewise
             pd_gemm_stream<2>(d->ff, DFF, L.ff2_wf, DFF, L.ff2_b, d->h, M, DM, s);
@@ -634,7 +687,7 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
         // x += MHA(LN1(x))
         g.A = d->h; g.bias = L.qkv_b; g.C = d->qkv; g.Nout = 3 * DM;
         launch_gemm<DM, 1, 0>(g, L.qkv_wp, MT, eng->gemm_wide_min_tiles, s);
-        hipLaunchKernelGGL(pd_attn_kernel, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
+        hipLaunchKernelGGL(pd_attn_kernel<false>, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
         g.A = d->ctx; g.bias = L.out_b; g.C = d->h; g.Nout = DM;
         launch_gemm<DM, 0, 2>(g, L.out_wp, MT, eng->gemm_wide_min_tiles, s);
         // x += W2 relu(W1 LN2(x))

@@ -33,6 +33,7 @@ struct PdLayerDev {          // [0] = 32-wide-tile packing, [1] = 16-wide-tile p
     float *ff1_wp[2], *ff1_b;  // LayerNorm-2 folded likewise
     float *ff2_wp[2], *ff2_b;
     float *qkv_wf, *out_wf, *ff1_wf, *ff2_wf;   // row-major copies (LayerNorm scale folded) for the streamed GEMM at >= 1024 token rows
+    unsigned *qkv_ws, *out_ws, *ff1_ws, *ff2_ws;   // split into bf16 hi / lo in MFMA fragment order (pd_gemm_split.h): the fast mode, built on demand
 };
 
 struct PdDenoiserDev {
@@ -45,6 +46,7 @@ struct PdDenoiserDev {
     float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ff = nullptr, *hid = nullptr;   // activations [rows, .]
     float *hn = nullptr;               // LayerNorm(h) without affine, streamed path only
     float *sched = nullptr;            // [T,8]: c_recip, c_recipm1, coef1, coef2, sigma per step
+    bool split_ready = false;          // the fast mode's split weights exist
     std::vector<void *> allocs;
 };
 

@@ -329,6 +329,7 @@ extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *nois
         key.cond_start = has_ggs ? cond_start_step : 0;
         key.has_ggs = has_ggs;
         key.phase = phase;
+        key.den_split = eng->den_split;
         if (has_ggs) {
             key.cfg = *ggs;
             // the GGS nodes bake the match-derived launch shape in: a re-upload with another item count must not
@@ -341,7 +342,7 @@ extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *nois
         hipGraphExec_t exec = nullptr;
         for (auto &g : eng->graphs)
             if (g.first.B == B && g.first.N == N && g.first.cond_start == key.cond_start && g.first.has_ggs == key.has_ggs &&
-                g.first.phase == phase && same_cfg(g.first.cfg, key.cfg) &&
+                g.first.phase == phase && g.first.den_split == key.den_split && same_cfg(g.first.cfg, key.cfg) &&
                 memcmp(&g.first.plan, &key.plan, sizeof(PdGgsPlan)) == 0)
                 exec = g.second;
         if (!exec) {
@@ -381,6 +382,32 @@ extern "C" int pd_sample(pd_engine *eng, const float *z, const float *noise, int
                          void *stream) {
     return pd_sample_phase(eng, z, noise, B, N, cond_start_step, ggs, PD_PHASE_ALL, pose_out, process_out, stats_out, use_graph,
                            stream);
+}
+
+// ---- options ------------------------------------------------------------------------------------
+extern "C" int pd_engine_set_option(pd_engine *eng, int option, int value) {
+    if (!eng) {
+        pd_set_error("pd_engine_set_option: NULL engine");
+        return PD_ERR_INVALID_ARG;
+    }
+    switch (option) {
+    case PD_OPT_DENOISER_SPLIT:
+        if (value != 0 && value != 1) {
+            pd_set_error("pd_engine_set_option: PD_OPT_DENOISER_SPLIT takes 0 or 1 (got %d)", value);
+            return PD_ERR_INVALID_ARG;
+        }
+        if (value) {
+            PD_HIP_CHECK(hipSetDevice(eng->device));
+            int rc = pd_denoiser_build_split(eng);
+            if (rc) return rc;
+        }
+        eng->den_split = value;
+        break;
+    default:
+        pd_set_error("pd_engine_set_option: unknown option %d", option);
+        return PD_ERR_INVALID_ARG;
+    }
+    return PD_OK;      // (captured graphs are keyed on the option: nothing to drop)
 }
 
 // ---- measurement helper -------------------------------------------------------------------------

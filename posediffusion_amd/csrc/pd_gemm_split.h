@@ -1,0 +1,209 @@
+// pd_gemm_split.h -- split-precision GEMM on the bf16 matrix pipe, shared by the image feature extractor (pd_vit.hip) and the
+// denoiser's fast mode (pd_denoiser.hip): every fp32 operand is carried as bf16 hi + bf16 lo (x ~= hi + lo, 16 mantissa bits),
+// x * w ~= hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (16 x the rate of the f32 instruction per product, three
+// products), fp32 accumulation.  Activations between kernels are one 32-bit word per element {hi | lo << 16}
+// (pd_split_word, pd_gemm_stream.h).
+#pragma once
+#include "pd_gemm_stream.h"
+
+// GELU for the split-precision path: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, below the 2^-17 the split operands
+// keep), a dozen instructions instead of erff's ~35 -- the epilogue of fc1 is as long as its matrix loop otherwise.
+// 0.5 v (1 + erf(v / sqrt 2)) = v (1 - q / 2) for v >= 0 and v q / 2 for v < 0, q = erfc(|v| / sqrt 2) (no cancellation).
+__device__ __forceinline__ float vit_gelu_fast(float v) {
+    const float x = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float q = 0.5f * p * t * __expf(-x * x);
+    return v * (v >= 0.0f ? 1.0f - q : q);
+}
+
+// W[n][k] * gamma[k] -> split and packed in MFMA fragment order: [n / 32][k / 16][hi | lo][lane] x 16 B, lane = (n % 32) +
+// 32 * ((k / 8) % 2), 8 consecutive k per lane: one wave-wide 16-byte load is 1 KB contiguous
+static __global__ void vit_frag_split_kernel(const float *__restrict__ W, const float *__restrict__ gamma, int K, size_t total, uint4 *__restrict__ out) {
+    const int KS = K / 16;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const size_t t = idx >> 6;
+        const int ks = (int)(t % KS), nt = (int)(t / KS);
+        const int n = nt * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+        unsigned w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = W[(size_t)n * K + k0 + e];
+            w[e] = pd_split_word(gamma ? v * gamma[k0 + e] : v);
+        }
+        uint4 hi, lo;
+        hi.x = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u); lo.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
+        hi.y = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u); lo.y = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+        hi.z = __builtin_amdgcn_perm(w[5], w[4], 0x05040100u); lo.z = __builtin_amdgcn_perm(w[5], w[4], 0x07060302u);
+        hi.w = __builtin_amdgcn_perm(w[7], w[6], 0x05040100u); lo.w = __builtin_amdgcn_perm(w[7], w[6], 0x07060302u);
+        out[(t * 2) * 64 + lane] = hi;
+        out[(t * 2 + 1) * 64 + lane] = lo;
+    }
+}
+
+struct VitSplitArgs {
+    const unsigned *A, *W;      // A: split words [M][lda]; W: vit_frag_split_kernel's fragment order
+    const float *bias;
+    void *C;                    // EPI 0 / 2: fp32 [M][Nout]; EPI 3 (gelu) / 4 (relu): split words [M][Nout]
+    int M, Nout, K, lda;
+};
+
+// A rows stream through LDS (un-zipped into hi / lo fragments on the way, shared by the waves of a row block); the weight
+// fragments go straight from global memory / L2 to registers, one chunk ahead (they are already in operand order, and
+// keeping them out of LDS halves its traffic -- the LDS array, not the matrix pipe, limited the first version).
+template <int EPI, int WM, int WN>
+__global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
+    constexpr int KC = PD_STREAM_KC, LR = PD_STREAM_LR, TM = 64 * WM, TN = 64 * WN, GROUP = 2048 / TM;
+    static_assert(KC == 32 && WM <= 2 && WN <= 2, "staging: 4 groups of 8 per row chunk, passes of 64 rows");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned *As = (unsigned *)lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5, wm = wave & 1, wn = wave >> 1;
+    const int MT = (g.M + TM - 1) / TM, NT = g.Nout / TN;
+    int mtile, ntile;
+    {
+        const int b = blockIdx.x, full = (MT / GROUP) * GROUP * NT;
+        if (b < full) {
+            const int grp = b / (NT * GROUP), r = b - grp * (NT * GROUP);
+            ntile = r / GROUP;
+            mtile = grp * GROUP + r % GROUP;
+        } else {
+            const int r = b - full, rest = MT % GROUP;
+            ntile = r / rest;
+            mtile = (MT / GROUP) * GROUP + r % rest;
+        }
+    }
+    const int m0 = mtile * TM, n0 = ntile * TN;
+    const int sr = tid >> 2, sg = tid & 3, st = sr * LR + 8 * sg;      // 4 threads per row chunk, one group of 8 each
+    const int KS = g.K / 16;
+#define VP_EACH(X) X(0) X(1)
+#define VP_DECL(j)                                                                                                            \
+    const uint4 *ap##j = (const uint4 *)(g.A + (size_t)min(m0 + sr + 64 * (j < WM ? j : 0), g.M - 1) * g.lda) + 2 * sg;        \
+    const uint4 *wq##j = (const uint4 *)g.W + (size_t)(n0 / 32 + wn * WN + (j < WN ? j : 0)) * KS * 128 + lane;                 \
+    uint4 ra##j##a, ra##j##b, cw##j##0h, cw##j##0l, cw##j##1h, cw##j##1l, nw##j##0h, nw##j##0l, nw##j##1h, nw##j##1l;
+#define VP_LOAD(j)                                  \
+    if constexpr (j < WM) {                         \
+        ra##j##a = ap##j[nx];                       \
+        ra##j##b = ap##j[nx + 1];                   \
+    }                                               \
+    if constexpr (j < WN) {                         \
+        nw##j##0h = wq##j[(size_t)(nc * 4 + 0) * 64]; \
+        nw##j##0l = wq##j[(size_t)(nc * 4 + 1) * 64]; \
+        nw##j##1h = wq##j[(size_t)(nc * 4 + 2) * 64]; \
+        nw##j##1l = wq##j[(size_t)(nc * 4 + 3) * 64]; \
+    }
+#define VP_ROLL(j)             \
+    if constexpr (j < WN) {    \
+        cw##j##0h = nw##j##0h; \
+        cw##j##0l = nw##j##0l; \
+        cw##j##1h = nw##j##1h; \
+        cw##j##1l = nw##j##1l; \
+    }
+#define VP_STORE(j)                                                                                       \
+    if constexpr (j < WM) {                                                                               \
+        uint4 h, l;                                                                                       \
+        h.x = __builtin_amdgcn_perm(ra##j##a.y, ra##j##a.x, 0x05040100u);                                 \
+        l.x = __builtin_amdgcn_perm(ra##j##a.y, ra##j##a.x, 0x07060302u);                                 \
+        h.y = __builtin_amdgcn_perm(ra##j##a.w, ra##j##a.z, 0x05040100u);                                 \
+        l.y = __builtin_amdgcn_perm(ra##j##a.w, ra##j##a.z, 0x07060302u);                                 \
+        h.z = __builtin_amdgcn_perm(ra##j##b.y, ra##j##b.x, 0x05040100u);                                 \
+        l.z = __builtin_amdgcn_perm(ra##j##b.y, ra##j##b.x, 0x07060302u);                                 \
+        h.w = __builtin_amdgcn_perm(ra##j##b.w, ra##j##b.z, 0x05040100u);                                 \
+        l.w = __builtin_amdgcn_perm(ra##j##b.w, ra##j##b.z, 0x07060302u);                                 \
+        *(uint4 *)(da + st + j * 64 * LR) = h;                                                            \
+        *(uint4 *)(da + st + j * 64 * LR + 4) = l;                                                        \
+    }
+// the three products of one (column tile j, k step s) against every row tile
+#define VP_MMA(j, s)                                                                                                         \
+    if constexpr (j < WN) {                                                                                                  \
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, cw##j##s##h), bl = __builtin_bit_cast(bf16x8, cw##j##s##l);               \
+        _Pragma("unroll") for (int mi = 0; mi < WM; ++mi) {                                                                  \
+            acc[mi][j < WN ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al##s[mi], bh, acc[mi][j < WN ? j : 0], 0, 0, 0); \
+            acc[mi][j < WN ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah##s[mi], bl, acc[mi][j < WN ? j : 0], 0, 0, 0); \
+            acc[mi][j < WN ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah##s[mi], bh, acc[mi][j < WN ? j : 0], 0, 0, 0); \
+        }                                                                                                                    \
+    }
+    VP_EACH(VP_DECL)
+    {
+        const int nx = 0, nc = 0;
+        unsigned *da = As;
+        VP_EACH(VP_LOAD)
+        VP_EACH(VP_STORE)
+        VP_EACH(VP_ROLL)
+    }
+    __syncthreads();
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.0f;
+    const int nk = g.K / KC;
+    const int aoff = (wm * 32 * WM + l31) * LR + 8 * hi;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int nc = min(kc + 1, nk - 1), nx = nc * (KC / 4);       // the chunk after the last is the last again
+        VP_EACH(VP_LOAD)
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned *a = As + (kc & 1) * TM * LR + aoff;
+        bf16x8 ah0[WM], al0[WM], ah1[WM], al1[WM];     // 16 k per step: lanes 0-31 take group 2 s, lanes 32-63 group 2 s + 1
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+            ah0[mi] = __builtin_bit_cast(bf16x8, *(const uint4 *)(a + mi * 32 * LR));
+            al0[mi] = __builtin_bit_cast(bf16x8, *(const uint4 *)(a + mi * 32 * LR + 4));
+            ah1[mi] = __builtin_bit_cast(bf16x8, *(const uint4 *)(a + mi * 32 * LR + 16));
+            al1[mi] = __builtin_bit_cast(bf16x8, *(const uint4 *)(a + mi * 32 * LR + 20));
+        }
+        VP_MMA(0, 0)
+        VP_MMA(1, 0)
+        VP_MMA(0, 1)
+        VP_MMA(1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned *da = As + ((kc + 1) & 1) * TM * LR;
+        VP_EACH(VP_STORE)
+        VP_EACH(VP_ROLL)
+        __syncthreads();
+    }
+#undef VP_DECL
+#undef VP_LOAD
+#undef VP_ROLL
+#undef VP_STORE
+#undef VP_MMA
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            const int col = n0 + (wn * WN + ni) * 32 + l31, r0 = m0 + (wm * WM + mi) * 32 + 4 * hi;
+            const float bias = g.bias[col];
+            float res[16];
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) res[i] = ((const float *)g.C)[(size_t)min(r0 + (i & 3) + 8 * (i >> 2), g.M - 1) * g.Nout + col];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = r0 + (i & 3) + 8 * (i >> 2);
+                float v = acc[mi][ni][i] + bias;
+                if constexpr (EPI == 3) v = vit_gelu_fast(v);
+                if constexpr (EPI == 4) v = fmaxf(v, 0.0f);
+                if constexpr (EPI == 2) v += res[i];
+                if (row < g.M) {
+                    if constexpr (EPI == 3 || EPI == 4)
+                        ((unsigned *)g.C)[(size_t)row * g.Nout + col] = pd_split_word(v);
+                    else
+                        ((float *)g.C)[(size_t)row * g.Nout + col] = v;
+                }
+            }
+        }
+}
+
+static constexpr size_t pd_split_lds(int WM) { return (size_t)2 * 64 * WM * PD_STREAM_LR * sizeof(float); }
+template <int EPI, int WM, int WN>
+static inline void pd_gemm_split(const unsigned *A, int lda, const unsigned *W, int K, const float *bias, void *C, int M, int Nout, hipStream_t s) {
+    VitSplitArgs g{A, W, bias, C, M, Nout, K, lda};
+    constexpr int TM = 64 * WM, TN = 64 * WN;
+    hipLaunchKernelGGL((vit_gemm_split_kernel<EPI, WM, WN>), dim3(((M + TM - 1) / TM) * (Nout / TN)), dim3(256), pd_split_lds(WM), s, g);
+}

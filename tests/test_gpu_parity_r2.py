@@ -359,3 +359,47 @@ def test_async_match_ingestion_flags_bad_input(seeded_diffuser):
         eng.set_matches_async(0, torch.zeros(4, 2, dtype=torch.float64), torch.zeros(4, 2, dtype=torch.float64),
                               torch.zeros(4, 2, dtype=torch.int64), [0, 4], (N, 3, 224, 224))
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ fast mode (split precision)
+def test_split_precision_denoiser_fast_mode_deviation(seeded_diffuser, oracle_weights):
+    """PD_OPT_DENOISER_SPLIT (fast mode, never the default): the encoder GEMMs of the large-batch path as bf16 hi + lo, three
+    bf16 MFMA products, fp32 accumulation.  Measured here, not assumed: (a) one denoiser step at 1 040 token rows against the
+    fp32 oracle -- the split mode must stay inside the 1e-4 contract (the exact mode is asserted at 2e-5); (b) 100 free-running
+    steps against the fp64 oracle next to the exact mode's own deviation (chaotic with random-init weights: same order of
+    magnitude is the bound, as for the exact mode in test_sampler_free_running_vs_fp64_oracle)."""
+    from posediffusion_amd.engine import PoseEngine
+    from posediffusion_amd.host import denoiser_state, draw_noise
+    dev = torch.device(DEV)
+    diff = seeded_diffuser.to(dev)
+    B, N = 52, 20                                                       # 1 040 rows: the streamed path
+    eng = PoseEngine(denoiser_state(diff.model), {k: v for k, v in diff.named_buffers(recurse=False)}, device=dev, max_B=B, max_N=N)
+    g = torch.Generator().manual_seed(77)
+    x, z = torch.randn(B, N, 9, generator=g), synth.make_z(B, N, seed=3)
+    devs = {}
+    for t in (99, 40, 0):
+        ref = O.denoiser_forward(oracle_weights, x, torch.full((B,), t, dtype=torch.long), z)
+        for mode in (False, True):
+            eng.set_split_precision(mode)
+            devs[(t, mode)] = rel_err(eng.denoise(x.to(dev), z.to(dev), t), ref)
+    print("denoiser step vs fp32 oracle, (t, split) -> rel:", {k: f"{v:.2e}" for k, v in devs.items()})
+    assert all(v < TOL for (t, m), v in devs.items() if not m)
+    assert all(v < 1e-4 for (t, m), v in devs.items() if m)
+    # free-running: 100 steps, GGS off, against the fp64 oracle (8 sequences of the batch are enough for the oracle's clock)
+    noise = draw_noise((B, N, 9), 100, dev, generator=torch.Generator(device=dev).manual_seed(5))
+    finals = {}
+    for mode in (False, True):
+        eng.set_split_precision(mode)
+        pose, _, _ = eng.sample(z.to(dev), noise, 0, None, use_graph=True, want_process=False)
+        finals[mode] = pose.cpu()
+    eng.set_split_precision(False)
+    sub = slice(0, 4)
+    sd64 = {k: v.double() for k, v in oracle_weights.items()}
+    t64 = O.diffusion_tables(dtype=torch.float64)
+    nz = noise.cpu().double()
+    with torch.no_grad():
+        p64, _ = O.p_sample_loop(sd64, t64, z[sub].double(), nz[0][sub], [None if t == 0 else nz[100 - t][sub] for t in range(100)])
+    d_exact, d_split = rel_err(finals[False][sub], p64), rel_err(finals[True][sub], p64)
+    print(f"free-running 100 steps vs fp64: exact fp32 mode {d_exact:.2e}, split mode {d_split:.2e}; split vs exact {rel_err(finals[True], finals[False]):.2e}")
+    assert d_split <= max(4.0 * d_exact, 1e-3), (d_split, d_exact)
+    eng.close()
