@@ -245,7 +245,7 @@ __device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, 
 }
 
 // LDS carve (floats).  Everything lives in the one dynamic region (guide G17).
-#define PD_GGS_LDS_FIXED (64 * 9 + 64 * 3 + 64 * 2 + 64 * 2 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8 + 64 * 16)   // + pinc_rows * 16
+#define PD_GGS_LDS_FIXED (64 * 9 + 64 * 3 + 64 * 2 + 64 * 2 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8 + 64 * 16 + 2 * 64 * 9)   // + pinc_rows * 16
 struct Lds {
     float *Rc;     // [64*9]  R_cv per frame  (opencv_from_cameras_projection)
     float *tc;     // [64*3]
@@ -256,6 +256,8 @@ struct Lds {
     float *gR;     // [64*9]  per-frame dL/dR  (PyTorch3D R, un-normalised)
     float *gA;     // [64*4]  per-frame partial dL/dA {00,02,11,12}
     float *ctl;    // [8]     ctl[0] = stage done flag, ctl[1] = abort
+    float *xst;    // [64*9]  pose parameters per frame (lane = frame in P4) -- in LDS, not in registers: wave 0 touches them once per
+    float *mst;    // [64*9]  iteration, and 18 VGPRs held by every wave for the whole launch is what the match pass cannot spare
     float *pinc;   // [pinc_rows*16] backward results of the current chunk of pairs, one row per (pair, side), frame-sorted
                    //   (pinc_rows = 2 x pairs per chunk, at most PD_GGS_PINC_ROWS; the two-hop kernel always carves the maximum)
     float *psum;   // [64*16]  per-frame partial sums across chunks (N > 32 only)
@@ -277,7 +279,9 @@ __device__ __forceinline__ Lds carve(float *base, int n_slots, int pinc_rows, in
     L.gR = L.gT + 64 * 3;
     L.gA = L.gR + 64 * 9;
     L.ctl = L.gA + 64 * 4;
-    L.pinc = L.ctl + 8;
+    L.xst = L.ctl + 8;
+    L.mst = L.xst + 64 * 9;
+    L.pinc = L.mst + 64 * 9;
     L.psum = L.pinc + pinc_rows * 16;
     L.itab = (int4 *)(L.psum + 64 * 16);
     L.incoff = (int *)(L.itab + n_slots);
@@ -514,13 +518,14 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
     float *xg = P.x + (size_t)b * N * PD_POSE_DIM;
     u64 *xchg = P.xchg ? P.xchg + (size_t)b * 2 * P.xchg_stride : nullptr;
 
-    // wave 0, lane n owns frame n: parameters + momentum in registers for the whole launch
-    float xr[9], mom[9];
+    // wave 0, lane n owns frame n: parameters + momentum live in LDS (L.xst / L.mst) and visit registers only inside P4
     const bool own = (wave == 0 && lane < N);
+    if (wave == 0) {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) {
-        xr[c] = own ? xg[lane * 9 + c] : 0.0f;
-        mom[c] = 0.0f;
+        for (int c = 0; c < 9; ++c) {
+            L.xst[lane * 9 + c] = own ? xg[lane * 9 + c] : 0.0f;
+            L.mst[lane * 9 + c] = 0.0f;
+        }
     }
     // local item table -> LDS (slot = wave + 8 * round <-> item = wg*8 + wave + round * nW)
     for (int s = tid; s < n_slots; s += PD_GGS_THREADS) {
@@ -538,7 +543,12 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
         L.ctl[0] = 0.0f;
         L.ctl[1] = 0.0f;
     }
-    if (wave == 0) decode_all(L, xr, lane, N, D);
+    if (wave == 0) {
+        float xr0[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) xr0[c] = L.xst[lane * 9 + c];
+        decode_all(L, xr0, lane, N, D);
+    }
     __syncthreads();
     // matches of this wave's first item stay in registers for the whole launch when every wave owns
     // at most one item (the k = ceil(items/8) regime): no per-iteration match traffic at all
@@ -945,7 +955,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
     }
     if (own && wg == 0 && !P.eval_only) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) xg[lane * 9 + c] = xr[c];
+        for (int c = 0; c < 9; ++c) xg[lane * 9 + c] = L.xst[lane * 9 + c];
     }
     if (STAGE_P > 0) pd_vmcnt<0>();   // the look-ahead LDS-DMA of the last item must land before the LDS is handed on
 }
@@ -1018,12 +1028,13 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
     float *tot_rows = L.pinc + 640 * 16;
     int *grow = (int *)(L.pinc + 768 * 16);
 
-    float xr[9], mom[9];
     const bool own = (wave == 0 && lane < N);
+    if (wave == 0) {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) {
-        xr[c] = own ? xg[lane * 9 + c] : 0.0f;
-        mom[c] = 0.0f;
+        for (int c = 0; c < 9; ++c) {
+            L.xst[lane * 9 + c] = own ? xg[lane * 9 + c] : 0.0f;
+            L.mst[lane * 9 + c] = 0.0f;
+        }
     }
     for (int s = tid; s < n_slots; s += PD_GGS_THREADS) {
         const int item = wg * PD_GGS_WAVES + (s & 7) + (s >> 3) * nW;
@@ -1044,7 +1055,12 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
         L.ctl[0] = 0.0f;
         L.ctl[1] = 0.0f;
     }
-    if (wave == 0) decode_all(L, xr, lane, N, D);
+    if (wave == 0) {
+        float xr0[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) xr0[c] = L.xst[lane * 9 + c];
+        decode_all(L, xr0, lane, N, D);
+    }
     __syncthreads();
     // one item per wave (the usual case here: k = ceil(pairs / 8)): its matches stay in registers for the whole launch
     const bool resident = (n_slots == PD_GGS_WAVES);
@@ -1235,7 +1251,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
     }
     if (own && wg == 0 && !P.eval_only) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) xg[lane * 9 + c] = xr[c];
+        for (int c = 0; c < 9; ++c) xg[lane * 9 + c] = L.xst[lane * 9 + c];
     }
 }
 
