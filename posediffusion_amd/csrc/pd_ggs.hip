@@ -195,9 +195,11 @@ __device__ __forceinline__ v2f pd_splat(float a) { return (v2f){a, a}; }
 #define PD_SAMPSON_BAND_ULPS 16.0f
 // Every fused multiply-add below is written out and contraction is off inside the two step functions, so the packed and the
 // single-match form perform the same roundings: an item's sums do not depend on which form ran its tail.
+// n_valid is counted on the scalar unit (popcount of the two compare masks: wave-uniform, exact) instead of in a lane
+// accumulator: acc[10] stays zero and item_totals() puts the count into its slot after the reduction.
 template <bool EXACT>
 __device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, bool ina, bool inb, const float *F, float smax,
-                                              v2f (&acc)[PD_ITEM_VALS], float &mind) {
+                                              v2f (&acc)[PD_ITEM_VALS], float &mind, int &nv) {
 #pragma clang fp contract(off)
     const v2f u1 = {pa.x, pb.x}, v1 = {pa.y, pb.y}, u2 = {pa.z, pb.z}, v2 = {pa.w, pb.w};
     // left = x1^T F, right = F x2   (:158-159)
@@ -229,7 +231,7 @@ __device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, 
     const v2f sam_v = EXACT ? (v2f){va ? sam.x : 0.0f, vb ? sam.y : 0.0f} : top * inv_v;   // = sam where valid, else 0
     const v2f cb = (sam_v + sam_v) * inv_v;           // 2 sam / bottom
     acc[9] += sam_v;
-    acc[10] += (v2f){va ? 1.0f : 0.0f, vb ? 1.0f : 0.0f};
+    nv += __builtin_popcountll(__builtin_amdgcn_ballot_w64(va)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(vb));
     // d sam / dF[r][c] = x1[r] g_c - cb r_r x2[c] [r<2],  g_c = ca x2[c] - cb l_c [c<2]   (x1[2] = x2[2] = 1)
     const v2f g0 = pd_fma2(ca, u2, -(cb * l0)), g1 = pd_fma2(ca, v2, -(cb * l1));
     const v2f nbr0 = -(cb * r0), nbr1 = -(cb * r1);
@@ -359,7 +361,7 @@ __device__ __forceinline__ void decode_all(const Lds &L, const float *xr, int la
 // (+0 contributions), so an item's sums do not depend on which of the two forms ran its tail.
 template <bool EXACT>
 __device__ __forceinline__ void sampson_step1(const float4 pa, bool ina, const float *F, float smax, v2f (&acc)[PD_ITEM_VALS],
-                                              float &mind) {
+                                              float &mind, int &nv) {
 #pragma clang fp contract(off)
     const float u1 = pa.x, v1 = pa.y, u2 = pa.z, v2 = pa.w;
     const float l0 = __builtin_fmaf(u1, F[0], __builtin_fmaf(v1, F[3], F[6]));
@@ -386,7 +388,7 @@ __device__ __forceinline__ void sampson_step1(const float4 pa, bool ina, const f
     const float sam_v = EXACT ? (va ? sam : 0.0f) : top * inv_v;
     const float cb = (sam_v + sam_v) * inv_v;
     acc[9].x += sam_v;
-    acc[10].x += va ? 1.0f : 0.0f;
+    nv += __builtin_popcountll(__builtin_amdgcn_ballot_w64(va));
     const float g0 = __builtin_fmaf(ca, u2, -(cb * l0)), g1 = __builtin_fmaf(ca, v2, -(cb * l1));
     const float nbr0 = -(cb * r0), nbr1 = -(cb * r1);
     acc[0].x = __builtin_fmaf(nbr0, u2, __builtin_fmaf(u1, g0, acc[0].x));
@@ -413,26 +415,28 @@ struct MatchLds {
 
 // the (<= 4) two-match steps of an item as straight-line code per step count: without the per-step branch the
 // scheduler interleaves the independent steps, which hides the VALU dependency latency two waves per SIMD cannot
-#define PD_P2_STEP(j) sampson_step2<EXACT>(src.get(2 * (j), lane), src.get(2 * (j) + 1, lane), (lane + 128 * (j)) < cnt, (lane + 128 * (j) + 64) < cnt, Fm, smax, acc2, mind)
+// (a FULL step lies wholly inside the item: its range masks are compile-time true and the selects they feed fold away)
+#define PD_P2_FULL(j) sampson_step2<EXACT>(src.get(2 * (j), lane), src.get(2 * (j) + 1, lane), true, true, Fm, smax, acc2, mind, nv)
+#define PD_P2_STEP(j) sampson_step2<EXACT>(src.get(2 * (j), lane), src.get(2 * (j) + 1, lane), (lane + 128 * (j)) < cnt, (lane + 128 * (j) + 64) < cnt, Fm, smax, acc2, mind, nv)
 #define PD_P2_TAIL(j)                                                                                           \
     do {                                                                                                        \
         if (rem > 64 || (!TAIL1 && rem > 0)) PD_P2_STEP(j);                                                     \
-        else if (TAIL1 && rem > 0) sampson_step1<EXACT>(src.get(2 * (j), lane), (lane + 128 * (j)) < cnt, Fm, smax, acc2, mind); \
+        else if (TAIL1 && rem > 0) sampson_step1<EXACT>(src.get(2 * (j), lane), (lane + 128 * (j)) < cnt, Fm, smax, acc2, mind, nv); \
     } while (0)
 // TAIL1: run a tail of <= 64 matches as a single-match step (same sums; the variants that keep matches in registers leave it
 // off -- they sit at the register limit and are latency-, not issue-bound)
 template <bool EXACT, bool TAIL1, typename Src>
 __device__ __forceinline__ void item_steps(const Src &src, int cnt, int lane, const float *Fm, float smax,
-                                           v2f (&acc2)[PD_ITEM_VALS], float &mind) {
+                                           v2f (&acc2)[PD_ITEM_VALS], float &mind, int &nv) {
     const int full = cnt >> 7, rem = cnt & 127;       // full packed steps; the rest: a packed step, a single-match step or nothing
     if (full >= 4) {
-        PD_P2_STEP(0); PD_P2_STEP(1); PD_P2_STEP(2); PD_P2_STEP(3);
+        PD_P2_FULL(0); PD_P2_FULL(1); PD_P2_FULL(2); PD_P2_FULL(3);
     } else if (full == 3) {
-        PD_P2_STEP(0); PD_P2_STEP(1); PD_P2_STEP(2); PD_P2_TAIL(3);
+        PD_P2_FULL(0); PD_P2_FULL(1); PD_P2_FULL(2); PD_P2_TAIL(3);
     } else if (full == 2) {
-        PD_P2_STEP(0); PD_P2_STEP(1); PD_P2_TAIL(2);
+        PD_P2_FULL(0); PD_P2_FULL(1); PD_P2_TAIL(2);
     } else if (full == 1) {
-        PD_P2_STEP(0); PD_P2_TAIL(1);
+        PD_P2_FULL(0); PD_P2_TAIL(1);
     } else {
         PD_P2_TAIL(0);
     }
@@ -441,17 +445,27 @@ __device__ __forceinline__ void item_steps(const Src &src, int cnt, int lane, co
 // 1-ulp quotient could decide differently from the IEEE quotient -- the exact pass over the same data instead
 template <bool TAIL1, typename Src>
 __device__ __forceinline__ void item_pass(const Src &src, int cnt, int lane, const float *Fm, float smax,
-                                          v2f (&acc2)[PD_ITEM_VALS]) {
+                                          v2f (&acc2)[PD_ITEM_VALS], int &nv) {
     float mind = __int_as_float(0x7f800000);
+    nv = 0;
 #pragma unroll
     for (int c = 0; c < PD_ITEM_VALS; ++c) acc2[c] = (v2f){0.0f, 0.0f};
-    item_steps<false, TAIL1>(src, cnt, lane, Fm, smax, acc2, mind);
+    item_steps<false, TAIL1>(src, cnt, lane, Fm, smax, acc2, mind, nv);
     const float band = smax * (PD_SAMPSON_BAND_ULPS * 1.1920929e-7f);
     if (__builtin_amdgcn_ballot_w64(mind <= band) != 0ull) {   // wave-uniform, rare (P ~ 1e-7 per match)
 #pragma unroll
         for (int c = 0; c < PD_ITEM_VALS; ++c) acc2[c] = (v2f){0.0f, 0.0f};
-        item_steps<true, false>(src, cnt, lane, Fm, smax, acc2, mind);
+        nv = 0;
+        item_steps<true, false>(src, cnt, lane, Fm, smax, acc2, mind, nv);
     }
+}
+// fold the two-match partial sums, reduce across the wave: this lane then holds the item total of `slot` (n_valid: the scalar count)
+__device__ __forceinline__ float item_totals(const v2f (&acc2)[PD_ITEM_VALS], int nv, int lane, int &slot) {
+    float acc[PD_ITEM_VALS];
+#pragma unroll
+    for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = acc2[c].x + acc2[c].y;
+    const float tot = wave_reduce12_transpose(acc, lane, slot);
+    return slot == 10 ? (float)nv : tot;
 }
 
 // LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land lane-linear at the wave-uniform LDS byte address in M0) straight from
@@ -704,8 +718,9 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
                 }
                 // two 64-match steps per pass: lane handles matches lane + 64*(2j) and lane + 64*(2j+1) together
                 v2f acc2[PD_ITEM_VALS];
+                int nv;
                 if constexpr (RESIDENT) {   // straight from the resident registers (no copies)
-                    item_pass<false>(MatchRegs{mres}, e.y, lane, Fm, P.sampson_max, acc2);
+                    item_pass<false>(MatchRegs{mres}, e.y, lane, Fm, P.sampson_max, acc2, nv);
                 } else if constexpr (STAGE_P > 0) {
                     // the slot this wave computes next (or its own first one, for the next iteration: the matches never
                     // change) goes into the other buffer while this one is computed; STAGE_P pieces stay in flight
@@ -720,7 +735,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
 #pragma unroll
                         for (int q = 0; q < 8; ++q) mb[q] = q < STAGE_P ? Bp[64 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
-                    item_pass<true>(MatchRegs{mb}, e.y, lane, Fm, P.sampson_max, acc2);
+                    item_pass<true>(MatchRegs{mb}, e.y, lane, Fm, P.sampson_max, acc2, nv);
                     pb ^= 1;
                 } else {
                     // stream this item: all (<= 8) lines in flight at once, indices clamped (no
@@ -733,17 +748,14 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
                         const int m = lane + 64 * st;
                         mb[st] = pts[m < e.y ? m : last];
                     }
-                    item_pass<false>(MatchRegs{mb}, e.y, lane, Fm, P.sampson_max, acc2);
+                    item_pass<false>(MatchRegs{mb}, e.y, lane, Fm, P.sampson_max, acc2, nv);
                 }
 #ifdef PD_GGS_PROF2
                 if (prof) { acc2[0].x += 0.0f * (float)__builtin_amdgcn_readfirstlane(__float_as_int(acc2[11].y)); }   // (keeps the pass before the timer)
 #endif
                 PD_PROF2(13);
-                float acc[PD_ITEM_VALS];
-#pragma unroll
-                for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = acc2[c].x + acc2[c].y;
                 int slot;
-                const float tot = wave_reduce12_transpose(acc, lane, slot);   // this lane holds the item total of `slot`
+                const float tot = item_totals(acc2, nv, lane, slot);   // this lane holds the item total of `slot`
                 if (lane < 16 && slot < PD_ITEM_VALS) {
                     if (k == 1) {
                         L.item[item * PD_ITEM_VALS + slot] = tot;
@@ -1124,8 +1136,9 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                     Fm[8] = L.F[s * PD_F_STRIDE + 8];
                 }
                     v2f acc2[PD_ITEM_VALS];
+                    int nv;
                     if (resident) {
-                        item_pass<false>(MatchRegs{mres}, e.y, lane, Fm, P.sampson_max, acc2);
+                        item_pass<false>(MatchRegs{mres}, e.y, lane, Fm, P.sampson_max, acc2, nv);
                     } else {
                         float4 mb[8];
                         const float4 *pts = D.pts + e.x;
@@ -1135,13 +1148,10 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                             const int m = lane + 64 * q;
                             mb[q] = pts[m < e.y ? m : last];
                         }
-                        item_pass<false>(MatchRegs{mb}, e.y, lane, Fm, P.sampson_max, acc2);
+                        item_pass<false>(MatchRegs{mb}, e.y, lane, Fm, P.sampson_max, acc2, nv);
                     }
-                    float acc[PD_ITEM_VALS];
-#pragma unroll
-                    for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = acc2[c].x + acc2[c].y;
                     int slot;
-                    const float tot = wave_reduce12_transpose(acc, lane, slot);
+                    const float tot = item_totals(acc2, nv, lane, slot);
                     if (lane < 16 && slot < PD_ITEM_VALS) L.item[s * PD_ITEM_VALS + slot] = tot;
                 }
             }
