@@ -184,7 +184,10 @@ __device__ __forceinline__ v2f pd_fma2(v2f a, v2f b, v2f c) { return __builtin_e
 __device__ __forceinline__ v2f pd_splat(float a) { return (v2f){a, a}; }
 
 // Sampson residual + dL/dF of two matches (geometry_guided_sampling.py:157-170); acc[0..8] dL/dF sums,
-// acc[9] sum(s valid), acc[10] n_valid, acc[11] sum(min(s, max)), each as {match A, match B} partial sums.
+// acc[9] sum(s valid), each as {match A, match B} partial sums.  Kept out of the per-match work (item_totals() finishes them per item):
+//   * acc[0..8] accumulate HALF of dL/dF (ca, cb below without their factor 2 -- an exact scaling, doubled after the reduction);
+//   * n_valid (slot 10) is counted on the scalar unit: popcounts of the two compare masks, wave-uniform and exact;
+//   * sum(min(s, max)) (slot 11, the printed statistic :169) = sum(s valid) + max * (in-range matches - n_valid).
 //
 // Threshold rule (:170 `sampson < sampson_max` on torch's IEEE quotient top / bottom): EXACT = false computes the
 // quotient as top * v_rcp_f32(bottom) (within 2 ulp of the IEEE quotient) and records in `mind` how close any in-range
@@ -195,8 +198,6 @@ __device__ __forceinline__ v2f pd_splat(float a) { return (v2f){a, a}; }
 #define PD_SAMPSON_BAND_ULPS 16.0f
 // Every fused multiply-add below is written out and contraction is off inside the two step functions, so the packed and the
 // single-match form perform the same roundings: an item's sums do not depend on which form ran its tail.
-// n_valid is counted on the scalar unit (popcount of the two compare masks: wave-uniform, exact) instead of in a lane
-// accumulator: acc[10] stays zero and item_totals() puts the count into its slot after the reduction.
 template <bool EXACT>
 __device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, bool ina, bool inb, const float *F, float smax,
                                               v2f (&acc)[PD_ITEM_VALS], float &mind, int &nv) {
@@ -221,18 +222,16 @@ __device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, 
         // lanes past the item's end carry a clamped copy of its last match: harmless (same decision as that match)
         mind = fminf(mind, fminf(fabsf(d.x), fabsf(d.y)));              // one v_min3_f32 with |.| modifiers
     }
-    const v2f clamped = __builtin_elementwise_min(sam, pd_splat(smax));
-    acc[11] += (v2f){ina ? clamped.x : 0.0f, inb ? clamped.y : 0.0f};   // :169
     const bool va = ina && (sam.x < smax), vb = inb && (sam.y < smax);   // :170 (false for NaN)
     // everything below is scaled by inv_v = valid ? 1/bottom : 0 (a select, not a product: 1/bottom may be inf),
     // so invalid / out-of-range matches contribute exact zeros without further masking
     const v2f inv_v = {va ? inv.x : 0.0f, vb ? inv.y : 0.0f};
-    const v2f ca = (ee + ee) * inv_v;                 // 2 ee / bottom
+    const v2f ca = ee * inv_v;                        // ee / bottom      (half of d sam / d ee)
     const v2f sam_v = EXACT ? (v2f){va ? sam.x : 0.0f, vb ? sam.y : 0.0f} : top * inv_v;   // = sam where valid, else 0
-    const v2f cb = (sam_v + sam_v) * inv_v;           // 2 sam / bottom
+    const v2f cb = sam_v * inv_v;                     // sam / bottom     (half of -d sam / d bottom)
     acc[9] += sam_v;
     nv += __builtin_popcountll(__builtin_amdgcn_ballot_w64(va)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(vb));
-    // d sam / dF[r][c] = x1[r] g_c - cb r_r x2[c] [r<2],  g_c = ca x2[c] - cb l_c [c<2]   (x1[2] = x2[2] = 1)
+    // (d sam / dF[r][c]) / 2 = x1[r] g_c - cb r_r x2[c] [r<2],  g_c = ca x2[c] - cb l_c [c<2]   (x1[2] = x2[2] = 1)
     const v2f g0 = pd_fma2(ca, u2, -(cb * l0)), g1 = pd_fma2(ca, v2, -(cb * l1));
     const v2f nbr0 = -(cb * r0), nbr1 = -(cb * r1);
     acc[0] = pd_fma2(nbr0, u2, pd_fma2(u1, g0, acc[0]));
@@ -380,13 +379,11 @@ __device__ __forceinline__ void sampson_step1(const float4 pa, bool ina, const f
         sam = top * inv;
         mind = fminf(mind, fabsf(sam - smax));
     }
-    const float clamped = fminf(sam, smax);
-    acc[11].x += ina ? clamped : 0.0f;
     const bool va = ina && (sam < smax);
     const float inv_v = va ? inv : 0.0f;
-    const float ca = (ee + ee) * inv_v;
+    const float ca = ee * inv_v;
     const float sam_v = EXACT ? (va ? sam : 0.0f) : top * inv_v;
-    const float cb = (sam_v + sam_v) * inv_v;
+    const float cb = sam_v * inv_v;
     acc[9].x += sam_v;
     nv += __builtin_popcountll(__builtin_amdgcn_ballot_w64(va));
     const float g0 = __builtin_fmaf(ca, u2, -(cb * l0)), g1 = __builtin_fmaf(ca, v2, -(cb * l1));
@@ -460,12 +457,16 @@ __device__ __forceinline__ void item_pass(const Src &src, int cnt, int lane, con
     }
 }
 // fold the two-match partial sums, reduce across the wave: this lane then holds the item total of `slot` (n_valid: the scalar count)
-__device__ __forceinline__ float item_totals(const v2f (&acc2)[PD_ITEM_VALS], int nv, int lane, int &slot) {
+__device__ __forceinline__ float item_totals(const v2f (&acc2)[PD_ITEM_VALS], int nv, int cnt, float smax, int lane, int &slot) {
     float acc[PD_ITEM_VALS];
 #pragma unroll
     for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = acc2[c].x + acc2[c].y;
+    acc[11] = acc[9];                                   // slot 11 reduces to the same sum(s valid), bit for bit
     const float tot = wave_reduce12_transpose(acc, lane, slot);
-    return slot == 10 ? (float)nv : tot;
+    if (slot < 9) return tot + tot;                     // the factor 2 of ca, cb
+    if (slot == 10) return (float)nv;
+    if (slot == 11) return tot + smax * (float)(cnt - nv);   // every in-range match that is not valid contributes min(s, max) = max
+    return tot;
 }
 
 // LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land lane-linear at the wave-uniform LDS byte address in M0) straight from
@@ -751,11 +752,11 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
                     item_pass<false>(MatchRegs{mb}, e.y, lane, Fm, P.sampson_max, acc2, nv);
                 }
 #ifdef PD_GGS_PROF2
-                if (prof) { acc2[0].x += 0.0f * (float)__builtin_amdgcn_readfirstlane(__float_as_int(acc2[11].y)); }   // (keeps the pass before the timer)
+                if (prof) { acc2[0].x += 0.0f * (float)__builtin_amdgcn_readfirstlane(__float_as_int(acc2[9].y)); }   // (keeps the pass before the timer)
 #endif
                 PD_PROF2(13);
                 int slot;
-                const float tot = item_totals(acc2, nv, lane, slot);   // this lane holds the item total of `slot`
+                const float tot = item_totals(acc2, nv, e.y, P.sampson_max, lane, slot);   // this lane holds the item total of `slot`
                 if (lane < 16 && slot < PD_ITEM_VALS) {
                     if (k == 1) {
                         L.item[item * PD_ITEM_VALS + slot] = tot;
@@ -1151,7 +1152,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                         item_pass<false>(MatchRegs{mb}, e.y, lane, Fm, P.sampson_max, acc2, nv);
                     }
                     int slot;
-                    const float tot = item_totals(acc2, nv, lane, slot);
+                    const float tot = item_totals(acc2, nv, e.y, P.sampson_max, lane, slot);
                     if (lane < 16 && slot < PD_ITEM_VALS) L.item[s * PD_ITEM_VALS + slot] = tot;
                 }
             }
