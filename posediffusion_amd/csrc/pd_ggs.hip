@@ -75,12 +75,13 @@ __device__ __forceinline__ float wave_allsum(float v) {
 __device__ __forceinline__ float pd_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float pd_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-// Transposing butterfly over the 12 per-item sums: at every step a lane KEEPS half of its values and SENDS the
-// other half to the partner that differs in exactly ONE lane bit (who keeps exactly those), so the live values
-// go 16 -> 8 -> 4 -> 2 -> 1 per lane over bits 0..3 (xor-1 / xor-2 as DPP quad permutes, xor-4 / xor-8 as DPP row shifts,
-// xor-16 / xor-32 as permlane swaps), ~55 instructions instead of 12 full 64-lane reductions (~200 incl.
-// s_nop / readlane / select chains).  Value `slot` ends up in every lane whose low four bits encode that slot,
-// ready to be stored from there.  Fixed tree -> bitwise reproducible; every lane of the wave must be active.
+// Transposing butterfly over the per-item sums (slots 0..9 carry values; 10..15 are padding): at every step a lane KEEPS half
+// of its values and SENDS the other half to the partner that differs in exactly ONE lane bit (who keeps exactly those), so the
+// live values go 16 -> 8 -> 4 -> 2 -> 1 per lane.  Lane bits 2 and 3 go first: they select a DPP bank (4 lanes), so a row shift
+// with a bank mask adds the partner's value AND picks which of the two values a lane keeps in one v_add_f32_dpp -- no selects
+// (hand-written: hipcc only emits the masked form as v_mov_b32_dpp pairs + selects).  Then bits 0 / 1 as quad permutes with
+// selects, bits 4 / 5 as permlane swaps.  ~45 instructions per item instead of 10 full 64-lane reductions.  Value `slot`
+// ends up in every lane whose low four bits encode that slot.  Fixed tree -> bitwise reproducible; every lane must be active.
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
@@ -90,14 +91,6 @@ __device__ __forceinline__ float dpp_mov(float v) {
 //   lane ^ 4, lane ^ 8   two DPP row shifts each (up for the lanes whose bit is clear, down for the others, picked by bank_mask)
 //   lane ^ 16, lane ^ 32 gfx950's v_permlane16_swap / v_permlane32_swap: swapping the odd rows (upper half) of one copy with
 //                        the even rows (lower half) of another leaves {x[lane & ~b], x[lane | b]} in the two copies
-template <int XOR>
-__device__ __forceinline__ float dpp_xor(float v) {
-    static_assert(XOR == 4 || XOR == 8, "row shifts cover lane ^ 4 and lane ^ 8");
-    const int x = __float_as_int(v);
-    int t = __builtin_amdgcn_update_dpp(0, x, 0x100 + XOR, 0xf, XOR == 4 ? 0x5 : 0x3, false);    // row_shl: lane <- lane + XOR
-    t = __builtin_amdgcn_update_dpp(t, x, 0x110 + XOR, 0xf, XOR == 4 ? 0xa : 0xc, false);        // row_shr: lane <- lane - XOR
-    return __int_as_float(t);
-}
 __device__ __forceinline__ float add_xor16(float v) {    // v[lane] + v[lane ^ 16]
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
     return __int_as_float(r[0]) + __int_as_float(r[1]);
@@ -107,21 +100,43 @@ __device__ __forceinline__ float add_xor32(float v) {    // v[lane] + v[lane ^ 3
     return __int_as_float(r[0]) + __int_as_float(r[1]);
 }
 __device__ __forceinline__ float wave_reduce12_transpose(const float (&a)[PD_ITEM_VALS], int lane, int &slot) {
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-    float w8[8], w4[4], w2[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {   // slots 12..15 are padding (zero)
-        const float lo = a[j], hi = (j + 8 < PD_ITEM_VALS) ? a[j + 8] : 0.0f;
-        w8[j] = (b0 ? hi : lo) + dpp_mov<0xB1>(b0 ? lo : hi);     // partner lane ^ 1
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w4[j] = (b1 ? w8[j + 4] : w8[j]) + dpp_mov<0x4E>(b1 ? w8[j] : w8[j + 4]);   // lane ^ 2
-#pragma unroll
-    for (int j = 0; j < 2; ++j) w2[j] = (b2 ? w4[j + 2] : w4[j]) + dpp_xor<4>(b2 ? w4[j] : w4[j + 2]);      // lane ^ 4
-    float v = (b3 ? w2[1] : w2[0]) + dpp_xor<8>(b3 ? w2[0] : w2[1]);                                         // lane ^ 8
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float w0, w1, w2, w3, w4, w5, w6, w7;
+    // lane ^ 4: banks 0, 2 (bit 2 clear) keep slot j = a[j] + a[j] of lane + 4; banks 1, 3 keep slot j + 8 (only 8 and 9 exist; the
+    // other lanes of w2..w7 stay undefined -- they would hold the padding slots, which nobody reads).  The leading s_nop covers
+    // the VALU-write -> DPP-read hazard the assembler cannot see for us.
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %1, %9, %9 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %2, %10, %10 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %3, %11, %11 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %4, %12, %12 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %5, %13, %13 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %6, %14, %14 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %7, %15, %15 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %16, %16 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %1, %17, %17 row_shr:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(w4), "=&v"(w5), "=&v"(w6), "=&v"(w7)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]));
+    // lane ^ 8: banks 0, 1 (bit 3 clear) keep w[j], banks 2, 3 keep w[j + 4]
+    float q0, q1, q2, q3;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %4, %4 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %1, %5, %5 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %2, %6, %6 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %3, %7, %7 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %0, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %1, %9, %9 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %2, %10, %10 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %3, %11, %11 row_shr:8 row_mask:0xf bank_mask:0xc"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+                 : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7));
+    const float p0 = (b0 ? q2 : q0) + dpp_mov<0xB1>(b0 ? q0 : q2);     // lane ^ 1
+    const float p1 = (b0 ? q3 : q1) + dpp_mov<0xB1>(b0 ? q1 : q3);
+    float v = (b1 ? p1 : p0) + dpp_mov<0x4E>(b1 ? p0 : p1);            // lane ^ 2
     v = add_xor16(v);
     v = add_xor32(v);
-    slot = (b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0);
+    slot = ((lane & 4) ? 8 : 0) + ((lane & 8) ? 4 : 0) + (b0 ? 2 : 0) + (b1 ? 1 : 0);
     return v;
 }
 
@@ -460,12 +475,13 @@ __device__ __forceinline__ void item_pass(const Src &src, int cnt, int lane, con
 __device__ __forceinline__ float item_totals(const v2f (&acc2)[PD_ITEM_VALS], int nv, int cnt, float smax, int lane, int &slot) {
     float acc[PD_ITEM_VALS];
 #pragma unroll
-    for (int c = 0; c < PD_ITEM_VALS; ++c) acc[c] = acc2[c].x + acc2[c].y;
-    acc[11] = acc[9];                                   // slot 11 reduces to the same sum(s valid), bit for bit
+    for (int c = 0; c < 10; ++c) acc[c] = acc2[c].x + acc2[c].y;
+    acc[10] = acc[11] = 0.0f;                           // not reduced: finished from the scalar count below
     const float tot = wave_reduce12_transpose(acc, lane, slot);
+    const float tot9 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 6));   // lane 6 holds slot 9 (see the slot map)
     if (slot < 9) return tot + tot;                     // the factor 2 of ca, cb
     if (slot == 10) return (float)nv;
-    if (slot == 11) return tot + smax * (float)(cnt - nv);   // every in-range match that is not valid contributes min(s, max) = max
+    if (slot == 11) return tot9 + smax * (float)(cnt - nv);   // every in-range match that is not valid contributes min(s, max) = max
     return tot;
 }
 
