@@ -319,12 +319,26 @@ def main():
                 out = engines[j].sample(z, noise, COND_START, cfg, use_graph=use_graph, want_process=False, phase=1)
                 engines[j].sample(z, noise, COND_START, cfg, use_graph=use_graph, want_process=False, phase=2, out=out)
             torch.cuda.synchronize()
+    stagger_ms = float(os.environ.get("PD_BENCH_STAGGER_MS", "0"))
+    sleep_cycles_per_ms = 0.0
+    if stagger_ms > 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1_000_000)
+        e0.record()
+        torch.cuda._sleep(20_000_000)
+        e1.record()
+        torch.cuda.synchronize()
+        sleep_cycles_per_ms = 20_000_000 / e0.elapsed_time(e1)
     for b in passes_for(args.warmup):
         submit(b)
     torch.cuda.synchronize()
     shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if stagger_ms > 0 and depth > 1:     # context j starts j x stagger late (inside the timed region): the contexts' guided halves
+        for j in range(1, depth):        # then meet the other contexts' unguided halves instead of each other
+            with torch.cuda.stream(pipe.g_streams[j % len(pipe.g_streams)]):
+                torch.cuda._sleep(int(j * stagger_ms * sleep_cycles_per_ms))
     pend = [submit(b) for b in passes_for(K)]
     torch.cuda.synchronize()
     # poses of step s = rows [(s % group) * B_step, +B_step) of pass s // group; ONE all_gather of all K steps (still timed)

@@ -67,6 +67,49 @@ __global__ void pd_fold_bias_kernel(const float *__restrict__ W, const float *__
     out[n] = b[n] + a;
 }
 
+// _first's input rows for the streamed path (>= PD_STREAM_MIN_ROWS token rows): [z | t_emb | harmonic(x) | x | pivot | 0 0] in the
+// engine's column order (pd_first_col), one wave per row, written once per step and read by pd_gemm_stream like any activation
+// (denoiser.py:56-68; the same expressions as the AMODE 2 staging of pd_gemm_kernel).
+__global__ __launch_bounds__(256) void pd_embed_rows_kernel(const float *__restrict__ x, const float *__restrict__ z,
+                                                            const float *__restrict__ temb, int n_frames, int M, float *__restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float4 *dst = (float4 *)(out + (size_t)row * KFIRST_PAD);
+    const float4 *zr = (const float4 *)(z + (size_t)row * ZD), *te = (const float4 *)temb;
+    dst[lane] = zr[lane];                                       // z: 96 float4
+    if (lane < 32) dst[64 + lane] = zr[64 + lane];
+    else dst[64 + lane] = te[lane - 32];                        // t_emb: 32 float4 at [96, 128)
+    float xv[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) xv[d] = x[(size_t)row * 9 + d];
+    if (lane < 45) {                                            // harmonic: 180 values = 45 float4 at [128, 173)
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = 4 * lane + e, s = idx / 90, rem = idx - s * 90, d = rem / 10, kk = rem - d * 10;
+            float xd = xv[0];
+#pragma unroll
+            for (int q = 1; q < 9; ++q) xd = (d == q) ? xv[q] : xd;
+            const float a = xd * (float)(1 << kk);
+            o[e] = sinf(s ? a + 1.5707963267948966f : a);
+        }
+        dst[128 + lane] = make_float4(o[0], o[1], o[2], o[3]);
+    } else if (lane == 45) {
+        dst[173] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+    } else if (lane == 46) {
+        dst[174] = make_float4(xv[4], xv[5], xv[6], xv[7]);
+    } else if (lane == 47) {
+        dst[175] = make_float4(xv[8], (row % n_frames == 0) ? 1.0f : 0.0f, 0.0f, 0.0f);   // pivot one-hot on frame 0, padding
+    }
+}
+// W_first [512, 702] -> row-major [512, 704] in the engine's column order
+__global__ void pd_first_rowmajor_kernel(const float *__restrict__ W, float *__restrict__ Wf) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= DM * KFIRST_PAD) return;
+    const int n = idx / KFIRST_PAD, k = pd_first_col(idx - n * KFIRST_PAD);
+    Wf[idx] = k < KFIRST ? W[(size_t)n * KFIRST + k] : 0.0f;
+}
+
 // time-step embedding table (util/embedding.py:28-37): one block per step t
 __global__ void pd_time_table_kernel(const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w2,
                                      const float *__restrict__ b2, float *__restrict__ table) {
@@ -555,7 +598,15 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(dev_alloc(d, &d->ctx, rows * DM));
     PD_TRY(dev_alloc(d, &d->ff, rows * DFF));
     PD_TRY(dev_alloc(d, &d->hid, rows * HID));
-    if (rows >= PD_STREAM_MIN_ROWS) PD_TRY(dev_alloc(d, &d->hn, rows * DM));
+    if (rows >= PD_STREAM_MIN_ROWS) {
+        PD_TRY(dev_alloc(d, &d->hn, rows * DM));
+        // the streamed path's _first (input rows materialised by pd_embed_rows_kernel) and _last.0
+        PD_TRY(dev_alloc(d, &d->emb, rows * KFIRST_PAD));
+        PD_TRY(dev_alloc(d, &d->first_wf, (size_t)DM * KFIRST_PAD));
+        hipLaunchKernelGGL(pd_first_rowmajor_kernel, dim3((DM * KFIRST_PAD + 255) / 256), dim3(256), 0, 0, w->first_w, d->first_wf);
+        PD_HIP_CHECK(hipGetLastError());
+        PD_TRY(dev_rowmajor(d, &d->last0_wf, w->last0_w, HID, DM, nullptr));
+    }
     {
         std::vector<float> sc((size_t)w->timesteps * 8, 0.0f);
         for (int t = 0; t < w->timesteps; ++t) {
@@ -653,15 +704,20 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.M = M;
-    // _first with the embedding fused into the A staging
-    g.bias = d->first_b; g.C = d->h; g.Nout = DM;
-    g.x = x; g.z = z; g.temb = d->t_table + (size_t)t * 128; g.n_frames = N;
-    launch_gemm<KFIRST_PAD, 2, 0>(g, d->first_wp, MT, eng->gemm_wide_min_tiles, s);
+    const bool streamed = M >= PD_STREAM_MIN_ROWS && d->hn;
+    if (streamed) {
+        hipLaunchKernelGGL(pd_embed_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, z, d->t_table + (size_t)t * 128, N, M, d->emb);
+        pd_gemm_stream<0>(d->emb, KFIRST_PAD, d->first_wf, KFIRST_PAD, d->first_b, d->h, M, DM, s);
+    } else {
+        // _first with the embedding fused into the A staging
+        g.bias = d->first_b; g.C = d->h; g.Nout = DM;
+        g.x = x; g.z = z; g.temb = d->t_table + (size_t)t * 128; g.n_frames = N;
+        launch_gemm<KFIRST_PAD, 2, 0>(g, d->first_wp, MT, eng->gemm_wide_min_tiles, s);
+    }
     // >= 1024 token rows (52 sequences of 20 frames): the encoder GEMMs are large enough for 64 x 64 tiles streamed through LDS
     // (pd_gemm_stream.h; same sums in another order than the 32-row split-K tiles below, i.e. rounding-level differences
     // between small and large batches).  LayerNorm is fused into the A staging there too (pre-pass per workgroup; affine folded
     // into the weights, as below).
-    const bool streamed = M >= PD_STREAM_MIN_ROWS && d->hn;
     for (int l = 0; l < d->num_layers; ++l) {
         const PdLayerDev &L = d->layers[l];
         if (streamed && eng->den_split && d->split_ready) {
@@ -697,8 +753,12 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
         launch_gemm<DFF, 0, 2>(g, L.ff2_wp, MT, eng->gemm_wide_min_tiles, s);
     }
     // _last.0 as a plain tile GEMM, then the fused LN/ReLU/Linear(128->9)/DDPM tail
-    g.A = d->h; g.bias = d->last0_b; g.C = d->hid; g.Nout = HID;
-    launch_gemm<DM, 0, 0>(g, d->last0_wp, MT, eng->gemm_wide_min_tiles, s);
+    if (streamed) {
+        pd_gemm_stream<0>(d->h, DM, d->last0_wf, DM, d->last0_b, d->hid, M, HID, s);
+    } else {
+        g.A = d->h; g.bias = d->last0_b; g.C = d->hid; g.Nout = HID;
+        launch_gemm<DM, 0, 0>(g, d->last0_wp, MT, eng->gemm_wide_min_tiles, s);
+    }
     HeadArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.hid = d->hid; ha.lnw = d->last_ln_w; ha.lnb = d->last_ln_b;
