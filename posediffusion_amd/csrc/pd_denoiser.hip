@@ -607,18 +607,6 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
         PD_HIP_CHECK(hipGetLastError());
         PD_TRY(dev_rowmajor(d, &d->last0_wf, w->last0_w, HID, DM, nullptr));
     }
-    {
-        std::vector<float> sc((size_t)w->timesteps * 8, 0.0f);
-        for (int t = 0; t < w->timesteps; ++t) {
-            sc[t * 8 + 0] = eng->c_recip[t];
-            sc[t * 8 + 1] = eng->c_recipm1[t];
-            sc[t * 8 + 2] = eng->coef1[t];
-            sc[t * 8 + 3] = eng->coef2[t];
-            sc[t * 8 + 4] = expf(0.5f * eng->logvar[t]);
-        }
-        PD_TRY(dev_alloc(d, &d->sched, sc.size()));
-        PD_HIP_CHECK(hipMemcpy(d->sched, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
     PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0, 32>, 32 * (KFIRST_PAD + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0, 16>, 32 * (KFIRST_PAD + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 0, 32>, 32 * (DM + 4) * 4));

@@ -46,7 +46,6 @@ struct PdDenoiserDev {
     float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ff = nullptr, *hid = nullptr;   // activations [rows, .]
     float *hn = nullptr;               // LayerNorm(h) without affine, streamed path only
     float *emb = nullptr, *first_wf = nullptr, *last0_wf = nullptr;   // streamed path: _first's input rows [rows, 704], row-major _first / _last.0 weights
-    float *sched = nullptr;            // [T,8]: c_recip, c_recipm1, coef1, coef2, sigma per step
     bool split_ready = false;          // the fast mode's split weights exist
     std::vector<void *> allocs;
 };
