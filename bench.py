@@ -8,10 +8,11 @@ A "step" = one full pass of the hot path over ONE batch of 64 independent synthe
   resident in HBM before the timed region.
 
 Scaling (`--scaling`, default strong = what configs[3] names: "batch of 64 ... sharded across 8 x MI355X"):
-  strong  every step's 64 sequences are block-partitioned over the N ranks (64 / N each).  A rank keeps its engine
-          launches at 64 sequences by running the shards of N consecutive steps in one engine pass, `--pipeline-depth`
-          passes in flight -- so the per-GPU launch shape (and efficiency) is the single-GPU one and only the
-          pipeline fill / drain of a short run costs.  Total work is fixed: K x 64 sequences whatever N.
+  strong  every step's 64 sequences are block-partitioned over the N ranks (64 / N each).  A rank runs the shards of
+          several consecutive steps as ONE engine pass of up to `--engine-batch` = 256 sequences (a GGS launch of 256
+          workgroups holds every CU once), `--pipeline-depth` passes in flight, the run's passes balanced
+          (shard.steps_per_pass) -- so the per-GPU launch shape is the single-GPU one as long as a rank has that many
+          sequences, and the pipeline fill / drain of a short run is what costs.  Total work is fixed: K x 64 sequences.
   weak    every rank runs its own 64-sequence batch per step (64 x N sequences per step).
 There is no collective on the data path; ONE all_gather of the poses of all K steps ends the timed region.
 
@@ -99,7 +100,7 @@ def lib_sha256():
     return h.hexdigest()
 
 
-def pmc_traffic(which):
+def pmc_traffic(which, eb=None):
     """Fabric-side traffic per launch from the committed rocprofv3 PMC summary (counters need their own `rocprofv3 --pmc`
     passes: tools/collect_pmc.sh).  Valid only for the binary it was collected with: the summary records the sha256 of
     libpd_engine.so and a mismatch voids it LOUDLY (stderr + reason in the JSON) instead of quoting a stale number."""
@@ -114,6 +115,8 @@ def pmc_traffic(which):
                f"running library is {want[:12]}...: traffic not reported (re-run tools/collect_pmc.sh)")
         print("bench.py: " + msg, file=sys.stderr)
         return None, msg
+    if eb is not None and d.get("batch_sequences") != eb:
+        return None, f"{os.path.relpath(PMC_SUMMARY, ROOT)} is for an engine batch of {d.get('batch_sequences')} sequences, this run uses {eb}"
     return d[which]["traffic_bytes_corrected"], (
         f"{os.path.relpath(PMC_SUMMARY, ROOT)}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, separate --pmc passes, gfx950 "
         "FETCH_SIZE x2 correction; fabric-side counters (Infinity-Cache hits are counted: an upper bound on HBM bytes); same "
@@ -244,10 +247,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--seqs-per-step", type=int, default=STEP_SEQS, help="sequences per step: in total (strong) / per GPU (weak)")
-    ap.add_argument("--engine-batch", type=int, default=64, help="sequences per engine pass (a rank groups the shards of consecutive steps up to this)")
+    ap.add_argument("--engine-batch", type=int, default=256,
+                    help="most sequences per engine pass (a rank groups the shards of consecutive steps up to this; 256 = one GGS workgroup per CU)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ggs-wgs", type=int, default=0, help="override GGS workgroups per sequence (0 = from the pipeline shape)")
-    ap.add_argument("--pipeline-depth", type=int, default=4,
+    ap.add_argument("--pipeline-depth", type=int, default=3,
                     help="engine contexts / HIP streams per GPU (engine passes in flight); 1 = serial")
     ap.add_argument("--trace", action="store_true", help="print the pipeline timeline (per-pass phase times) to stderr")
     ap.add_argument("--no-per-config", action="store_true", help="skip the per-BASELINE-config measurements")
@@ -279,7 +283,8 @@ def main():
     if strong:
         g0, g1, group, _ = shard.strong_schedule(K, step_total, world, rank, args.engine_batch)
     else:
-        g0, g1, group = rank * args.seqs_per_step, (rank + 1) * args.seqs_per_step, max(1, args.engine_batch // args.seqs_per_step)
+        g0, g1 = rank * args.seqs_per_step, (rank + 1) * args.seqs_per_step
+        group = shard.steps_per_pass(K, args.seqs_per_step, args.engine_batch)
     B_step = g1 - g0                                                            # this rank's sequences of one step
     if B_step <= 0:
         raise SystemExit(f"rank {rank} has no sequences: {step_total} per step over {world} ranks")
@@ -319,7 +324,7 @@ def main():
                 out = engines[j].sample(z, noise, COND_START, cfg, use_graph=use_graph, want_process=False, phase=1)
                 engines[j].sample(z, noise, COND_START, cfg, use_graph=use_graph, want_process=False, phase=2, out=out)
             torch.cuda.synchronize()
-    stagger_ms = float(os.environ.get("PD_BENCH_STAGGER_MS", "0"))
+    stagger_ms = float(os.environ.get("PD_BENCH_STAGGER_MS", "0"))      # experiment knob, default off (measured: profiles/round2_overlap_probe.txt)
     sleep_cycles_per_ms = 0.0
     if stagger_ms > 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -475,7 +480,7 @@ def main():
     ggs_set_ms = max(evs[0][0].elapsed_time(e1) for _, e1 in evs)
     ggs_set_tflops = depth * ggs_flops / (ggs_set_ms * 1e-3) / 1e12
     match_bytes = float(EB) * M * MATCH_BYTES * 7 * cfg.iter_num             # streamed once per iteration at one workgroup per sequence
-    ggs_traffic, traffic_src = pmc_traffic("ggs_launch") if (EB == 64 and (wgs or 24) == 1) else (None, "PMC summary is for 64 sequences, one workgroup each")
+    ggs_traffic, traffic_src = pmc_traffic("ggs_launch", EB) if (wgs or 24) == 1 else (None, "PMC summary is for one workgroup per sequence")
     k_eff = wgs or 24
     roofline = {
         "kernel": f"pd_ggs_kernel (one launch = one guided diffusion step = 700 iterations x {EB} sequences, {k_eff} workgroup(s) per sequence)",
@@ -484,7 +489,7 @@ def main():
         "achieved": ggs_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ggs_tflops / FP32_PEAK_TFLOPS,
         "algorithmic_flops_per_launch": ggs_flops, "algorithmic_flop_per_match_iteration": FLOP_PER_MATCH_ITER,
         "launch_ms": ggs_ms, "launch_timing": "hipEvents around the launch on its stream (pd_time_kernel), one launch alone on the chip: "
-                                              f"its {EB * k_eff} workgroups occupy {EB * k_eff} of the 256 CUs",
+                                              f"its {EB * k_eff} workgroups take one CU each (256 CUs)",
         "traffic": ggs_traffic, "traffic_source": traffic_src,
         "co_resident": {"launches": depth, "wall_ms": ggs_set_ms, "achieved": ggs_set_tflops, "frac": ggs_set_tflops / FP32_PEAK_TFLOPS,
                         "note": f"the {depth} contexts' launches issued together on their streams, as in the pipe; reproducible from "
@@ -516,7 +521,7 @@ def main():
     den_flops = tokens * DENOISER_MFLOP_PER_TOKEN * 1e6
     den_tflops = den_flops / (den_ms * 1e-3) / 1e12
     den_gbs = DENOISER_PARAMS * 4 / (den_ms * 1e-3) / 1e9
-    den_traffic, den_src = pmc_traffic("denoiser_step") if EB == 64 else (None, None)
+    den_traffic, den_src = pmc_traffic("denoiser_step", EB)
     if tokens > 50:      # the weight stream bounds the denoiser up to ~50 tokens, the exact-fp32 matrix pipe above
         roofline_den = {"kernel": f"one denoiser step at {tokens} token rows (pd_gemm_stream_kernel / pd_gemm_kernel / pd_attn_kernel / pd_tail_kernel launches)",
                         "bound": "mfma", "bound_detail": "exact-fp32 matrix instruction (157.3 TFLOP/s)",

@@ -185,22 +185,32 @@ def test_colmap_keypoint_bookkeeping_vs_reference_fixture(golden):
 
 def test_strong_scaling_schedule_covers_every_sequence_once():
     """bench.py's strong-scaling plan (posediffusion_amd/shard.py): K steps x 64 sequences over 1/2/4/8 (and an uneven 3)
-    ranks -- every (step, sequence) lands on exactly one rank, in one pass, at the rows `step_rows` says, and a rank's
-    engine passes hold `engine_batch` sequences except the last."""
+    ranks -- every (step, sequence) lands on exactly one rank, in one pass, at the rows `step_rows` says; a rank's engine
+    passes hold at most `engine_batch` sequences, are equally long except the last, and are balanced: no more passes than
+    ceil(S / engine_batch) (two for a run that fits one), the last one at least half as long as the others."""
     from posediffusion_amd import shard
     for world in (1, 2, 3, 4, 8):
-        for K in (1, 5, 20, 24):
-            seen = {}
-            for rank in range(world):
-                g0, g1, group, passes = shard.strong_schedule(K, 64, world, rank, 64)
-                b = g1 - g0
-                assert sum(passes) == K * b and all(p == group * b for p in passes[:-1]) and 0 < passes[-1] <= group * b
-                assert group * b <= 64
-                for step in range(K):
-                    p, r0, r1 = shard.step_rows(step, group, b)
-                    assert r1 - r0 == b and r1 <= passes[p]
-                    for q in range(b):
-                        key = (step, g0 + q)
-                        assert key not in seen
-                        seen[key] = (rank, p, r0 + q)
-            assert len(seen) == K * 64
+        for K in (1, 5, 20, 24, 96):
+            for EB in (64, 256):
+                seen = {}
+                for rank in range(world):
+                    g0, g1, group, passes = shard.strong_schedule(K, 64, world, rank, EB)
+                    b = g1 - g0
+                    assert sum(passes) == K * b and all(p == group * b for p in passes[:-1]) and 0 < passes[-1] <= group * b
+                    assert group * b <= max(EB, b)
+                    want = max(-(-K * b // EB), min(2, K))
+                    assert group == max(1, min(-(-K // want), max(1, EB // b))) and len(passes) == -(-K // group), (world, K, EB, passes)
+                    for step in range(K):
+                        p, r0, r1 = shard.step_rows(step, group, b)
+                        assert r1 - r0 == b and r1 <= passes[p]
+                        for q in range(b):
+                            key = (step, g0 + q)
+                            assert key not in seen
+                            seen[key] = (rank, p, r0 + q)
+                assert len(seen) == K * 64
+    # the shapes the sweep behind the defaults measured (profiles/round2_inflight_sweep.txt): 20 steps on 1 / 2 / 4 / 8 GPUs
+    assert shard.strong_schedule(20, 64, 1, 0, 256)[3] == [256] * 5
+    assert shard.strong_schedule(20, 64, 2, 0, 256)[3] == [224, 224, 192]
+    assert shard.strong_schedule(20, 64, 4, 0, 256)[3] == [160, 160]
+    assert shard.strong_schedule(20, 64, 8, 0, 256)[3] == [80, 80]
+    assert shard.strong_schedule(24, 64, 1, 0, 256)[3] == [256] * 6

@@ -43,13 +43,16 @@ def main():
     def corrected(prefix):
         return sum(v["traffic_bytes_per_dispatch_corrected"] for k, v in kernels.items() if prefix in k)
 
-    # one denoiser step = 34 GEMM launches of 7 kinds + 8 attention + 1 tail (+ 16 LayerNorm launches on the streamed path);
-    # weight per kind by its launches per step (kinds that did not run in the profiled process contribute nothing)
+    # one denoiser step, launches per kind (kinds that did not run in the profiled process contribute nothing; a kind's
+    # figure is the average over its dispatches, so kinds that serve layers of different sizes are weighted by their count).
+    # < 1024 token rows: 34 tile-GEMM launches of 7 kinds + 8 attention + 1 tail
     per_step = {"pd_gemm_kernel<704": 1, "pd_gemm_kernel<512, 1, 0": 8, "pd_gemm_kernel<512, 0, 2": 8,
                 "pd_gemm_kernel<512, 1, 1": 8, "pd_gemm_kernel<1024, 0, 2": 8, "pd_gemm_kernel<512, 0, 0": 1,
                 "pd_attn_kernel": 8, "pd_tail_kernel": 1,
-                # >= 1024 token rows: the encoder GEMMs of a layer run on the streamed kernel (pd_gemm_stream.h) instead
-                "pd_gemm_stream_kernel<0": 8, "pd_gemm_stream_kernel<2": 16, "pd_gemm_stream_kernel<1": 8, "pd_ln_rows_kernel<512": 16}
+                # >= 1024 token rows: everything on the streamed kernel (pd_gemm_stream.h): QKV (LayerNorm in the staging) x 8,
+                # FF1 likewise x 8, out-projection + FF2 x 16, _first + _last.0 x 2, and the input-row kernel of _first
+                "pd_gemm_stream_kernel<0, 1, 1, true": 8, "pd_gemm_stream_kernel<1, 1, 1, true": 8,
+                "pd_gemm_stream_kernel<2, 1, 1, false": 16, "pd_gemm_stream_kernel<0, 1, 1, false": 2, "pd_embed_rows_kernel": 1}
     den = 0.0
     for k, v in kernels.items():
         for pre, n in per_step.items():
@@ -61,8 +64,9 @@ def main():
         lib_hash = hashlib.sha256(fh.read()).hexdigest()
     out = {
         "libpd_engine_sha256": lib_hash,   # bench.py quotes these figures only for the binary they were measured on
+        "batch_sequences": int(cmd.split()[2]) if len(cmd.split()) > 2 and cmd.split()[2].isdigit() else None,   # ... and for this engine batch
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `{cmd}` "
-                  "(one batch of the default size, N=20, GGS on, GGS workgroups per sequence as in the default 4-batch pipeline), 1x MI355X; tools/collect_pmc.sh + tools/pmc_summary.py",
+                  "(one engine batch of the bench default size, N=20, GGS on, one GGS workgroup per sequence), 1x MI355X; tools/collect_pmc.sh + tools/pmc_summary.py",
         "units": "KB per dispatch as reported by rocprofv3 (FETCH_SIZE / WRITE_SIZE); bytes = KB * 1024",
         "gfx950_correction": "MI355X_MICROARCH.md section HBM: FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) "
                              "coalesced read stream on gfx950 -> doubled in *_corrected; Infinity-Cache hits are counted "
