@@ -385,15 +385,17 @@ def test_full_size_properties_n20_m57000(engine):
     assert 0.2 < final_loss < 0.45, final_loss
 
 
-def test_bench_default_shape_64_sequences_one_workgroup_each(seeded_diffuser, engine):
-    """bench.py's default launch shape: 64 sequences in one persistent launch, one workgroup (= one CU) per sequence, all 190
-    pairs of a sequence on that workgroup.  Every slot must equal, bit for bit, the same sequence optimised alone (B = 1) at
-    1 and at 24 workgroups, and a guided sampling pass of the 64 must equal 64 single passes."""
+@pytest.mark.parametrize("B", [64, 256])
+def test_bench_default_shape_one_workgroup_per_sequence(seeded_diffuser, engine, B):
+    """bench.py's launch shapes: one step's batch (64 sequences) and the default engine pass (256 sequences = a workgroup on
+    every CU) in one persistent launch, one workgroup per sequence, all 190 pairs of a sequence on that workgroup.  Every slot
+    must equal, bit for bit, the same sequence optimised alone (B = 1) at 1 and at 24 workgroups, and a guided sampling pass
+    of the batch replayed from its hipGraph must equal the eager launches."""
     from posediffusion_amd.engine import PoseEngine
     from posediffusion_amd.host import denoiser_state
     dev = torch.device(DEV)
     diff = seeded_diffuser.to(dev)
-    B, N = 64, 20
+    N = 20
     eng = PoseEngine(denoiser_state(diff.model), {k: v for k, v in diff.named_buffers(recurse=False)}, device=dev, max_B=B, max_N=N)
     mds, x0s = [], []
     for b in range(B):
@@ -407,7 +409,7 @@ def test_bench_default_shape_64_sequences_one_workgroup_each(seeded_diffuser, en
     out64, st64, _ = eng.ggs_optimize(x0, cfg=cfg1)
     eng.check_async()
     assert (st64.reshape(B, -1)[:, 1] == 12).all()                      # 6 iterations x 2 runs ("all" = T alone, then all) everywhere
-    for b in (0, 17, 42, 63):
+    for b in (0, 17, 42, B - 1):
         md = mds[b]
         engine.set_matches(0, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
         for k in (1, 24):
