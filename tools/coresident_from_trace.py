@@ -1,7 +1,8 @@
 """Co-resident GGS launches from a rocprofv3 kernel trace (rocpd sqlite):  python tools/coresident_from_trace.py results.db [flops_per_launch]
 
 bench.py runs `--pipeline-depth` engine contexts, each on its own HIP stream; their persistent pd_ggs_kernel launches
-(one per guided diffusion step) are meant to be resident TOGETHER (64 workgroups each on a 256-CU chip).  This reads the
+(one per guided diffusion step; 256 workgroups each by default = one per CU, so launches issued together queue behind each
+other workgroup by workgroup; 64 each in the 4 x 64 shape of round 1) overlap in time.  This reads the
 kernel dispatch timestamps of a trace of the bench command, merges overlapping pd_ggs_kernel intervals into sets and
 reports, per set size, the wall time of a set (union of its intervals) and the fp32-ALU rate it implies
 (n launches x flops_per_launch / wall) -- the `roofline.co_resident` figure of bench.py, recomputed from profiles/.
@@ -11,7 +12,7 @@ import sys
 from collections import defaultdict
 
 db = sqlite3.connect(sys.argv[1])
-flops = float(sys.argv[2]) if len(sys.argv) > 2 else 64 * 57000 * 100.0 * 700
+flops = float(sys.argv[2]) if len(sys.argv) > 2 else 256 * 57000 * 100.0 * 700     # the bench default engine pass
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
 kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
 ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
@@ -40,6 +41,6 @@ for n in sorted(by_size):
     w = sum(walls) / len(walls)
     print(f"sets of {n} overlapping launch(es): {len(walls)} sets, wall {w:.3f} ms per set -> {n * flops / (w * 1e-3) / 1e12:.2f} TFLOP/s = "
           f"{n * flops / (w * 1e-3) / 1e12 / 157.3 * 100:.1f} % of the fp32 vector ALU peak")
-if max(by_size) == 1:
+if max(by_size) == 1 and len(rows) > 4:
     print("NOTE: no two launches overlap in this trace: the tracer serialised the streams; the co-resident figure cannot be read from it "
           "(see the single 256-sequence launch of tools/pmc_target.py 256 1 instead: one launch that fills the chip)")

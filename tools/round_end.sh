@@ -12,7 +12,7 @@ timeout 900 python bench.py > $F/bench_line.json 2> $F/bench.err; tail -2 $F/ben
 cd /tmp && export TMPDIR=/tmp
 timeout 500 rocprofv3 --kernel-trace --stats -d $R/$F/trace -o bench -- python $R/bench.py --no-per-config --no-fresh-inputs --cpu-budget-s 0 > $R/$F/bench_traced.json 2>/dev/null
 cd $R; python tools/rocpd_stats.py $F/trace/bench_results.db 16 > $F/kernel_stats.txt
-python tools/coresident_from_trace.py $F/trace/bench_results.db > $F/coresident.txt 2>&1; cat $F/coresident.txt; rm -rf $F/trace
+python tools/coresident_from_trace.py $F/trace/bench_results.db $(python -c "import json; print(json.load(open('$F/bench_traced.json'))['roofline']['algorithmic_flops_per_launch'])") > $F/coresident.txt 2>&1; cat $F/coresident.txt; rm -rf $F/trace
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$F/trace256 -o t256 -- python $R/tools/pmc_target.py 256 1 > /dev/null 2>&1
 cd $R; python tools/rocpd_stats.py $F/trace256/t256_results.db 6 > $F/fullchip_launch_stats.txt
