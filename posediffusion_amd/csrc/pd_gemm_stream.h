@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
 
 #define PD_STREAM_MIN_ROWS 1024
 // 64 x 64 tiles: 128 x 64 and 128 x 128 (WM / WN = 2) measured no faster at 31 520 rows and slower at 3 940
-// (profiles/round1_j_vit_notes.md), so only <EPI, 1, 1> is instantiated
+// (profiles/round1_j_vit_notes.md); 64 x 128 (WN = 2) for the 1 536- / 1 024-wide denoiser GEMMs at 5 120 rows: the same bits and the
+// same time (2.37 ms per step alone, 5.72 ms for three contexts, round 2) -- so only <EPI, 1, 1> is instantiated
 template <int EPI, bool ALN = false>
 static inline void pd_gemm_stream(const float *A, int lda, const float *W, int K, const float *bias, float *C, int M, int Nout, hipStream_t s,
                                   float ln_eps = 0.0f) {
