@@ -97,6 +97,8 @@ typedef struct pd_ggs_cfg {
 #define PD_GGS_CFG_NO_LDS_STAGING 2   /* pd_ggs_cfg.reserved: stream match items through registers even where the LDS-DMA double
                                        * buffer applies (several items per wavefront, every item <= 384 matches); same arithmetic,
                                        * bitwise the same results -- comparison / testing */
+#define PD_GGS_CFG_WAVES8 4           /* pd_ggs_cfg.reserved: keep 8 wavefronts per workgroup where the staged one-workgroup-per-
+                                       * sequence shape would run 12 (three per SIMD); bitwise the same results -- comparison */
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
 

@@ -38,6 +38,9 @@
 // that fuses a*b+c differently in two instantiations of the same source line would break that.
 #pragma clang fp contract(on)
 
+#ifndef PD_GGS_PROF12
+#define PD_GGS_PROF12 0
+#endif
 #ifndef PD_GGS_MIN_WAVES_PER_SIMD
 #define PD_GGS_MIN_WAVES_PER_SIMD 2      // one 512-thread workgroup per CU; 4 = experiment: two workgroups per CU (<= 128 VGPRs)
 #endif
@@ -281,7 +284,7 @@ struct Lds {
     int *incoff;   // [PD_GGS_MAX_PCHUNKS][68] per chunk of pairs: CSR offsets of its incidences per frame
     float *F;      // [n_slots*PD_F_STRIDE]
     float *item;   // [n_items*12]
-    float *stage;  // [8 waves][2 buffers][STAGE_P KiB] LDS-DMA staging of the match pass (pd_ggs_kernel<STAGE_P > 0>), 1 KiB aligned
+    float *stage;  // [8 waves][2 buffers][STAGE_P KiB] (or [12 waves][1 buffer]) LDS-DMA staging of the match pass (pd_ggs_kernel<STAGE_P > 0>), 1 KiB aligned
 };
 
 __device__ __forceinline__ Lds carve(float *base, int n_slots, int pinc_rows, int n_items_cap) {
@@ -306,11 +309,11 @@ __device__ __forceinline__ Lds carve(float *base, int n_slots, int pinc_rows, in
     L.stage = base + ((((L.item + n_items_cap * PD_ITEM_VALS) - base) + 255) & ~255);   // 1 KiB aligned (base is the LDS origin)
     return L;
 }
-static size_t ggs_lds_bytes(int n_slots, int n_items, int pinc_rows, int stage_p) {
+static size_t ggs_lds_bytes(int n_slots, int n_items, int pinc_rows, int stage_p, int stage_bufs = PD_GGS_WAVES * 2) {
     const size_t f9 = (size_t)n_slots * PD_F_STRIDE;
     size_t b = ((size_t)PD_GGS_LDS_FIXED + (size_t)pinc_rows * 16 + PD_GGS_MAX_PCHUNKS * 68 + f9 + (size_t)n_items * PD_ITEM_VALS) * 4 +
                (size_t)n_slots * 16;
-    if (stage_p > 0) b = ((b + 1023) & ~(size_t)1023) + (size_t)PD_GGS_WAVES * 2 * stage_p * 1024;
+    if (stage_p > 0) b = ((b + 1023) & ~(size_t)1023) + (size_t)stage_bufs * stage_p * 1024;   // 8 waves x 2 buffers, or 12 x 1
     return b;
 }
 
@@ -536,8 +539,16 @@ __device__ __forceinline__ void pd_vmcnt() {
 // the first item of the next iteration in flight across the serial phases.  STAGE_P = 0: through registers (any item size).
 // RESIDENT: every wave owns at most one item (n_slots == 8, the k = ceil(items / 8) regime): its matches stay in registers for
 // the whole launch -- a compile-time variant, so the other variants do not carry those 32 registers.
-template <int STAGE_P, bool RESIDENT>
-__global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_ggs_kernel(PdGgsParams P, int B, int n_slots, int pinc_rows, int items_cap) {
+// NW: waves per workgroup.  8 (two per SIMD, up to 256 VGPRs) everywhere; 12 (three per SIMD, 168 VGPRs: the compiler spills launch
+// constants of the serial phases, the match pass itself stays in registers) for the staged k = 1 shape, where the match pass is bound
+// by VALU cycles two waves per SIMD leave unused.  Slots, chunks of pairs and the P3 thread roles keep their 8-wave / 512-thread
+// geometry (the extra waves only take part in the match pass and the strided loops), so every sum is the one the 8-wave kernel forms;
+// with 12 waves a wave has ONE staging buffer: the item is read out of LDS whole, after which the buffer takes the next item.
+template <int STAGE_P, bool RESIDENT, int NW = PD_GGS_WAVES>
+__global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_PER_SIMD) void pd_ggs_kernel(PdGgsParams P, int B, int n_slots, int pinc_rows, int items_cap) {
+    constexpr int NT = NW * 64;                       // threads of this instantiation
+    constexpr bool SINGLE = NW > PD_GGS_WAVES;        // one staging buffer per wave
+    static_assert(!(RESIDENT && SINGLE) && (NW == PD_GGS_WAVES || STAGE_P > 0), "12 waves: the staged variants only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x % B, wg = blockIdx.x / B;   // XCD-aware: see header comment
@@ -546,6 +557,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
     const int nW = k * PD_GGS_WAVES;
     const int n_items = D.n_items;
     const Lds L = carve(smem, n_slots, pinc_rows, items_cap);
+    const bool p3t = tid < PD_GGS_THREADS;            // takes part in the 512-thread roles of P3
     float *xg = P.x + (size_t)b * N * PD_POSE_DIM;
     u64 *xchg = P.xchg ? P.xchg + (size_t)b * 2 * P.xchg_stride : nullptr;
 
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
         }
     }
     // local item table -> LDS (slot = wave + 8 * round <-> item = wg*8 + wave + round * nW)
-    for (int s = tid; s < n_slots; s += PD_GGS_THREADS) {
+    for (int s = tid; s < n_slots; s += NT) {
         const int item = wg * PD_GGS_WAVES + (s & 7) + (s >> 3) * nW;
         int4 e = make_int4(0, 0, 0, 0);
         if (item < n_items) {
@@ -569,7 +581,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
         }
         L.itab[s] = e;
     }
-    for (int q = tid; q < D.n_pchunks * (N + 1); q += PD_GGS_THREADS) L.incoff[(q / (N + 1)) * 68 + q % (N + 1)] = D.pchunk_off[q];
+    for (int q = tid; q < D.n_pchunks * (N + 1); q += NT) L.incoff[(q / (N + 1)) * 68 + q % (N + 1)] = D.pchunk_off[q];
     if (tid == 0) {
         L.ctl[0] = 0.0f;
         L.ctl[1] = 0.0f;
@@ -615,8 +627,8 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
     }
 #endif
     const bool staged = STAGE_P > 0 && !resident && wave < n_local;
-    const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(L.stage + wave * (2 * STAGE_P * 256)));
-    const float4 *stage_ptr = (const float4 *)(L.stage + wave * (2 * STAGE_P * 256));
+    const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(L.stage + wave * ((SINGLE ? 1 : 2) * STAGE_P * 256)));
+    const float4 *stage_ptr = (const float4 *)(L.stage + wave * ((SINGLE ? 1 : 2) * STAGE_P * 256));
     int pb = 0;                                   // buffer that holds (or is receiving) the item computed next
     // byte offsets of this lane's match in each piece (lane + 64 q), clamped per item to its last match
     unsigned lane_off[6];
@@ -655,10 +667,13 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
     const bool small_n = N <= PD_GGS_THREADS / 16;              // every frame has its own thread group
     const bool spare_wave = N * 16 <= (PD_GGS_WAVES - 1) * 64;   // the last wave is entirely idle in P3b
     // pair-level backward in chunks of PD_GGS_THREADS pairs (one chunk up to N = 32); chunk 0's table entry is hoisted
-    const int4 my_pair = (tid < D.n_pairs) ? D.ptab[tid] : make_int4(0, 0, 0, 0);
+    const int4 my_pair = (p3t && tid < D.n_pairs) ? D.ptab[tid] : make_int4(0, 0, 0, 0);
     unsigned epoch = 0;
     int trace_row = 0;
-    const bool prof = P.prof != nullptr && blockIdx.x == 0 && wave == (P.prof_wave & 7);   // one wave of WG 0
+    // the in-kernel cycle counters cost 24 VGPRs for the whole launch: compiled out of the 12-wave variants, which run at the
+    // 168-register limit (build with -DPD_GGS_PROF12 to study those; pd_ggs_plan keeps 8 waves while profiling is on otherwise)
+    constexpr bool HAS_PROF = !SINGLE || PD_GGS_PROF12;
+    const bool prof = HAS_PROF && P.prof != nullptr && blockIdx.x == 0 && wave == (P.prof_wave & 7);   // one wave of WG 0
     #ifdef PD_GGS_PROF2   // build with -DPD_GGS_PROF2 for the timers INSIDE the match pass (claim / DMA issue / wait / pass / reduce)
     long long pt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pc = 0, pq = 0;
 #else
@@ -674,8 +689,8 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
             if (prof) pc = __builtin_readcyclecounter();
             // ---- P1: F for the pairs of this workgroup's items -------------------------------
             const Cam cam = {L.cam[0], L.cam[1], L.cam[2], L.cam[3]};
-            if (tid == 0) *q_ctr = PD_GGS_WAVES;          // first slot the match pass hands out dynamically
-            for (int s = tid; s < n_slots; s += PD_GGS_THREADS) {
+            if (tid == 0) *q_ctr = NW;                    // first slot the match pass hands out dynamically
+            for (int s = tid; s < n_slots; s += NT) {
                 const int4 e = L.itab[s];
                 if (e.y > 0) {
                     float Ri[9], Rj[9], ti[3], tj[3];
@@ -741,16 +756,20 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
                 } else if constexpr (STAGE_P > 0) {
                     // the slot this wave computes next (or its own first one, for the next iteration: the matches never
                     // change) goes into the other buffer while this one is computed; STAGE_P pieces stay in flight
-                    stage_item(s_next < n_local ? s_next : wave, pb ^ 1);
+                    if constexpr (!SINGLE) stage_item(s_next < n_local ? s_next : wave, pb ^ 1);
                     PD_PROF2(11);
-                    pd_vmcnt<STAGE_P>();
+                    pd_vmcnt<SINGLE ? 0 : STAGE_P>();
                     PD_PROF2(12);
                     // the whole item out of LDS at once (one exposed LDS latency instead of one per step)
                     float4 mb[8];
                     {
-                        const float4 *Bp = stage_ptr + pb * (STAGE_P * 64) + lane;
+                        const float4 *Bp = stage_ptr + (SINGLE ? 0 : pb) * (STAGE_P * 64) + lane;
 #pragma unroll
                         for (int q = 0; q < 8; ++q) mb[q] = q < STAGE_P ? Bp[64 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    if constexpr (SINGLE) {     // the item is in registers: its buffer takes the next one while this one is computed
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mb[0].x), "+v"(mb[1].x), "+v"(mb[2].x), "+v"(mb[3].x), "+v"(mb[4].x), "+v"(mb[5].x) :: "memory");
+                        stage_item(s_next < n_local ? s_next : wave, 0);
                     }
                     item_pass<true>(MatchRegs{mb}, e.y, lane, Fm, P.sampson_max, acc2, nv);
                     pb ^= 1;
@@ -794,12 +813,12 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
                 // each item is one 128-byte line of 16 granules (12 used); a thread fetches 16-byte pieces
                 // (2 granules) with write-through-coherent (sc1) loads, up to 3 pieces in flight per pass
                 const int n_piece = n_items * 6;
-                for (int p0 = tid; p0 < n_piece; p0 += 3 * PD_GGS_THREADS) {
+                for (int p0 = tid; p0 < n_piece; p0 += 3 * NT) {
                     const u64 *a[3];
                     int pi_[3];
 #pragma unroll
                     for (int u = 0; u < 3; ++u) {
-                        const int pc = p0 + u * PD_GGS_THREADS;
+                        const int pc = p0 + u * NT;
                         pi_[u] = pc < n_piece ? pc : p0;
                         a[u] = slot + (size_t)(pi_[u] / 6) * PD_XCHG_LINE + (pi_[u] % 6) * 2;
                     }
@@ -827,7 +846,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
                     const u32x4 vv[3] = {v0, v1, v2};
 #pragma unroll
                     for (int u = 0; u < 3; ++u) {
-                        if (p0 + u * PD_GGS_THREADS < n_piece) {
+                        if (p0 + u * NT < n_piece) {
                             const int g = (pi_[u] / 6) * PD_ITEM_VALS + (pi_[u] % 6) * 2;
                             L.item[g] = __uint_as_float(vv[u][0]);
                             L.item[g + 1] = __uint_as_float(vv[u][2]);
@@ -859,7 +878,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
                     // per SIMD: cost is per wave-instruction, so this halves the critical path of the per-incidence
                     // form (6 waves, two SIMDs carrying two waves each).
                     const int pair = ck * PD_GGS_THREADS + tid;
-                    if (pair < D.n_pairs) {
+                    if (p3t && pair < D.n_pairs) {
                         const int4 mp = (ck == 0) ? my_pair : D.ptab[pair];
                         const int pi = mp.x & 0xff, pj = mp.x >> 8, nit = mp.z;
                         float G[9];
@@ -908,7 +927,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
                 } else {         // several passes over the frames, partial sums carried across chunks in LDS
                     for (int n0 = 0; n0 < N; n0 += PD_GGS_THREADS / 16) {
                         const int n = n0 + fb_n;
-                        if (n < N) {
+                        if (p3t && n < N) {
                             const int lo = coff[n], hi = coff[n + 1];
                             float acc2 = (ck == 0) ? 0.0f : L.psum[n * 16 + fb_c];
                             for (int e = lo; e < hi; e += 16) {   // 16 LDS loads in flight, summed in order
@@ -948,7 +967,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS, PD_GGS_MIN_WAVES_PER_SIMD) void pd_
             } else {
                 for (int n0 = 0; n0 < N; n0 += PD_GGS_THREADS / 16) {
                     const int n = n0 + fb_n;
-                    if (n < N) {
+                    if (p3t && n < N) {
                         const float v = L.psum[n * 16 + fb_c];
                         if (fb_c < 9) {
                             const int aa = fb_c / 3, bb = fb_c % 3;
@@ -1492,7 +1511,8 @@ __global__ void pd_ggs_zero_kernel(unsigned long long *p, size_t n) {
 
 int pd_ggs_init() {
     const void *variants[] = {(const void *)pd_ggs_kernel<0, true>, (const void *)pd_ggs_kernel<0, false>, (const void *)pd_ggs_kernel<3, false>,
-                              (const void *)pd_ggs_kernel<5, false>, (const void *)pd_ggs_kernel<6, false>};
+                              (const void *)pd_ggs_kernel<5, false>, (const void *)pd_ggs_kernel<6, false>,
+                              (const void *)pd_ggs_kernel<3, false, 12>, (const void *)pd_ggs_kernel<5, false, 12>, (const void *)pd_ggs_kernel<6, false, 12>};
     for (const void *f : variants) PD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PD_HIP_CHECK(hipFuncSetAttribute((const void *)pd_ggs2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return PD_OK;
@@ -1579,6 +1599,17 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
         pd_set_error("pd_ggs: %d work items need %zu B of LDS per workgroup (> 160 KiB) at B=%d", max_items, lds, B);
         return PD_ERR_UNSUPPORTED;
     }
+    // three waves per SIMD for the staged match pass at one workgroup per sequence with several rounds of items per wave (the
+    // bench shape): A/B switch PD_GGS_CFG_WAVES8 keeps the 8-wave kernel
+    int waves = PD_GGS_WAVES;
+    if (!two_hop && stage_p > 0 && k == 1 && n_slots >= 3 * 12 && !(cfg->reserved & PD_GGS_CFG_WAVES8) && (PD_GGS_PROF12 || !eng->ggs_prof_on)) {
+        const size_t lds12 = ggs_lds_bytes(n_slots, max_items, pinc_rows, stage_p, 12);
+        if (lds12 <= 160 * 1024) {
+            waves = 12;
+            lds = lds12;
+        }
+    }
+    out->waves = waves;
     out->pinc_rows = pinc_rows;
     out->stage_p = stage_p;
     out->k = k;
@@ -1638,11 +1669,14 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     else {
         void (*kern)(PdGgsParams, int, int, int, int) =
             n_slots == PD_GGS_WAVES ? pd_ggs_kernel<0, true>
+            : plan.waves == 12 && plan.stage_p == 6 ? pd_ggs_kernel<6, false, 12>
+            : plan.waves == 12 && plan.stage_p == 5 ? pd_ggs_kernel<5, false, 12>
+            : plan.waves == 12 && plan.stage_p == 3 ? pd_ggs_kernel<3, false, 12>
             : plan.stage_p == 6 ? pd_ggs_kernel<6, false>
             : plan.stage_p == 5 ? pd_ggs_kernel<5, false>
             : plan.stage_p == 3 ? pd_ggs_kernel<3, false>
                                 : pd_ggs_kernel<0, false>;
-        hipLaunchKernelGGL(kern, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots, pinc_rows, items_cap);
+        hipLaunchKernelGGL(kern, dim3(B * k), dim3(plan.waves * 64), lds, s, P, B, n_slots, pinc_rows, items_cap);
     }
     PD_HIP_CHECK(hipGetLastError());
     return pd_mark_use(eng, s);

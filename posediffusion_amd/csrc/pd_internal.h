@@ -80,6 +80,7 @@ struct PdGgsParams {
 struct PdGgsPlan {
     int k, n_slots, lds, two_hop, max_items;
     int pinc_rows, stage_p;    // one-hop kernel: LDS rows of the pair backward; LDS-DMA staging pieces per item (0 = through registers)
+    int waves;                 // one-hop kernel: waves per workgroup (8, or 12 for the staged k = 1 shape)
 };
 
 struct PdSeqHost {
