@@ -403,3 +403,34 @@ def test_split_precision_denoiser_fast_mode_deviation(seeded_diffuser, oracle_we
     print(f"free-running 100 steps vs fp64: exact fp32 mode {d_exact:.2e}, split mode {d_split:.2e}; split vs exact {rel_err(finals[True], finals[False]):.2e}")
     assert d_split <= max(4.0 * d_exact, 1e-3), (d_split, d_exact)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_one_workgroup_per_sequence_kernel_variants_agree_bitwise(seeded_diffuser):
+    """At one workgroup per sequence (the bench shape: 190 items, 24 rounds per wave) pd_ggs_plan picks the LDS-staged kernel with
+    12 waves (three per SIMD, one staging buffer per wave).  pd_ggs_cfg.reserved switches back to 8 waves (PD_GGS_CFG_WAVES8 = 4)
+    and to the register-streamed match pass (PD_GGS_CFG_NO_LDS_STAGING = 2): same arithmetic in the same order -> the same bits,
+    for a guided step with the full stage schedule and for the per-stage statistics."""
+    from posediffusion_amd.engine import PoseEngine, make_ggs_cfg
+    from posediffusion_amd.host import denoiser_state
+    dev = torch.device("cuda:0")
+    diff = seeded_diffuser.to(dev)
+    B, N = 6, 20
+    eng = PoseEngine(denoiser_state(diff.model), {k: v for k, v in diff.named_buffers(recurse=False)}, device=dev, max_B=B, max_N=N)
+    xs = []
+    for b in range(B):
+        enc = synth.make_cameras(N, seed=900 + b)
+        md = synth.make_matches(enc, 224, 224, per_pair=(300, 130, 64, 333, 200, 90)[b], seed=900 + b)   # 2..6 staging pieces per item
+        eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+        xs.append(synth.perturb_pose(enc, seed=910 + b))
+    x0 = torch.cat(xs).to(dev)
+    res = {}
+    for flags in (0, 4, 2, 6):
+        out, stats = eng.ggs_guide(x0, 3, make_ggs_cfg(synth.GGS_CFG, iter_num=5, wgs_per_seq=1, reserved=flags))
+        eng.check_async()
+        res[flags] = (out.clone(), stats.clone())
+    for flags in (4, 2, 6):
+        assert torch.equal(res[0][0], res[flags][0]), flags
+        assert torch.equal(res[0][1].nan_to_num(-1.0), res[flags][1].nan_to_num(-1.0)), flags
+    assert torch.isfinite(res[0][0]).all()
+    eng.close()
