@@ -49,6 +49,13 @@ class pd_vit_weights(C.Structure):
                 + [("layers", pd_vit_layer_weights * 16)])
 
 
+# pd_ggs_cfg.reserved flags and pd_engine_set_option ids (include/pd_engine.h; tests/test_host_cpu.py checks them against the header)
+PD_GGS_CFG_FORCE_ONE_HOP = 1
+PD_GGS_CFG_NO_LDS_STAGING = 2
+PD_GGS_CFG_WAVES8 = 4
+PD_OPT_DENOISER_SPLIT = 2
+
+
 class pd_ggs_cfg(C.Structure):
     _fields_ = [("alpha", C.c_float), ("learning_rate", C.c_float), ("iter_num", C.c_int32),
                 ("sampson_max", C.c_float), ("min_matches", C.c_int32), ("momentum", C.c_float),

@@ -259,7 +259,7 @@ class PoseEngine:
         """Fast mode of the denoiser at >= 1024 token rows (include/pd_engine.h PD_OPT_DENOISER_SPLIT): encoder GEMMs in split
         precision on the bf16 matrix pipe.  Not the default: narrower arithmetic than the reference's fp32."""
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.pd_engine_set_option(self._h, 2, int(bool(on))), "pd_engine_set_option")
+            _lib.check(self.lib.pd_engine_set_option(self._h, _lib.PD_OPT_DENOISER_SPLIT, int(bool(on))), "pd_engine_set_option")
 
     def pose_to_camera(self, enc: torch.Tensor):
         enc = self._f32(enc).reshape(-1, 9)

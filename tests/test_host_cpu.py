@@ -30,6 +30,12 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.pd_layer_weights) == 12 * 8
     assert ctypes.sizeof(_lib.pd_weights) == 10 * 4 + 6 * 8 + 16 * 12 * 8 + 11 * 8
     assert ctypes.sizeof(_lib.pd_ggs_cfg) == 32
+    # the flag / option constants Python uses are the header's
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pd_engine.h")).read()
+    for name in ("PD_GGS_CFG_FORCE_ONE_HOP", "PD_GGS_CFG_NO_LDS_STAGING", "PD_GGS_CFG_WAVES8", "PD_OPT_DENOISER_SPLIT"):
+        m = re.search(r"#define\s+" + name + r"\s+(\d+)", hdr)
+        assert m and int(m.group(1)) == getattr(_lib, name), name
 
 
 def test_engine_fails_loudly_without_gpu(seeded_diffuser):
