@@ -459,7 +459,8 @@ def main():
                 engines[j].set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
 
     # ---- roofline of the dominant kernel + the denoiser step, timed with hipEvents on the launch stream
-    ggs_ms = eng.time_kernel(1, EB, N_FRAMES, cfg, reps=3)
+    eng.time_kernel(1, EB, N_FRAMES, cfg, reps=2)             # warm: the timed launches below start on a busy chip (clocks up), as in the pipe
+    ggs_ms = eng.time_kernel(1, EB, N_FRAMES, cfg, reps=5)
     den_ms = eng.time_kernel(0, EB, N_FRAMES, cfg, reps=20)
     M = N_FRAMES * (N_FRAMES - 1) // 2 * PER_PAIR
     ggs_flops = EB * M * FLOP_PER_MATCH_ITER * 7 * cfg.iter_num              # one pd_ggs_guide launch = 700 iterations
@@ -497,6 +498,9 @@ def main():
                                 "profiles/ with tools/coresident_from_trace.py (union of the kernel's intervals in a rocprofv3 kernel trace)"},
         "fabric": {"algorithmic_bytes_per_launch": match_bytes, "achieved_GBps_one_launch": match_bytes / (ggs_ms * 1e-3) / 1e9,
                    "achieved_GBps_co_resident": depth * match_bytes / (ggs_set_ms * 1e-3) / 1e9,
+                   "hbm_peak_GBps": HBM_PEAK_GBS, "frac_of_hbm_peak_one_launch": match_bytes / (ggs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "why_reported": "with three waves per SIMD the full-chip launch is bandwidth-sensitive: it runs ~5-9 % slower inside the pipe, "
+                                   "where the other contexts' denoiser kernels share the fabric, than alone (DESIGN 3.2, profiles/round2_coresident.txt)",
                    "note": f"{EB * depth} sequences in flight, at most 256 of them (one GGS workgroup per CU) iterating at a time: {min(EB * depth, 256)} x "
                            f"{M * MATCH_BYTES / 1e6:.2f} MB of matches = {min(EB * depth, 256) * M * MATCH_BYTES / 1e6:.0f} MB re-read every iteration at one workgroup "
                            "per sequence (a chosen trade: no replicated serial phase); that set fits the 256 MiB Infinity Cache, so this is fabric / "
