@@ -1,0 +1,41 @@
+"""Register / scratch budget of the GGS kernel variants, read from hipcc's own resource remarks (cross-compiled for gfx950, no GPU
+needed).  The design rests on these numbers: the 8-wave variants must hold two waves per SIMD without touching scratch, the
+12-wave variants must fit three waves per SIMD (168 VGPRs) with the match pass free of spills -- what little is spilled are launch
+constants of the serial phases."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "posediffusion_amd", "csrc", "pd_ggs.hip")
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not installed")
+def test_ggs_kernel_variants_keep_their_register_budget(tmp_path):
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-Rpass-analysis=kernel-resource-usage",
+                          "-c", SRC, "-o", str(tmp_path / "pd_ggs.o")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    ggs = {k: v for k, v in kernels.items() if "pd_ggs_kernel" in k}
+    assert len(ggs) == 8, sorted(kernels)                       # <0,true,8> <0,false,8> <3|5|6,false,8> <3|5|6,false,12>
+    for name, r in ggs.items():
+        twelve = "ELi12EE" in name
+        if twelve:
+            assert r["VGPRs"] <= 168 and r["Occupancy"] == 3, (name, r)
+            assert r["VGPRs Spill"] <= 16 and r["ScratchSize"] <= 64, (name, r)     # launch constants of the serial phases only
+        else:
+            assert r["VGPRs"] <= 256 and r["Occupancy"] == 2, (name, r)
+            assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
+    two_hop = [v for k, v in kernels.items() if "pd_ggs2_kernel" in k]
+    assert two_hop and two_hop[0]["VGPRs Spill"] == 0 and two_hop[0]["ScratchSize"] == 0
