@@ -217,10 +217,9 @@ __device__ __forceinline__ v2f pd_splat(float a) { return (v2f){a, a}; }
 // Every fused multiply-add below is written out and contraction is off inside the two step functions, so the packed and the
 // single-match form perform the same roundings: an item's sums do not depend on which form ran its tail.
 template <bool EXACT>
-__device__ __forceinline__ void sampson_step2(const float4 pa, const float4 pb, bool ina, bool inb, const float *F, float smax,
+__device__ __forceinline__ void sampson_step2(const v2f u1, const v2f v1, const v2f u2, const v2f v2, bool ina, bool inb, const float *F, float smax,
                                               v2f (&acc)[PD_ITEM_VALS], float &mind, int &nv) {
 #pragma clang fp contract(off)
-    const v2f u1 = {pa.x, pb.x}, v1 = {pa.y, pb.y}, u2 = {pa.z, pb.z}, v2 = {pa.w, pb.w};
     // left = x1^T F, right = F x2   (:158-159)
     const v2f l0 = pd_fma2(u1, pd_splat(F[0]), pd_fma2(v1, pd_splat(F[3]), pd_splat(F[6])));
     const v2f l1 = pd_fma2(u1, pd_splat(F[1]), pd_fma2(v1, pd_splat(F[4]), pd_splat(F[7])));
@@ -419,20 +418,31 @@ __device__ __forceinline__ void sampson_step1(const float4 pa, bool ina, const f
 
 // where an item's matches come from: registers (resident / streamed through registers) or this wave's LDS staging buffer
 // (lane-linear image written by LDS-DMA: match m at byte 16 m)
+// Table layout (built at upload, host and device builders alike): inside an item every FULL group of 128 matches is stored
+// pair-interleaved -- element lane of the group = (u1_A, u1_B, v1_A, v1_B), element 64 + lane = (u2_A, u2_B, v2_A, v2_B) with A = match
+// lane, B = match 64 + lane of the group -- so a full packed step finds its four operand pairs in adjacent registers (8 register
+// moves per step less; the pass is bound by VALU cycles).  The remainder of an item (< 128 matches) stays one float4 per match.
 struct MatchRegs {
     const float4 (&M)[8];
     __device__ __forceinline__ float4 get(int j, int) const { return M[j]; }
+    __device__ __forceinline__ void full_pairs(int j, v2f &u1, v2f &v1, v2f &u2, v2f &v2) const {
+        const float4 q0 = M[2 * j], q1 = M[2 * j + 1];
+        u1 = (v2f){q0.x, q0.y}; v1 = (v2f){q0.z, q0.w}; u2 = (v2f){q1.x, q1.y}; v2 = (v2f){q1.z, q1.w};
+    }
 };
 struct MatchLds {
     const float4 *B;
     __device__ __forceinline__ float4 get(int j, int lane) const { return B[lane + 64 * j]; }
 };
 
+
 // the (<= 4) two-match steps of an item as straight-line code per step count: without the per-step branch the
 // scheduler interleaves the independent steps, which hides the VALU dependency latency two waves per SIMD cannot
 // (a FULL step lies wholly inside the item: its range masks are compile-time true and the selects they feed fold away)
-#define PD_P2_FULL(j) sampson_step2<EXACT>(src.get(2 * (j), lane), src.get(2 * (j) + 1, lane), true, true, Fm, smax, acc2, mind, nv)
-#define PD_P2_STEP(j) sampson_step2<EXACT>(src.get(2 * (j), lane), src.get(2 * (j) + 1, lane), (lane + 128 * (j)) < cnt, (lane + 128 * (j) + 64) < cnt, Fm, smax, acc2, mind, nv)
+#define PD_P2_FULL(j) do { v2f a_, b_, c_, d_; src.full_pairs(j, a_, b_, c_, d_); sampson_step2<EXACT>(a_, b_, c_, d_, true, true, Fm, smax, acc2, mind, nv); } while (0)
+#define PD_P2_STEP(j) do { const float4 pa_ = src.get(2 * (j), lane), pb_ = src.get(2 * (j) + 1, lane);                                       \
+        sampson_step2<EXACT>((v2f){pa_.x, pb_.x}, (v2f){pa_.y, pb_.y}, (v2f){pa_.z, pb_.z}, (v2f){pa_.w, pb_.w}, (lane + 128 * (j)) < cnt,   \
+                             (lane + 128 * (j) + 64) < cnt, Fm, smax, acc2, mind, nv); } while (0)
 #define PD_P2_TAIL(j)                                                                                           \
     do {                                                                                                        \
         if (rem > 64 || (!TAIL1 && rem > 0)) PD_P2_STEP(j);                                                     \
@@ -1463,6 +1473,15 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     const size_t o_gio = al(o_gps + sizeof(int2) * gpos.size());
     const size_t total = al(o_gio + sizeof(int) * ginc_off.size());
     std::vector<char> host(total, 0);
+    for (const int4 &it : items)                                  // full 128-match groups of every item: pair-interleaved (MatchRegs)
+        for (int g = 0; g + 128 <= it.z; g += 128)
+            for (int l = 0; l < 64; ++l) {
+                float4 &a = pts[(size_t)it.y + g + l], &b = pts[(size_t)it.y + g + 64 + l];
+                float4 q0, q1;
+                pd_interleave_pair(a, b, q0, q1);
+                a = q0;
+                b = q1;
+            }
     memcpy(host.data() + o_pts, pts.data(), sizeof(float4) * pts.size());
     memcpy(host.data() + o_pij, pair_ij.data(), sizeof(int2) * pair_ij.size());
     memcpy(host.data() + o_pio, pair_item_off.data(), sizeof(int) * pair_item_off.size());

@@ -309,6 +309,25 @@ __global__ __launch_bounds__(64) void ingest_scatter_kernel(IngestArgs A) {
     }
 }
 
+// ---- kernel 4: pair-interleave the full 128-match groups of every item (the layout pd_ggs.hip's packed steps read) -----------
+// one wave per work item; a lane rewrites exactly the two elements it read (group[lane], group[64 + lane]): in place, no hazards
+__global__ __launch_bounds__(64) void ingest_interleave_kernel(IngestArgs A) {
+    const IngestSeq S = A.s[blockIdx.y];
+    const int item = blockIdx.x, lane = threadIdx.x;
+    if (item >= S.desc->n_items) return;               // actual count, written by ingest_tables_kernel
+    IngestLayout L;
+    ingest_layout(S.M, A.N, A.P_cap, A.I_cap, A.C_cap, L);
+    const int4 it = ((const int4 *)(S.blob + L.itm))[item];   // (pair, first match, count, 0)
+    float4 *pts = (float4 *)(S.blob + L.pts) + it.y;
+    for (int g = 0; g + 128 <= it.z; g += 128) {
+        const float4 a = pts[g + lane], b = pts[g + 64 + lane];
+        float4 q0, q1;
+        pd_interleave_pair(a, b, q0, q1);
+        pts[g + lane] = q0;
+        pts[g + 64 + lane] = q1;
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 static size_t tables_lds_bytes(int N, int P_cap, int C_cap) {
     return sizeof(int) * ((size_t)2 * N * N + 2 * (size_t)P_cap + (size_t)(C_cap + 1) * (N + 1) + 16 + 4);
@@ -417,6 +436,7 @@ extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n
         hipLaunchKernelGGL(ingest_hist_kernel, dim3(max_tiles, nb), dim3(256), lds_hist, s, A);
         hipLaunchKernelGGL(ingest_tables_kernel, dim3(nb), dim3(ING_TABLE_THREADS), lds_tab, s, A);
         hipLaunchKernelGGL(ingest_scatter_kernel, dim3(max_tiles, nb), dim3(64), lds_hist, s, A);
+        hipLaunchKernelGGL(ingest_interleave_kernel, dim3(I_cap, nb), dim3(64), 0, s, A);
         PD_HIP_CHECK(hipGetLastError());
     }
     // later GGS launches on OTHER streams wait for this point (pd_sample_phase / pd_ggs_launch), again on the device

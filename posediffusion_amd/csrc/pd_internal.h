@@ -77,6 +77,14 @@ struct PdGgsParams {
 };
 
 // launch shape of one GGS launch (pd_ggs_plan): everything a captured graph node bakes in besides its arguments
+// Match table layout inside a work item: every FULL group of 128 matches is stored pair-interleaved (pd_ggs.hip MatchRegs) -- this is the
+// transform of one lane's two matches A = group[lane], B = group[64 + lane], applied by both table builders (host: pd_ggs_set_matches;
+// device: ingest_interleave_kernel)
+__host__ __device__ inline void pd_interleave_pair(const float4 a, const float4 b, float4 &q0, float4 &q1) {
+    q0 = make_float4(a.x, b.x, a.y, b.y);
+    q1 = make_float4(a.z, b.z, a.w, b.w);
+}
+
 struct PdGgsPlan {
     int k, n_slots, lds, two_hop, max_items;
     int pinc_rows, stage_p;    // one-hop kernel: LDS rows of the pair backward; LDS-DMA staging pieces per item (0 = through registers)
