@@ -256,7 +256,7 @@ def make_preprocess():
     print("preprocess.npz", os.path.getsize(os.path.join(OUT, "preprocess.npz")))
 
 
-def make_guided_free(seeds=(0, 1, 2), N=8, cond_start=3, per_pair=60):
+def make_guided_free(seeds=(0, 1, 2), N=8, cond_start=3, per_pair=60, name="guided_free"):
     """tests/golden/guided_free.npz -- SURVEY.md section 8c's FREE-RUNNING GGS-on criterion, scaled down from BASELINE
     configs[2]: N = 8 frames, 28 pairs x 60 matches, 100 DDPM steps, the last `cond_start` = 3 of them guided with the
     FULL default schedule (5 optimisations = 700 iterations per guided step, cfgs/default.yaml:6-13).  Per seed:
@@ -265,7 +265,12 @@ def make_guided_free(seeds=(0, 1, 2), N=8, cond_start=3, per_pair=60):
     and each one's final mean Sampson error over its valid matches (evaluated in fp64 at the final pose).
     With random-init weights the sampled poses are arbitrary, so -- as bench.py does -- the matches are synthesised
     to be epipolar-consistent (+0.5 px noise, 10 % outliers) with the fp32 model mean at the first guided step, which
-    puts the guided steps in the basin the trained model + SuperGlue matches would give (all 2 100 iterations run)."""
+    puts the guided steps in the basin the trained model + SuperGlue matches would give (all 2 100 iterations run).
+
+    `make_guided_free(seeds=(0,), N=20, cond_start=10, per_pair=300, name="guided_free_full")` writes
+    tests/golden/guided_free_full.npz: ONE seed of BASELINE configs[2] at its real size -- 20 frames, 190 pairs x 300 =
+    57 000 matches, 224^2, 100 steps, the last 10 guided x 700 iterations = 7 000 iterations.
+    (about 20 CPU-minutes: the reference and the fp64 oracle each run 7 000 iterations over 57 000 matches on one thread)."""
     torch.set_num_threads(1)
     ref = RS.load_reference()
     diff = RS.build_reference_diffuser(seed=0)
@@ -318,13 +323,15 @@ def make_guided_free(seeds=(0, 1, 2), N=8, cond_start=3, per_pair=60):
                     f"s{s}_pose32": pose32.numpy(), f"s{s}_pose64": pose64.detach().numpy(), f"s{s}_mean_at_first_guided": mean.numpy(),
                     f"s{s}_sampson32": np.array(sam["32"]), f"s{s}_sampson64": np.array(sam["64"]), f"s{s}_ref_optimize_calls": n_it})
     out["img_shape"] = np.array([N, 3, 224, 224])
-    np.savez_compressed(os.path.join(OUT, "guided_free.npz"), **out)
-    print("guided_free.npz", os.path.getsize(os.path.join(OUT, "guided_free.npz")))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ".npz", os.path.getsize(os.path.join(OUT, name + ".npz")))
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "guided_free":
         make_guided_free()      # only the free-running GGS-on fixture
+    elif len(sys.argv) > 1 and sys.argv[1] == "guided_free_full":
+        make_guided_free(seeds=(0,), N=20, cond_start=10, per_pair=300, name="guided_free_full")   # configs[2] at real size
     elif len(sys.argv) > 1 and sys.argv[1] == "metrics":
         make_metrics()          # only the N3 fixture (the others stay byte-identical)
     elif len(sys.argv) > 1 and sys.argv[1] == "preprocess":
@@ -334,3 +341,4 @@ if __name__ == "__main__":
         make_metrics()
         make_preprocess()
         make_guided_free()
+        make_guided_free(seeds=(0,), N=20, cond_start=10, per_pair=300, name="guided_free_full")
