@@ -308,9 +308,9 @@ def make_guided_free(seeds=(0, 1, 2), N=8, cond_start=3, per_pair=60, name="guid
         pose64, process64 = O.p_sample_loop(sd64, t64, z.double(), init.double(), [None if n is None else n.double() for n in noises],
                                             cond_fn=cond64, cond_start_step=cond_start)
         sam = {}
-        for name, pose in (("32", pose32), ("64", pose64)):
+        for tag, pose in (("32", pose32), ("64", pose64)):
             v, _ = O.compute_sampson_distance(pose.detach().double(), pm)
-            sam[name] = (float(v.mean()), len(v))
+            sam[tag] = (float(v.mean()), len(v))
         noise = np.zeros((T + 1, 1, N, 9), dtype=np.float32)
         noise[0] = init.numpy()
         for step in range(T):

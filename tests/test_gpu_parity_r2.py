@@ -79,47 +79,63 @@ def test_long_sequence_n50_full_size_m367500(engine):
 
 
 # ------------------------------------------------------------------------------------------------ free-running GGS-on
-def test_free_running_ggs_on_criterion_vs_reference_fixture(engine, golden):
-    """SURVEY.md section 8c, free-running GGS-on (scaled-down BASELINE configs[2]: N = 8, 28 pairs x 60 matches, 100
-    steps, the last 10 guided with the full 700-iteration schedule = 7 000 iterations; three seeds).  The fixture holds,
-    per seed, the UNMODIFIED reference's fp32 result and the fp64 oracle's on the same z / noise / matches.
-
-    Pass criterion as SURVEY states it: engine-vs-fp64 deviation <= 2 x (reference-fp32-vs-fp64 deviation) -- taken
-    over the three seeds together, because one chaotic trajectory is one sample (the reference's own deviation is
-    3.2e-4, 1.7e-3 and 6.5e-4 on these seeds) -- and no seed worse than 4 x its reference deviation.
-    Final mean Sampson error: SURVEY asks for 1 % of the oracle's.  The fixture shows the reference itself misses
-    that by far (fp32 vs fp64: 2.7 %, 4.0 %, 50 % on these seeds: |pose| ~ 45 with random-init weights, a hard
-    threshold, 7 000 iterations), so the bound is max(1 %, 2 x the reference's own relative gap), seeds together."""
-    g = golden["guided_free"]
+def _free_running_case(engine, g, s, cfg):
+    """One seed of a free-running GGS-on fixture through the engine: (pose deviation from fp64, the reference-fp32's own,
+    relative gap of the final mean Sampson error to the fp64 oracle's, the reference-fp32's own gap)."""
     cond_start = int(g["cond_start_step"])
     shape = tuple(int(v) for v in g["img_shape"])
+    kp1, kp2, i12 = g[f"s{s}_kp1"], g[f"s{s}_kp2"], g[f"s{s}_i12"]
+    engine.set_matches(0, kp1, kp2, i12, shape)
+    z, noise = torch.from_numpy(g[f"s{s}_z"]).to(DEV), torch.from_numpy(g[f"s{s}_noise"]).to(DEV)
+    outs = []
+    for use_graph in (True, False):
+        pose, _, stats = engine.sample(z, noise, cond_start, cfg, use_graph=use_graph)
+        engine.check_async()
+        outs.append(pose.cpu())
+    assert torch.equal(outs[0], outs[1]), "hipGraph replay must equal eager launches bit for bit"
+    assert stats[:, 0, :, 1].sum().item() == 700 * cond_start, "every guided step must run its 700 iterations"
+    pose = outs[0]
+    p64, p32 = g[f"s{s}_pose64"], g[f"s{s}_pose32"]
+    pm = O.prepare_matches(kp1, kp2, i12, shape)
+    v, _ = O.compute_sampson_distance(pose.double(), pm)
+    s64, s32 = float(g[f"s{s}_sampson64"][0]), float(g[f"s{s}_sampson32"][0])
+    return rel_err(pose, p64), rel_err(p32, p64), abs(float(v.mean()) - s64) / s64, abs(s32 - s64) / s64
+
+
+def test_free_running_ggs_on_criterion_vs_reference_fixture(engine, golden):
+    """SURVEY.md section 8c, free-running GGS-on (scaled-down BASELINE configs[2]: N = 8, 28 pairs x 60 matches, 100
+    steps, the last 3 guided with the full 700-iteration schedule; three seeds).  The fixture holds, per seed, the
+    UNMODIFIED reference's fp32 result and the fp64 oracle's on the same z / noise / matches.
+
+    Pass criterion as SURVEY states it, PER SEED (no summing across seeds): engine-vs-fp64 pose
+    deviation <= 2 x (reference-fp32-vs-fp64 deviation).  Final mean Sampson error: SURVEY asks for 1 % of the
+    oracle's; the fixture shows the reference itself misses that by far (fp32 vs fp64: 2.7 %, 4.0 %, 50 % on these
+    seeds: |pose| ~ 45 with random-init weights, a hard threshold, 2 100 iterations), so the bound per seed is
+    max(1 %, 2 x the reference's own relative gap for that seed)."""
+    g = golden["guided_free"]
     cfg = dict(synth.GGS_CFG)
-    devs, ref_devs, sam_gaps, ref_sam_gaps = [], [], [], []
-    for s in g["seeds"].tolist():
-        kp1, kp2, i12 = g[f"s{s}_kp1"], g[f"s{s}_kp2"], g[f"s{s}_i12"]
-        engine.set_matches(0, kp1, kp2, i12, shape)
-        z, noise = torch.from_numpy(g[f"s{s}_z"]).to(DEV), torch.from_numpy(g[f"s{s}_noise"]).to(DEV)
-        outs = []
-        for use_graph in (True, False):
-            pose, _, stats = engine.sample(z, noise, cond_start, cfg, use_graph=use_graph)
-            engine.check_async()
-            outs.append(pose.cpu())
-        assert torch.equal(outs[0], outs[1]), "hipGraph replay must equal eager launches bit for bit"
-        assert stats[:, 0, :, 1].sum().item() == 700 * cond_start, "every guided step must run its 700 iterations"
-        pose = outs[0]
-        p64, p32 = g[f"s{s}_pose64"], g[f"s{s}_pose32"]
-        devs.append(rel_err(pose, p64))
-        ref_devs.append(rel_err(p32, p64))
-        pm = O.prepare_matches(kp1, kp2, i12, shape)
-        v, _ = O.compute_sampson_distance(pose.double(), pm)
-        s64, s32 = float(g[f"s{s}_sampson64"][0]), float(g[f"s{s}_sampson32"][0])
-        sam_gaps.append(abs(float(v.mean()) - s64) / s64)
-        ref_sam_gaps.append(abs(s32 - s64) / s64)
-    print(f"free-running GGS-on: engine vs fp64 {devs}, reference fp32 vs fp64 {ref_devs}; "
-          f"final mean Sampson gap to fp64: engine {sam_gaps}, reference fp32 {ref_sam_gaps}")
-    assert sum(devs) <= 2.0 * sum(ref_devs), (devs, ref_devs)
-    assert all(d <= 4.0 * r for d, r in zip(devs, ref_devs)), (devs, ref_devs)
-    assert sum(sam_gaps) <= max(0.01 * len(sam_gaps), 2.0 * sum(ref_sam_gaps)), (sam_gaps, ref_sam_gaps)
+    rows = [_free_running_case(engine, g, s, cfg) for s in g["seeds"].tolist()]
+    print("free-running GGS-on (N = 8): (engine dev, reference dev, engine Sampson gap, reference gap) per seed:", rows)
+    for dev, ref_dev, gap, ref_gap in rows:
+        assert dev <= 2.0 * ref_dev, rows
+        assert gap <= max(0.01, 2.0 * ref_gap), rows
+
+
+def test_free_running_ggs_on_full_size_configs2_vs_reference_fixture(engine, golden):
+    """The same criterion at the benchmark's REAL size: one seed of BASELINE configs[2] exactly --
+    N = 20, 190 pairs x 300 = 57 000 matches, 224^2, 100 steps, the last 10 guided x 700 iterations = 7 000 iterations --
+    through the unmodified reference in fp32 and the fp64 oracle (oracle/make_golden.py guided_free_full; the reference
+    ran all 50 GGS_optimize calls to completion).  Per-seed bounds: pose deviation from fp64 <= 2 x the reference's own
+    (5.8e-4), final mean Sampson gap to the fp64 oracle's <= max(1 %, 2 x the reference's own gap) (the reference's
+    fp32 run ends at 0.383 against fp64's 0.302: 27 %)."""
+    g = golden["guided_free_full"]
+    assert int(g["cond_start_step"]) == 10 and len(g["s0_kp1"]) == 57000 and int(g["s0_ref_optimize_calls"]) == 50
+    cfg = dict(synth.GGS_CFG)
+    dev, ref_dev, gap, ref_gap = _free_running_case(engine, g, 0, cfg)
+    print(f"free-running GGS-on, configs[2] full size: engine vs fp64 {dev:.3e} (reference fp32 {ref_dev:.3e}); "
+          f"final mean Sampson gap to fp64: engine {gap:.3%}, reference fp32 {ref_gap:.3%}")
+    assert dev <= 2.0 * ref_dev, (dev, ref_dev)
+    assert gap <= max(0.01, 2.0 * ref_gap), (gap, ref_gap)
 
 
 # ------------------------------------------------------------------------------------------------ the hard threshold

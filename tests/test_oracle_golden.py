@@ -272,3 +272,28 @@ def test_vit_oracle_loads_dino_state_dict_names():
     for k in ("cls_token", "pos_embed", "patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.bias", "norm.weight"):
         assert k in keys
     assert sum(v.numel() for v in VO.make_vit(0).state_dict().values()) == 21665664      # ViT-S/16
+
+
+@pytest.mark.parametrize("fname", ["guided_free", "guided_free_full"])
+def test_free_running_fixtures_are_self_consistent(golden, fname):
+    """The free-running GGS-on fixtures (reference fp32 run + fp64 oracle run, oracle/make_golden.py make_guided_free):
+    the stored final mean Sampson errors are what the oracle evaluates at the stored poses on the stored matches, the
+    noise tensor follows the reference's draw order (no noise on guided steps), and the full-size one is BASELINE
+    configs[2] exactly (20 frames, 190 pairs x 300 matches, 10 guided steps)."""
+    g = golden[fname]
+    cond_start = int(g["cond_start_step"])
+    shape = tuple(int(v) for v in g["img_shape"])
+    for s in g["seeds"].tolist():
+        kp1, kp2, i12 = g[f"s{s}_kp1"], g[f"s{s}_kp2"], g[f"s{s}_i12"]
+        pm = O.prepare_matches(kp1, kp2, i12, shape)
+        for tag in ("32", "64"):
+            v, _ = O.compute_sampson_distance(torch.from_numpy(g[f"s{s}_pose{tag}"]).double(), pm)
+            mean, n = g[f"s{s}_sampson{tag}"]
+            assert len(v) == int(n) and abs(float(v.mean()) - mean) <= 1e-12 * max(1.0, mean)
+        noise = g[f"s{s}_noise"]
+        assert noise.shape[0] == 101 and not noise[101 - cond_start:].any() and noise[1:101 - cond_start].any()
+        assert int(g[f"s{s}_ref_optimize_calls"]) == 5 * cond_start
+    if fname == "guided_free_full":
+        assert shape == (20, 3, 224, 224) and cond_start == 10
+        key = g["s0_i12"][:, 0] * 20 + g["s0_i12"][:, 1]
+        assert len(key) == 57000 and len(np.unique(key)) == 190 and (np.bincount(key)[np.unique(key)] == 300).all()
