@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 // Floating-point contraction is decided per source expression in this file (not by the backend across statements, as
@@ -200,6 +201,18 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pd_fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f pd_splat(float a) { return (v2f){a, a}; }
+// F[k] as a two-match operand.  From nine scalars (the wave-per-item kernels: F is wave-uniform) or from five register PAIRS
+// {F0,F1} {F2,F3} {F4,F5} {F6,F7} {F8,-} (the lane-per-item kernel: F is per lane; a half of a 64-bit pair feeds both halves of a
+// packed instruction through op_sel, so the nine values cost 10 registers instead of 18 splatted ones)
+struct PdFPairs {
+    v2f p[5];
+};
+template <int K>
+__device__ __forceinline__ v2f pd_fsplat(const float *F) { return pd_splat(F[K]); }
+template <int K>
+__device__ __forceinline__ v2f pd_fsplat(const PdFPairs &F) {
+    return (K & 1) ? __builtin_shufflevector(F.p[K / 2], F.p[K / 2], 1, 1) : __builtin_shufflevector(F.p[K / 2], F.p[K / 2], 0, 0);
+}
 
 // Sampson residual + dL/dF of two matches (geometry_guided_sampling.py:157-170); acc[0..8] dL/dF sums,
 // acc[9] sum(s valid), each as {match A, match B} partial sums.  Kept out of the per-match work (item_totals() finishes them per item):
@@ -216,16 +229,16 @@ __device__ __forceinline__ v2f pd_splat(float a) { return (v2f){a, a}; }
 #define PD_SAMPSON_BAND_ULPS 16.0f
 // Every fused multiply-add below is written out and contraction is off inside the two step functions, so the packed and the
 // single-match form perform the same roundings: an item's sums do not depend on which form ran its tail.
-template <bool EXACT>
-__device__ __forceinline__ void sampson_step2(const v2f u1, const v2f v1, const v2f u2, const v2f v2, bool ina, bool inb, const float *F, float smax,
-                                              v2f (&acc)[PD_ITEM_VALS], float &mind, int &nv) {
+template <bool EXACT, typename FT>
+__device__ __forceinline__ void sampson_step2(const v2f u1, const v2f v1, const v2f u2, const v2f v2, bool ina, bool inb, const FT &F, float smax,
+                                              v2f (&acc)[PD_ITEM_VALS], float &mind, int &nv, unsigned long long lanes = ~0ull) {
 #pragma clang fp contract(off)
     // left = x1^T F, right = F x2   (:158-159)
-    const v2f l0 = pd_fma2(u1, pd_splat(F[0]), pd_fma2(v1, pd_splat(F[3]), pd_splat(F[6])));
-    const v2f l1 = pd_fma2(u1, pd_splat(F[1]), pd_fma2(v1, pd_splat(F[4]), pd_splat(F[7])));
-    const v2f l2 = pd_fma2(u1, pd_splat(F[2]), pd_fma2(v1, pd_splat(F[5]), pd_splat(F[8])));
-    const v2f r0 = pd_fma2(pd_splat(F[0]), u2, pd_fma2(pd_splat(F[1]), v2, pd_splat(F[2])));
-    const v2f r1 = pd_fma2(pd_splat(F[3]), u2, pd_fma2(pd_splat(F[4]), v2, pd_splat(F[5])));
+    const v2f l0 = pd_fma2(u1, pd_fsplat<0>(F), pd_fma2(v1, pd_fsplat<3>(F), pd_fsplat<6>(F)));
+    const v2f l1 = pd_fma2(u1, pd_fsplat<1>(F), pd_fma2(v1, pd_fsplat<4>(F), pd_fsplat<7>(F)));
+    const v2f l2 = pd_fma2(u1, pd_fsplat<2>(F), pd_fma2(v1, pd_fsplat<5>(F), pd_fsplat<8>(F)));
+    const v2f r0 = pd_fma2(pd_fsplat<0>(F), u2, pd_fma2(pd_fsplat<1>(F), v2, pd_fsplat<2>(F)));
+    const v2f r1 = pd_fma2(pd_fsplat<3>(F), u2, pd_fma2(pd_fsplat<4>(F), v2, pd_fsplat<5>(F)));
     const v2f ee = pd_fma2(l0, u2, pd_fma2(l1, v2, l2));
     const v2f bottom = pd_fma2(r1, r1, pd_fma2(r0, r0, pd_fma2(l1, l1, l0 * l0)));   // :161
     const v2f inv = {pd_rcp(bottom.x), pd_rcp(bottom.y)};
@@ -247,7 +260,8 @@ __device__ __forceinline__ void sampson_step2(const v2f u1, const v2f v1, const 
     const v2f sam_v = EXACT ? (v2f){va ? sam.x : 0.0f, vb ? sam.y : 0.0f} : top * inv_v;   // = sam where valid, else 0
     const v2f cb = sam_v * inv_v;                     // sam / bottom     (half of -d sam / d bottom)
     acc[9] += sam_v;
-    nv += __builtin_popcountll(__builtin_amdgcn_ballot_w64(va)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(vb));
+    // (`lanes`: the lanes that count -- all of them in the wave-per-item kernels; the lane-per-item kernel's last wave has lanes without an item)
+    nv += __builtin_popcountll(__builtin_amdgcn_ballot_w64(va) & lanes) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(vb) & lanes);
     // (d sam / dF[r][c]) / 2 = x1[r] g_c - cb r_r x2[c] [r<2],  g_c = ca x2[c] - cb l_c [c<2]   (x1[2] = x2[2] = 1)
     const v2f g0 = pd_fma2(ca, u2, -(cb * l0)), g1 = pd_fma2(ca, v2, -(cb * l1));
     const v2f nbr0 = -(cb * r0), nbr1 = -(cb * r1);
@@ -260,6 +274,109 @@ __device__ __forceinline__ void sampson_step2(const v2f u1, const v2f v1, const 
     acc[6] += g0;
     acc[7] += g1;
     acc[8] += ca;
+}
+
+// W two-match steps at once, operation by operation (the lane-per-item kernel: one or two waves per SIMD cannot hide the VALU dependency
+// latency of ONE step's serial chain l -> bottom -> 1/bottom -> sam -> valid -> ca, cb -> g -> sums; W independent chains issued in
+// lockstep can).  Same operations as sampson_step2 on every match, and the sums take step 0's contribution first, then step 1's, ...:
+// exactly what W successive sampson_step2 calls compute.
+template <bool EXACT, int W, typename FT>
+__device__ __forceinline__ void sampson_stepW(const v2f (&u1)[W], const v2f (&v1)[W], const v2f (&u2)[W], const v2f (&v2)[W], const bool (&ina)[W],
+                                              const bool (&inb)[W], const FT &F, float smax, v2f (&acc)[PD_ITEM_VALS], float &mind, int &nv,
+                                              unsigned long long lanes) {
+#pragma clang fp contract(off)
+    v2f l0[W], l1[W], l2[W], r0[W], r1[W], ee[W], bottom[W], inv[W], top[W], sam[W], inv_v[W], ca[W], sam_v[W], cb[W], g0[W], g1[W], nbr0[W], nbr1[W];
+    bool va[W], vb[W];
+#define PD_W for (int w = 0; w < W; ++w)
+#pragma unroll
+    PD_W l0[w] = pd_fma2(v1[w], pd_fsplat<3>(F), pd_fsplat<6>(F));
+#pragma unroll
+    PD_W l1[w] = pd_fma2(v1[w], pd_fsplat<4>(F), pd_fsplat<7>(F));
+#pragma unroll
+    PD_W l2[w] = pd_fma2(v1[w], pd_fsplat<5>(F), pd_fsplat<8>(F));
+#pragma unroll
+    PD_W r0[w] = pd_fma2(pd_fsplat<1>(F), v2[w], pd_fsplat<2>(F));
+#pragma unroll
+    PD_W r1[w] = pd_fma2(pd_fsplat<4>(F), v2[w], pd_fsplat<5>(F));
+#pragma unroll
+    PD_W l0[w] = pd_fma2(u1[w], pd_fsplat<0>(F), l0[w]);
+#pragma unroll
+    PD_W l1[w] = pd_fma2(u1[w], pd_fsplat<1>(F), l1[w]);
+#pragma unroll
+    PD_W l2[w] = pd_fma2(u1[w], pd_fsplat<2>(F), l2[w]);
+#pragma unroll
+    PD_W r0[w] = pd_fma2(pd_fsplat<0>(F), u2[w], r0[w]);
+#pragma unroll
+    PD_W r1[w] = pd_fma2(pd_fsplat<3>(F), u2[w], r1[w]);
+#pragma unroll
+    PD_W ee[w] = pd_fma2(l1[w], v2[w], l2[w]);
+#pragma unroll
+    PD_W bottom[w] = l0[w] * l0[w];
+#pragma unroll
+    PD_W ee[w] = pd_fma2(l0[w], u2[w], ee[w]);
+#pragma unroll
+    PD_W bottom[w] = pd_fma2(l1[w], l1[w], bottom[w]);
+#pragma unroll
+    PD_W bottom[w] = pd_fma2(r0[w], r0[w], bottom[w]);
+#pragma unroll
+    PD_W bottom[w] = pd_fma2(r1[w], r1[w], bottom[w]);                      // :161
+#pragma unroll
+    PD_W top[w] = ee[w] * ee[w];
+#pragma unroll
+    PD_W inv[w] = (v2f){pd_rcp(bottom[w].x), pd_rcp(bottom[w].y)};
+    if (EXACT) {
+#pragma unroll
+        PD_W sam[w] = (v2f){top[w].x / bottom[w].x, top[w].y / bottom[w].y};   // IEEE, as torch divides   (:162-164)
+    } else {
+#pragma unroll
+        PD_W sam[w] = top[w] * inv[w];
+#pragma unroll
+        PD_W {
+            const v2f d = sam[w] - pd_splat(smax);
+            mind = fminf(mind, fminf(fabsf(d.x), fabsf(d.y)));               // one v_min3_f32 with |.| modifiers
+        }
+    }
+#pragma unroll
+    PD_W {
+        va[w] = ina[w] && (sam[w].x < smax);                                 // :170 (false for NaN)
+        vb[w] = inb[w] && (sam[w].y < smax);
+    }
+#pragma unroll
+    PD_W inv_v[w] = (v2f){va[w] ? inv[w].x : 0.0f, vb[w] ? inv[w].y : 0.0f};
+#pragma unroll
+    PD_W ca[w] = ee[w] * inv_v[w];
+#pragma unroll
+    PD_W sam_v[w] = EXACT ? (v2f){va[w] ? sam[w].x : 0.0f, vb[w] ? sam[w].y : 0.0f} : top[w] * inv_v[w];
+#pragma unroll
+    PD_W cb[w] = sam_v[w] * inv_v[w];
+#pragma unroll
+    PD_W nv += __builtin_popcountll(__builtin_amdgcn_ballot_w64(va[w]) & lanes) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(vb[w]) & lanes);
+#pragma unroll
+    PD_W g0[w] = -(cb[w] * l0[w]);
+#pragma unroll
+    PD_W g1[w] = -(cb[w] * l1[w]);
+#pragma unroll
+    PD_W nbr0[w] = -(cb[w] * r0[w]);
+#pragma unroll
+    PD_W nbr1[w] = -(cb[w] * r1[w]);
+#pragma unroll
+    PD_W g0[w] = pd_fma2(ca[w], u2[w], g0[w]);
+#pragma unroll
+    PD_W g1[w] = pd_fma2(ca[w], v2[w], g1[w]);
+#pragma unroll
+    PD_W {                                                                   // the sums, step by step
+        acc[9] += sam_v[w];
+        acc[0] = pd_fma2(nbr0[w], u2[w], pd_fma2(u1[w], g0[w], acc[0]));
+        acc[1] = pd_fma2(nbr0[w], v2[w], pd_fma2(u1[w], g1[w], acc[1]));
+        acc[2] = pd_fma2(u1[w], ca[w], acc[2]) + nbr0[w];
+        acc[3] = pd_fma2(nbr1[w], u2[w], pd_fma2(v1[w], g0[w], acc[3]));
+        acc[4] = pd_fma2(nbr1[w], v2[w], pd_fma2(v1[w], g1[w], acc[4]));
+        acc[5] = pd_fma2(v1[w], ca[w], acc[5]) + nbr1[w];
+        acc[6] += g0[w];
+        acc[7] += g1[w];
+        acc[8] += ca[w];
+    }
+#undef PD_W
 }
 
 // LDS carve (floats).  Everything lives in the one dynamic region (guide G17).
@@ -1311,6 +1428,27 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
     }
 }
 
+#include "pd_ggs_lane.inc"
+// (register-resident steps, streamed steps in flight) variants of the lane kernel; PD_LANE_VARIANT in the environment picks one (development)
+struct PdLaneVariant {
+    void (*fn)(PdGgsParams, int, int);
+    int rv, depth;
+};
+#define PD_LANE_VARIANTS 4
+static const PdLaneVariant pd_lane_variants[PD_LANE_VARIANTS] = {{pd_ggs_lane_kernel<PD_LANE_RV, PD_LANE_DEPTH>, PD_LANE_RV, PD_LANE_DEPTH},
+                                                                 {pd_ggs_lane_kernel<10, 4>, 10, 4},
+                                                                 {pd_ggs_lane_kernel<10, 6>, 10, 6},
+                                                                 {pd_ggs_lane_kernel<8, 6>, 8, 6}};
+static int pd_lane_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("PD_LANE_VARIANT");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v >= PD_LANE_VARIANTS) v = 0;
+    }
+    return v;
+}
+
 // --------------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------------
@@ -1461,6 +1599,60 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
             if (pair_item_off[p + 1] - pair_item_off[p] != 1) single_item_pairs = 0;
     }
 
+    // lane-per-item tables (pd_ggs_lane_kernel): every pair is cut into ceil(m / len) lane items of balanced size, len = the smallest
+    // length that leaves a sequence at most PD_LANE_MAX_ITEMS items; lane item q belongs to thread q, a wave's stream holds
+    // max-over-its-lanes steps of two matches per lane (a lane past its item's end re-reads its last match, masked in the kernel)
+    std::vector<int4> litems;
+    std::vector<int2> lwave, lptab(n_pairs);
+    std::vector<float4> lstream;
+    int l_item_len = 0, l_max_steps = 0;
+    if (n_pairs <= PD_LANE_MAX_ITEMS && n_pchunks == 1 && N <= PD_LANE_MAX_FRAMES) {
+        int lo = 1, hi = 1;
+        for (int q = 0; q < N * N; ++q) hi = std::max(hi, key_off[q + 1] - key_off[q]);
+        auto count_items = [&](int len) {
+            long long n = 0;
+            for (int q = 0; q < N * N; ++q) n += pd_lane_items_of(key_off[q + 1] - key_off[q], len);
+            return n;
+        };
+        while (lo < hi) {                                   // smallest len with <= PD_LANE_MAX_ITEMS items (n_pairs items at len = hi)
+            const int mid = (lo + hi) / 2;
+            if (count_items(mid) <= PD_LANE_MAX_ITEMS) hi = mid;
+            else lo = mid + 1;
+        }
+        l_item_len = lo;
+        for (int p = 0; p < n_pairs; ++p) {
+            const int q = pair_ij[p].x * N + pair_ij[p].y, m = key_off[q + 1] - key_off[q];
+            const int nch = pd_lane_items_of(m, l_item_len);
+            lptab[p] = make_int2((int)litems.size(), nch);
+            int start = key_off[q];
+            for (int c = 0; c < nch; ++c) {
+                const int len = m / nch + (c < m % nch ? 1 : 0);
+                litems.push_back(make_int4(pair_ij[p].x | (pair_ij[p].y << 8), len, p, start));
+                start += len;
+            }
+        }
+        const int n_lw = ((int)litems.size() + 63) / 64;
+        size_t base = 0;
+        for (int w = 0; w < n_lw; ++w) {
+            int steps = 0;
+            for (int l = 0; l < 64 && w * 64 + l < (int)litems.size(); ++l) steps = std::max(steps, (litems[w * 64 + l].y + 1) / 2);
+            lwave.push_back(make_int2((int)base, steps));
+            l_max_steps = std::max(l_max_steps, steps);
+            base += (size_t)steps * 128;
+        }
+        lstream.assign(base, make_float4(1.0f, 1.0f, 1.0f, 1.0f));
+        for (int w = 0; w < n_lw; ++w)
+            for (int t = 0; t < lwave[w].y; ++t)
+                for (int l = 0; l < 64 && w * 64 + l < (int)litems.size(); ++l) {
+                    const int4 it = litems[w * 64 + l];
+                    const float4 a = pts[(size_t)it.w + std::min(2 * t, it.y - 1)], b2 = pts[(size_t)it.w + std::min(2 * t + 1, it.y - 1)];
+                    float4 q0, q1;
+                    pd_interleave_pair(a, b2, q0, q1);
+                    lstream[(size_t)lwave[w].x + (size_t)(2 * t) * 64 + l] = q0;
+                    lstream[(size_t)lwave[w].x + (size_t)(2 * t + 1) * 64 + l] = q1;
+                }
+    }
+
     // one blob: pts | pair_ij | pair_item_off | items | ptab | pchunk_off   (aligned pieces)
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_pts = 0;
@@ -1471,7 +1663,11 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     const size_t o_pco = al(o_ptb + sizeof(int4) * ptab.size());
     const size_t o_gps = al(o_pco + sizeof(int) * pchunk_off.size());
     const size_t o_gio = al(o_gps + sizeof(int2) * gpos.size());
-    const size_t total = al(o_gio + sizeof(int) * ginc_off.size());
+    const size_t o_lit = al(o_gio + sizeof(int) * ginc_off.size());
+    const size_t o_lwv = al(o_lit + sizeof(int4) * litems.size());
+    const size_t o_lpt = al(o_lwv + sizeof(int2) * lwave.size());
+    const size_t o_lst = al(o_lpt + sizeof(int2) * lptab.size());
+    const size_t total = al(o_lst + sizeof(float4) * lstream.size());
     std::vector<char> host(total, 0);
     for (const int4 &it : items)                                  // full 128-match groups of every item: pair-interleaved (MatchRegs)
         for (int g = 0; g + 128 <= it.z; g += 128)
@@ -1490,6 +1686,12 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     memcpy(host.data() + o_pco, pchunk_off.data(), sizeof(int) * pchunk_off.size());
     memcpy(host.data() + o_gps, gpos.data(), sizeof(int2) * gpos.size());
     memcpy(host.data() + o_gio, ginc_off.data(), sizeof(int) * ginc_off.size());
+    if (!litems.empty()) {
+        memcpy(host.data() + o_lit, litems.data(), sizeof(int4) * litems.size());
+        memcpy(host.data() + o_lwv, lwave.data(), sizeof(int2) * lwave.size());
+        memcpy(host.data() + o_lpt, lptab.data(), sizeof(int2) * lptab.size());
+        memcpy(host.data() + o_lst, lstream.data(), sizeof(float4) * lstream.size());
+    }
     PdSeqHost &h = eng->seqs[seq];
     if (h.blob_bytes < total) {
         pd_ggs_free_seq(h);
@@ -1509,6 +1711,14 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     h.desc.gpos = (const int2 *)(base + o_gps);
     h.desc.ginc_off = (const int *)(base + o_gio);
     h.desc.single_item_pairs = single_item_pairs;
+    h.desc.lstream = (const float4 *)(base + o_lst);
+    h.desc.litems = (const int4 *)(base + o_lit);
+    h.desc.lwave = (const int2 *)(base + o_lwv);
+    h.desc.lptab = (const int2 *)(base + o_lpt);
+    h.desc.n_litems = (int)litems.size();
+    h.desc.n_lwaves = (int)lwave.size();
+    h.desc.l_item_len = l_item_len;
+    h.desc.l_max_steps = l_max_steps;
     h.desc.M = (int)M;
     h.desc.n_pairs = n_pairs;
     h.desc.n_items = n_items;
@@ -1534,6 +1744,8 @@ int pd_ggs_init() {
                               (const void *)pd_ggs_kernel<3, false, 12>, (const void *)pd_ggs_kernel<5, false, 12>, (const void *)pd_ggs_kernel<6, false, 12>};
     for (const void *f : variants) PD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PD_HIP_CHECK(hipFuncSetAttribute((const void *)pd_ggs2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (int v = 0; v < PD_LANE_VARIANTS; ++v)
+        PD_HIP_CHECK(hipFuncSetAttribute((const void *)pd_lane_variants[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return PD_OK;
 }
 
@@ -1563,7 +1775,38 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
     int device_cus = eng->num_cus > 0 ? eng->num_cus : 256;
     int k = cfg->wgs_per_seq > 0 ? cfg->wgs_per_seq : (max_items + PD_GGS_WAVES - 1) / PD_GGS_WAVES;
     k = std::max(1, std::min(k, device_cus / B));
-    if ((size_t)max_items * PD_XCHG_LINE > eng->xchg_granules) k = 1;
+    // the lane-per-item kernel: on request, or -- when the engine picks the shape and the launch holds more sequences than half the CUs
+    // (nothing to gain from several workgroups per sequence) -- where every sequence's matches stay RESIDENT in its registers + LDS
+    // (<= ~40 matches per lane item): there it runs 1.5 - 2 x faster than the wave-per-item kernel (profiles/round3_lane_kernel.txt).
+    // With more matches both kernels are bound by the same match stream from the Infinity Cache (7.2 - 7.7 TB/s) and the
+    // wave-per-item kernel, which keeps more of it in flight, stays the default.
+    memset(out, 0, sizeof(*out));
+    if (!(cfg->reserved & PD_GGS_CFG_NO_LANE_ITEMS) && ((cfg->reserved & PD_GGS_CFG_LANE_ITEMS) || (cfg->wgs_per_seq == 0 && device_cus / B <= 1))) {
+        bool ok = N <= PD_LANE_MAX_FRAMES;
+        int pairs = 0, steps = 0;
+        for (int b = 0; b < B && ok; ++b) {
+            const PdSeqDesc &d = eng->seqs[b].desc;
+            ok = d.n_litems > 0 && d.n_pchunks == 1;
+            pairs = std::max(pairs, d.n_pairs);
+            steps = std::max(steps, d.l_max_steps);
+        }
+        if (ok) {
+            const int rv = pd_lane_variants[pd_lane_variant()].rv;
+            const int pinc_rows = 2 * std::min(PD_LANE_MAX_ITEMS, std::max(pairs, 1));
+            const int room = (int)((160 * 1024 - lane_lds_bytes(pinc_rows, 0)) / (PD_LANE_WAVES * 2048));
+            const int rl = std::max(0, std::min(room, steps - rv));
+            if ((cfg->reserved & PD_GGS_CFG_LANE_ITEMS) || steps <= rv + rl) {
+                out->lane = 1;
+                out->lane_rl = rl;
+                out->k = 1;
+                out->waves = PD_LANE_WAVES;
+                out->pinc_rows = pinc_rows;
+                out->lds = (int)lane_lds_bytes(pinc_rows, rl);
+                out->max_items = PD_LANE_MAX_ITEMS;
+                return PD_OK;
+            }
+        }
+    }
     // many frames (several chunks of pairs): the two-hop kernel distributes the backward over the workgroups instead of
     // replicating it -- needs one work item per pair and room for its exchange lines; it keeps only a workgroup's own
     // item sums in LDS, so it also covers item counts whose full table would not fit
@@ -1683,7 +1926,9 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
         const size_t n_zero = 2 * eng->xchg_granules * B;
         hipLaunchKernelGGL(pd_ggs_zero_kernel, dim3(256), dim3(256), 0, s, eng->d_xchg, n_zero);
     }
-    if (two_hop)
+    if (plan.lane)
+        hipLaunchKernelGGL(pd_lane_variants[pd_lane_variant()].fn, dim3(B), dim3(PD_LANE_THREADS), lds, s, P, plan.lane_rl, pinc_rows);
+    else if (two_hop)
         hipLaunchKernelGGL(pd_ggs2_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots);
     else {
         void (*kern)(PdGgsParams, int, int, int, int) =

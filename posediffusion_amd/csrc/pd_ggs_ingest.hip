@@ -39,16 +39,17 @@ struct IngestArgs {
     const double *kp1, *kp2;
     const long long *i12;
     int N, P_cap, I_cap, C_cap, per_pair_cap;
+    int LS_cap;                  // capacity of the lane-major stream in steps per wave (0: no lane-per-item tables for this slice)
     float sc, cx, cy;
     unsigned int *err_flag;
 };
 
 // blob layout, by capacity (so that it is known before the counts are)
 struct IngestLayout {
-    size_t pts, pij, pio, itm, ptb, pco, gps, gio, cnt, keys, hist, total;
+    size_t pts, pij, pio, itm, ptb, pco, gps, gio, lit, lwv, lpt, lst, cnt, keys, hist, total;
 };
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-__host__ __device__ static inline void ingest_layout(int M, int N, int P_cap, int I_cap, int C_cap, IngestLayout &L) {
+__host__ __device__ static inline void ingest_layout(int M, int N, int P_cap, int I_cap, int C_cap, int LS_cap, IngestLayout &L) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t n_tiles = ((size_t)M + ING_TILE - 1) / ING_TILE;
     L.pts = 0;
@@ -59,7 +60,11 @@ __host__ __device__ static inline void ingest_layout(int M, int N, int P_cap, in
     L.pco = al(L.ptb + sizeof(int4) * (size_t)P_cap);
     L.gps = al(L.pco + sizeof(int) * (size_t)C_cap * (N + 1));
     L.gio = al(L.gps + sizeof(int2) * (size_t)P_cap);
-    L.cnt = al(L.gio + sizeof(int) * ((size_t)N + 1));
+    L.lit = al(L.gio + sizeof(int) * ((size_t)N + 1));
+    L.lwv = al(L.lit + sizeof(int4) * (size_t)PD_LANE_MAX_ITEMS);
+    L.lpt = al(L.lwv + sizeof(int2) * (size_t)PD_LANE_WAVES);
+    L.lst = al(L.lpt + sizeof(int2) * (size_t)P_cap);
+    L.cnt = al(L.lst + sizeof(float4) * (size_t)LS_cap * PD_LANE_WAVES * 128);
     L.keys = al(L.cnt + sizeof(int) * ((size_t)N * N + 1));
     L.hist = al(L.keys + sizeof(int) * (size_t)M);
     L.total = al(L.hist + sizeof(int) * n_tiles * (size_t)N * N);
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256) void ingest_hist_kernel(IngestArgs A) {
     const int tile = blockIdx.x;
     if (tile >= S.n_tiles) return;
     IngestLayout L;
-    ingest_layout(S.M, A.N, A.P_cap, A.I_cap, A.C_cap, L);
+    ingest_layout(S.M, A.N, A.P_cap, A.I_cap, A.C_cap, A.LS_cap, L);
     const int NN = A.N * A.N;
     for (int q = threadIdx.x; q < NN; q += 256) sh_hist[q] = 0;
     __syncthreads();
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(ING_TABLE_THREADS) void ingest_tables_kernel(Ingest
     extern __shared__ int sh[];
     const IngestSeq S = A.s[blockIdx.x];
     IngestLayout L;
-    ingest_layout(S.M, A.N, A.P_cap, A.I_cap, A.C_cap, L);
+    ingest_layout(S.M, A.N, A.P_cap, A.I_cap, A.C_cap, A.LS_cap, L);
     const int N = A.N, NN = N * N, tid = threadIdx.x;
     // LDS: totals[NN] | pidx[NN] (pair index of a key, -1 if empty) | pair_ij[P_cap] (i | j << 8) | pos0/pos1[P_cap] (shorts
     // packed in one int) | deg / offsets [C_cap + 1][N + 1] | scan scratch [16] | flags [4]
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(ING_TABLE_THREADS) void ingest_tables_kernel(Ingest
     int *pij = pidx + NN;
     int *ppos = pij + A.P_cap;
     int *foff = ppos + A.P_cap;                     // [(C_cap + 1)][N + 1]
-    int *scratch = foff + (A.C_cap + 1) * (N + 1);
+    int *scratch = foff + (A.C_cap + 1) * (N + 1);   // [16]: 0..8 the block scans, 8..15 the block maximum of (3b)
     int *flags = scratch + 16;
     int *hist = (int *)(S.blob + L.hist);
     int *cnt = (int *)(S.blob + L.cnt);
@@ -243,6 +248,74 @@ __global__ __launch_bounds__(ING_TABLE_THREADS) void ingest_tables_kernel(Ingest
     int *ginc_off = (int *)(S.blob + L.gio);
     for (int q = tid; q <= N; q += ING_TABLE_THREADS) ginc_off[q] = foff[A.C_cap * (N + 1) + q];
     for (int p = tid; p < np; p += ING_TABLE_THREADS) ptab[p].w = ppos[p];
+    // (3b) lane-per-item tables (pd_ggs_lane_kernel), exactly as pd_ggs_set_matches builds them: the smallest item length that leaves at
+    // most PD_LANE_MAX_ITEMS lane items, balanced cuts of every pair, one lane item per thread, per-wave step counts and stream bases
+    int n_litems = 0, n_lwaves = 0, l_len = 0, l_steps = 0;
+    int4 *litems = (int4 *)(S.blob + L.lit);
+    int2 *lwave = (int2 *)(S.blob + L.lwv);
+    int2 *lptab = (int2 *)(S.blob + L.lpt);
+    if (A.LS_cap > 0 && !bad && np <= PD_LANE_MAX_ITEMS && n_pchunks == 1 && N <= PD_LANE_MAX_FRAMES) {   // block-uniform
+        int mx = 1;
+        for (int key = tid; key < NN; key += ING_TABLE_THREADS) mx = max(mx, totals[key]);
+        __syncthreads();
+        scratch[8 + (tid >> 6)] = 0;
+        __syncthreads();
+        atomicMax(&scratch[8 + (tid >> 6)], mx);
+        __syncthreads();
+        int hi = 1;
+        for (int w = 0; w < ING_TABLE_THREADS / 64; ++w) hi = max(hi, scratch[8 + w]);
+        int lo = 1;
+        while (lo < hi) {                                     // block-uniform binary search: every thread takes the same branches
+            const int mid = (lo + hi) / 2;
+            int part = 0, tot;
+            for (int key = tid; key < NN; key += ING_TABLE_THREADS) part += pd_lane_items_of(totals[key], mid);
+            block_scan_incl(part, scratch, tot);
+            __syncthreads();
+            if (tot <= PD_LANE_MAX_ITEMS) hi = mid;
+            else lo = mid + 1;
+        }
+        l_len = lo;
+        int lit_base = 0;
+        for (int k0 = 0; k0 < NN; k0 += ING_TABLE_THREADS) {
+            const int key = k0 + tid;
+            const int m = key < NN ? totals[key] : 0;
+            const int nch = pd_lane_items_of(m, l_len);
+            int t_lit;
+            const int first = block_scan_incl(nch, scratch, t_lit) - nch + lit_base;
+            __syncthreads();
+            if (m > 0) {
+                const int p = pidx[key], i = key / N, j = key - i * N;
+                lptab[p] = make_int2(first, nch);
+                int start = cnt[key];
+                for (int c = 0; c < nch; ++c) {
+                    const int len = m / nch + (c < m % nch ? 1 : 0);
+                    litems[first + c] = make_int4(i | (j << 8), len, p, start);
+                    start += len;
+                }
+            }
+            lit_base += t_lit;
+        }
+        n_litems = lit_base;
+        n_lwaves = (n_litems + 63) / 64;
+        __syncthreads();                                       // litems written by this workgroup are read below
+        if (tid < n_lwaves) {
+            int steps = 0;
+            for (int l = 0; l < 64 && tid * 64 + l < n_litems; ++l) steps = max(steps, (litems[tid * 64 + l].y + 1) / 2);
+            scratch[tid] = steps;
+        }
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < n_lwaves; ++w) {
+            if (tid == 0) lwave[w] = make_int2(base, scratch[w]);
+            base += scratch[w] * 128;
+            l_steps = max(l_steps, scratch[w]);
+        }
+        if (l_steps > A.LS_cap) {                              // cannot happen within the hints; never write past the blob
+            n_litems = 0;
+            n_lwaves = 0;
+        }
+        __syncthreads();
+    }
     // (4) the descriptor (an emptied slot on error: the GGS kernels then find nothing to do)
     if (tid == 0) {
         PdSeqDesc D;
@@ -256,6 +329,14 @@ __global__ __launch_bounds__(ING_TABLE_THREADS) void ingest_tables_kernel(Ingest
         D.gpos = (const int2 *)(S.blob + L.gps);
         D.ginc_off = (const int *)(S.blob + L.gio);
         D.single_item_pairs = flags[1] ? 0 : 1;
+        D.lstream = (const float4 *)(S.blob + L.lst);
+        D.litems = litems;
+        D.lwave = lwave;
+        D.lptab = lptab;
+        D.n_litems = n_litems;
+        D.n_lwaves = n_lwaves;
+        D.l_item_len = l_len;
+        D.l_max_steps = l_steps;
         D.M = bad ? 1 : S.M;                 // (M only scales 1 / M; never 0: the kernels divide by it)
         D.n_pairs = np;
         D.n_items = bad ? 0 : n_items;
@@ -276,7 +357,7 @@ __global__ __launch_bounds__(64) void ingest_scatter_kernel(IngestArgs A) {
     const int tile = blockIdx.x, lane = threadIdx.x;
     if (tile >= S.n_tiles) return;
     IngestLayout L;
-    ingest_layout(S.M, A.N, A.P_cap, A.I_cap, A.C_cap, L);
+    ingest_layout(S.M, A.N, A.P_cap, A.I_cap, A.C_cap, A.LS_cap, L);
     const int NN = A.N * A.N;
     const int *cnt = (const int *)(S.blob + L.cnt);
     const int *hist = (const int *)(S.blob + L.hist) + (size_t)tile * NN;
@@ -309,6 +390,31 @@ __global__ __launch_bounds__(64) void ingest_scatter_kernel(IngestArgs A) {
     }
 }
 
+// ---- kernel 3b: the lane-major stream of pd_ggs_lane_kernel, gathered from the sorted table (before kernel 4 rewrites it) ---------
+// one workgroup per (wave of lane items, sequence); thread (l, r) writes lane l's two halves of steps r, r + 4, ...
+__global__ __launch_bounds__(256) void ingest_lane_stream_kernel(IngestArgs A) {
+    const IngestSeq S = A.s[blockIdx.y];
+    const int w = blockIdx.x, l = threadIdx.x & 63;
+    const int n_litems = S.desc->n_litems;                // actual counts, written by ingest_tables_kernel
+    if (w >= S.desc->n_lwaves) return;
+    IngestLayout L;
+    ingest_layout(S.M, A.N, A.P_cap, A.I_cap, A.C_cap, A.LS_cap, L);
+    const int2 lw = ((const int2 *)(S.blob + L.lwv))[w];
+    const float4 *pts = (const float4 *)(S.blob + L.pts);
+    float4 *st = (float4 *)(S.blob + L.lst) + lw.x;
+    const int q = w * 64 + l;
+    const int4 it = q < n_litems ? ((const int4 *)(S.blob + L.lit))[q] : make_int4(0, 0, 0, 0);
+    for (int t = threadIdx.x >> 6; t < lw.y; t += 4) {
+        float4 q0 = make_float4(1.0f, 1.0f, 1.0f, 1.0f), q1 = q0;
+        if (q < n_litems) {
+            const float4 a = pts[it.w + min(2 * t, it.y - 1)], b = pts[it.w + min(2 * t + 1, it.y - 1)];
+            pd_interleave_pair(a, b, q0, q1);
+        }
+        st[(2 * t) * 64 + l] = q0;
+        st[(2 * t + 1) * 64 + l] = q1;
+    }
+}
+
 // ---- kernel 4: pair-interleave the full 128-match groups of every item (the layout pd_ggs.hip's packed steps read) -----------
 // one wave per work item; a lane rewrites exactly the two elements it read (group[lane], group[64 + lane]): in place, no hazards
 __global__ __launch_bounds__(64) void ingest_interleave_kernel(IngestArgs A) {
@@ -316,7 +422,7 @@ __global__ __launch_bounds__(64) void ingest_interleave_kernel(IngestArgs A) {
     const int item = blockIdx.x, lane = threadIdx.x;
     if (item >= S.desc->n_items) return;               // actual count, written by ingest_tables_kernel
     IngestLayout L;
-    ingest_layout(S.M, A.N, A.P_cap, A.I_cap, A.C_cap, L);
+    ingest_layout(S.M, A.N, A.P_cap, A.I_cap, A.C_cap, A.LS_cap, L);
     const int4 it = ((const int4 *)(S.blob + L.itm))[item];   // (pair, first match, count, 0)
     float4 *pts = (float4 *)(S.blob + L.pts) + it.y;
     for (int g = 0; g + 128 <= it.z; g += 128) {
@@ -396,12 +502,16 @@ extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n
         A.P_cap = P_cap;
         A.I_cap = I_cap;
         A.C_cap = C_cap;
+        // lane-per-item tables: sum_p ceil(m_p / len) <= M / len + P, so the item length never exceeds ceil(M / (items - P))
+        const bool lane_ok = P_cap < PD_LANE_MAX_ITEMS && C_cap == 1 && N <= PD_LANE_MAX_FRAMES;
+        const int len_cap = lane_ok ? (int)((M_max + (PD_LANE_MAX_ITEMS - P_cap) - 1) / (PD_LANE_MAX_ITEMS - P_cap)) : 0;
+        A.LS_cap = lane_ok ? (len_cap + 1) / 2 : 0;
         int max_tiles = 0;
         for (int b = 0; b < nb; ++b) {
             const int slot = seq_first + b0 + b;
             const int M = (int)(seq_offsets[b0 + b + 1] - seq_offsets[b0 + b]);
             IngestLayout L;
-            ingest_layout(M, N, P_cap, I_cap, C_cap, L);
+            ingest_layout(M, N, P_cap, I_cap, C_cap, A.LS_cap, L);
             PdSeqHost &h = eng->seqs[slot];
             if (h.blob_bytes < L.total) {
                 // first use of the slot at this capacity: the only allocation (synchronous).  The old blob may still be read by
@@ -425,6 +535,9 @@ extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n
             h.desc.n_items = I_cap;
             h.desc.n_pchunks = C_cap;
             h.desc.single_item_pairs = single ? 1 : 0;
+            h.desc.n_litems = lane_ok ? PD_LANE_MAX_ITEMS : 0;   // capacities again (the plan only asks whether the tables exist)
+            h.desc.n_lwaves = lane_ok ? PD_LANE_WAVES : 0;
+            h.desc.l_max_steps = A.LS_cap;
             h.desc.n_frames = N;
             h.desc.sc = A.sc;
             h.desc.cx = A.cx;
@@ -436,6 +549,7 @@ extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n
         hipLaunchKernelGGL(ingest_hist_kernel, dim3(max_tiles, nb), dim3(256), lds_hist, s, A);
         hipLaunchKernelGGL(ingest_tables_kernel, dim3(nb), dim3(ING_TABLE_THREADS), lds_tab, s, A);
         hipLaunchKernelGGL(ingest_scatter_kernel, dim3(max_tiles, nb), dim3(64), lds_hist, s, A);
+        if (A.LS_cap > 0) hipLaunchKernelGGL(ingest_lane_stream_kernel, dim3(PD_LANE_WAVES, nb), dim3(256), 0, s, A);
         hipLaunchKernelGGL(ingest_interleave_kernel, dim3(I_cap, nb), dim3(64), 0, s, A);
         PD_HIP_CHECK(hipGetLastError());
     }

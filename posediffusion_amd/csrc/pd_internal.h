@@ -19,6 +19,13 @@
 #define PD_GGS_MAX_STAGES 5
 #define PD_ITEM_MAX_MATCHES 512   // one work item = <= 512 matches of one frame pair (8 per lane)
 #define PD_ITEM_VALS 12           // 9 dL/dF sums + sum(s valid) + n_valid + sum(min(s, max))
+// lane-per-item kernel (pd_ggs_lane_kernel, the throughput shape: one workgroup of 6 waves per sequence with up to 256 VGPRs each -- most
+// of them hold matches for the whole launch --, every LANE owns a work item)
+#define PD_LANE_WAVES 6
+#define PD_LANE_THREADS (PD_LANE_WAVES * PD_WAVE)
+#define PD_LANE_MAX_ITEMS PD_LANE_THREADS   // one lane item per thread
+#define PD_LANE_MAX_FRAMES 48               // 16 threads per frame in the per-frame sums
+#define PD_LANE_ITEM_VALS 10                // 9 dL/dF sums + sum(s valid) per lane item
 
 void pd_set_error(const char *fmt, ...);
 
@@ -46,6 +53,13 @@ struct PdSeqDesc {
     const int2 *gpos;          // [n_pairs] rows of the pair's (side 0, side 1) results among ALL incidences, frame-sorted
     const int *ginc_off;       // [n_frames + 1] CSR of those rows by frame (two-hop kernel for many frames)
     int single_item_pairs;     // 1: every pair is one work item (<= PD_ITEM_MAX_MATCHES matches)
+    // lane-per-item tables (pd_ggs_lane_kernel; n_litems == 0: not built -- more than PD_LANE_MAX_ITEMS pairs or several chunks of pairs)
+    const float4 *lstream;     // lane-major stream: wave w, step t, half h, lane l at [lwave[w].x + (2 t + h) * 64 + l]; half 0 =
+                               //   (u1_A, u1_B, v1_A, v1_B), half 1 = (u2_A, u2_B, v2_A, v2_B) for A, B = matches 2 t, 2 t + 1 of lane l's item
+    const int4 *litems;        // [n_litems] (i | j << 8, match count, pair, first match): lane item q belongs to thread q
+    const int2 *lwave;         // [n_lwaves] (first float4 of the wave's stream, steps = max over its lanes of ceil(count / 2))
+    const int2 *lptab;         // [n_pairs] (first lane item, lane items) of the pair
+    int n_litems, n_lwaves, l_item_len, l_max_steps;
     int M, n_pairs, n_items, n_frames;
     float sc, cx, cy;          // min(h, w) / 2, w / 2, h / 2 (opencv_from_cameras_projection)
     int pad;
@@ -89,7 +103,11 @@ struct PdGgsPlan {
     int k, n_slots, lds, two_hop, max_items;
     int pinc_rows, stage_p;    // one-hop kernel: LDS rows of the pair backward; LDS-DMA staging pieces per item (0 = through registers)
     int waves;                 // one-hop kernel: waves per workgroup (8, or 12 for the staged k = 1 shape)
+    int lane, lane_rl;         // lane-per-item kernel chosen; its LDS-resident steps per wave
 };
+
+// lane items of one frame pair with m matches at lane-item length len: ceil(m / len) items of balanced size (host and device builders)
+__host__ __device__ inline int pd_lane_items_of(int m, int len) { return (m + len - 1) / len; }
 
 struct PdSeqHost {
     void *blob = nullptr;      // one hipMalloc holding every array of the PdSeqDesc
