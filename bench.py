@@ -61,7 +61,7 @@ PD_STREAM_MIN_ROWS = 1024            # csrc/pd_gemm_stream.h
 FP32_PEAK_TFLOPS = 157.3             # MI355X fp32 vector ALU = dense fp32 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 MATCH_BYTES = 16                     # kp1, kp2: 2 x float2 per match (pair indices are per work item)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round2_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round3_pmc_summary.json")
 
 
 # ------------------------------------------------------------------------------------------------------------ inputs
@@ -487,8 +487,8 @@ def main():
     k_eff = wgs or 24
     roofline = {
         "kernel": f"pd_ggs_kernel (one launch = one guided diffusion step = 700 iterations x {EB} sequences, {k_eff} workgroup(s) per sequence)",
-        "bound": "mfma", "bound_detail": "fp32 vector ALU (SURVEY 8d names the arithmetic roofline for the Sampson kernel); its peak "
-                                         "equals the dense fp32 MFMA peak, 157.3 TFLOP/s",
+        "bound": "valu", "bound_detail": "fp32 vector ALU, 157.3 TFLOP/s (SURVEY 8d names the arithmetic roofline for the Sampson kernel; the kernel issues no "
+                                         "MFMA).  What actually binds the one-workgroup-per-sequence launch is the match stream: see `fabric`",
         "achieved": ggs_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ggs_tflops / FP32_PEAK_TFLOPS,
         "algorithmic_flops_per_launch": ggs_flops, "algorithmic_flop_per_match_iteration": FLOP_PER_MATCH_ITER,
         "launch_ms": ggs_ms, "launch_ms_each": ggs_each, "launch_timing": "hipEvents around the launch on its stream (pd_time_kernel), one launch alone on the chip: "
@@ -500,8 +500,12 @@ def main():
         "fabric": {"algorithmic_bytes_per_launch": match_bytes, "achieved_GBps_one_launch": match_bytes / (ggs_ms * 1e-3) / 1e9,
                    "achieved_GBps_co_resident": depth * match_bytes / (ggs_set_ms * 1e-3) / 1e9,
                    "hbm_peak_GBps": HBM_PEAK_GBS, "frac_of_hbm_peak_one_launch": match_bytes / (ggs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                   "why_reported": "with three waves per SIMD the full-chip launch is bandwidth-sensitive: it runs ~5-9 % slower inside the pipe, "
-                                   "where the other contexts' denoiser kernels share the fabric, than alone (DESIGN 3.2, profiles/round2_coresident.txt)",
+                   "measured_ceiling_GBps": [7200, 7700],
+                   "frac_of_measured_ceiling_one_launch": match_bytes / (ggs_ms * 1e-3) / 1e9 / 7450.0,
+                   "why_reported": "THE binding resource of this launch (round 3): every CU re-reading a private 912 KB region gets 7.2-7.7 TB/s chip-wide "
+                                   "(tools/stream_probe.hip, profiles/round3_stream_probe.txt: Infinity-Cache-resident working set, barely above HBM's 6.1-7.1), "
+                                   "and the launch moves exactly the algorithmic bytes at that rate; a kernel with 2.3 x fewer VALU instructions and 28 % of the "
+                                   "matches resident on chip (pd_ggs_lane_kernel) takes the same time (DESIGN 3.2, profiles/round3_lane_kernel_*.txt)",
                    "note": f"{EB * depth} sequences in flight, at most 256 of them (one GGS workgroup per CU) iterating at a time: {min(EB * depth, 256)} x "
                            f"{M * MATCH_BYTES / 1e6:.2f} MB of matches = {min(EB * depth, 256) * M * MATCH_BYTES / 1e6:.0f} MB re-read every iteration at one workgroup "
                            "per sequence (a chosen trade: no replicated serial phase); that set fits the 256 MiB Infinity Cache, so this is fabric / "

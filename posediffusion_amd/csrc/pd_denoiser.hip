@@ -417,6 +417,70 @@ __global__ __launch_bounds__(256) void pd_attn_kernel(const float *__restrict__ 
     }
 }
 
+// The same attention for large batches: ONE workgroup per (sequence, head) stages K, V and all N query rows once (pd_attn_kernel
+// stages K and V ceil(N / 4) times, once per group of four query rows: 5 120 workgroups per layer at the bench shape, 9 - 15 % of the
+// denoiser's kernel time for ~1 % of its FLOPs) and its four waves walk the query rows i = wave, wave + 4, ...  Per row the arithmetic
+// is pd_attn_kernel's, instruction for instruction: the same bits.
+template <bool SPLIT_OUT>
+__global__ __launch_bounds__(256) void pd_attn_seq_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int N) {
+    constexpr int LD = DH + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Kk = lds, *V = Kk + N * LD, *Q = V + N * LD, *P = Q + N * LD;   // P [4][64]
+    const int b = blockIdx.x / NH, h = blockIdx.x % NH, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float scale = 0.08838834764831845f;   // 1/sqrt(128)
+    const float *base = qkv + (size_t)b * N * (3 * DM) + h * DH;
+    for (int idx = tid; idx < N * (DH / 4); idx += 256) {
+        const int j = idx / (DH / 4), d4 = idx % (DH / 4);
+        const float *row = base + (size_t)j * (3 * DM) + d4 * 4;
+        float4 q = *(const float4 *)row;
+        q.x *= scale; q.y *= scale; q.z *= scale; q.w *= scale;
+        *(float4 *)(Q + j * LD + d4 * 4) = q;
+        *(float4 *)(Kk + j * LD + d4 * 4) = *(const float4 *)(row + DM);
+        *(float4 *)(V + j * LD + d4 * 4) = *(const float4 *)(row + 2 * DM);
+    }
+    __syncthreads();
+    const int jj = lane < N ? lane : N - 1;
+    const float4 *kb = (const float4 *)(Kk + jj * LD);
+    for (int i0 = 0; i0 < N; i0 += 4) {          // every wave takes part in every round (the barriers are workgroup-wide)
+        const int i = i0 + wave, ii = i < N ? i : N - 1;
+        const float4 *qa = (const float4 *)(Q + ii * LD);
+        float s = 0.0f;
+#pragma unroll 8
+        for (int d = 0; d < DH / 4; ++d) {
+            const float4 a = qa[d], c = kb[d];
+            s = fmaf(a.x, c.x, s);
+            s = fmaf(a.y, c.y, s);
+            s = fmaf(a.z, c.z, s);
+            s = fmaf(a.w, c.w, s);
+        }
+        const float sv = lane < N ? s : -INFINITY;
+        const float mx = pd_wave_max(sv);
+        const float e = lane < N ? expf(sv - mx) : 0.0f;
+        const float inv = 1.0f / pd_wave_sum(e);
+        P[wave * 64 + lane] = e * inv;
+        __syncthreads();
+        if (i < N) {
+            const float *p = P + wave * 64;
+            float o0 = 0.0f, o1 = 0.0f;
+            for (int j = 0; j < N; ++j) {
+                const float pj = p[j];
+                o0 = fmaf(pj, V[j * LD + lane], o0);
+                o1 = fmaf(pj, V[j * LD + 64 + lane], o1);
+            }
+            float *out = ctx + (size_t)(b * N + i) * DM + h * DH;
+            if constexpr (SPLIT_OUT) {
+                ((unsigned *)out)[lane] = pd_split_word(o0);
+                ((unsigned *)out)[64 + lane] = pd_split_word(o1);
+            } else {
+                out[lane] = o0;
+                out[64 + lane] = o1;
+            }
+        }
+        __syncthreads();                          // P is rewritten by the next round
+    }
+}
+static size_t attn_seq_lds(int N) { return ((size_t)3 * N * (DH + 4) + 4 * 64) * sizeof(float); }
+
 // --------------------------------------------------------------------------------------------
 // tail of the head: LayerNorm(128) -> ReLU -> Linear(128 -> 9) (denoiser.py:51,74 `_last.1..3`)
 // fused with predict_start_from_noise / q_posterior / the sample update
@@ -621,6 +685,9 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(set_lds(pd_gemm_kernel<DM, 0, 0, 16>, 32 * (DM + 4) * 4));
     PD_TRY(set_lds(pd_attn_kernel<false>, ((2 * 64 + 4) * (DH + 4) + 4 * 64) * 4));
     PD_TRY(set_lds(pd_attn_kernel<true>, ((2 * 64 + 4) * (DH + 4) + 4 * 64) * 4));
+    PD_TRY(set_lds(pd_attn_seq_kernel<false>, attn_seq_lds(64)));
+    PD_TRY(set_lds(pd_attn_seq_kernel<true>, attn_seq_lds(64)));
+    PD_TRY(set_lds((pd_gemm_stream_kernel<0, 2, 2, true>), (size_t)2 * 256 * PD_STREAM_LR * sizeof(float)));
     PD_HIP_CHECK(hipDeviceSynchronize());
     return PD_OK;
 }
@@ -713,7 +780,7 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
             // between them as split words -- LayerNorm, attention and the FF1 epilogue write them in place of fp32
             hipLaunchKernelGGL((pd_ln_rows_kernel<DM, true>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f);
             pd_gemm_split<0, 1, 2>((const unsigned *)d->hn, DM, L.qkv_ws, DM, L.qkv_b, d->qkv, M, 3 * DM, s);
-            hipLaunchKernelGGL(pd_attn_kernel<true>, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
+            hipLaunchKernelGGL(pd_attn_seq_kernel<true>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N);
             pd_gemm_split<2, 1, 1>((const unsigned *)d->ctx, DM, L.out_ws, DM, L.out_b, d->h, M, DM, s);
             hipLaunchKernelGGL((pd_ln_rows_kernel<DM, true>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f);
             pd_gemm_split<4, 1, 2>((const unsigned *)d->hn, DM, L.ff1_ws, DM, L.ff1_b, d->ff, M, DFF, s);
@@ -721,10 +788,13 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
             continue;
         }
         if (streamed) {
-            pd_gemm_stream<0, true>(d->h, DM, L.qkv_wf, DM, L.qkv_b, d->qkv, M, 3 * DM, s, 1e-5f);     // LayerNorm-1 in the A staging
-            hipLaunchKernelGGL(pd_attn_kernel<false>, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
+            float2 *stats = (float2 *)d->hn;           // (mean, rstd) per token row; applied in the A staging of the next GEMM
+            hipLaunchKernelGGL(pd_ln_stats_kernel<DM>, dim3((M + 3) / 4), dim3(256), 0, s, d->h, stats, M, 1e-5f);
+            pd_gemm_stream<0, true, 2, 2>(d->h, DM, L.qkv_wf, DM, L.qkv_b, d->qkv, M, 3 * DM, s, stats);       // LayerNorm-1; 128 x 128 tiles
+            hipLaunchKernelGGL(pd_attn_seq_kernel<false>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N);
             pd_gemm_stream<2>(d->ctx, DM, L.out_wf, DM, L.out_b, d->h, M, DM, s);
-            pd_gemm_stream<1, true>(d->h, DM, L.ff1_wf, DM, L.ff1_b, d->ff, M, DFF, s, 1e-5f);         // LayerNorm-2 likewise
+            hipLaunchKernelGGL(pd_ln_stats_kernel<DM>, dim3((M + 3) / 4), dim3(256), 0, s, d->h, stats, M, 1e-5f);
+            pd_gemm_stream<1, true>(d->h, DM, L.ff1_wf, DM, L.ff1_b, d->ff, M, DFF, s, stats);                  // LayerNorm-2 likewise
             pd_gemm_stream<2>(d->ff, DFF, L.ff2_wf, DFF, L.ff2_b, d->h, M, DM, s);
             continue;
         }

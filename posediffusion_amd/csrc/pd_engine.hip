@@ -6,6 +6,8 @@
 //   util/camera_transform.py:64-105      pose_encoding_to_camera (final decode)
 #include "pd_internal.h"
 
+#include <algorithm>
+
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
@@ -69,10 +71,13 @@ extern "C" void pd_engine_destroy(pd_engine *eng) {
     (void)hipSetDevice(eng->device);
     (void)hipDeviceSynchronize();
     for (auto &g : eng->graphs) (void)hipGraphExecDestroy(g.second);
-    if (eng->last_use) (void)hipEventDestroy(eng->last_use);
-    if (eng->upload_done) (void)hipEventDestroy(eng->upload_done);
+    for (auto &e : eng->uses) (void)hipEventDestroy(e.event);
+    for (auto &e : eng->uploads) (void)hipEventDestroy(e.event);
     for (auto &s : eng->seqs) pd_ggs_free_seq(s);
-    for (void *p : eng->retired_blobs) (void)hipFree(p);
+    for (auto &r : eng->retired_blobs) {
+        (void)hipFree(r.ptr);
+        (void)hipEventDestroy(r.done);
+    }
     pd_denoiser_destroy(eng);
     void *ptrs[] = {eng->d_seqs, eng->d_xchg, eng->d_err, eng->d_z, eng->d_noise, eng->d_process, eng->d_mean, eng->d_stats};
     for (void *p : ptrs)
@@ -340,11 +345,16 @@ extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *nois
             }
         }
         hipGraphExec_t exec = nullptr;
-        for (auto &g : eng->graphs)
+        for (size_t gi = 0; gi < eng->graphs.size(); ++gi) {
+            auto &g = eng->graphs[gi];
             if (g.first.B == B && g.first.N == N && g.first.cond_start == key.cond_start && g.first.has_ggs == key.has_ggs &&
                 g.first.phase == phase && g.first.den_split == key.den_split && same_cfg(g.first.cfg, key.cfg) &&
-                memcmp(&g.first.plan, &key.plan, sizeof(PdGgsPlan)) == 0)
+                memcmp(&g.first.plan, &key.plan, sizeof(PdGgsPlan)) == 0) {
                 exec = g.second;
+                std::rotate(eng->graphs.begin() + gi, eng->graphs.begin() + gi + 1, eng->graphs.end());   // most recently used last
+                break;
+            }
+        }
         if (!exec) {
             // capture on a private stream so the caller's stream state is untouched
             if (!eng->own_stream) PD_HIP_CHECK(hipStreamCreateWithFlags(&eng->own_stream, hipStreamNonBlocking));
@@ -359,6 +369,13 @@ extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *nois
             PD_HIP_CHECK(ce);
             PD_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             PD_HIP_CHECK(hipGraphDestroy(graph));
+            // bounded cache: a service whose match sets keep changing the launch plan must not pile up instantiated graphs.  The
+            // least recently used one goes; it may still be replaying on some stream, so this engine's work is drained first (rare)
+            if (eng->graphs.size() >= PD_GRAPH_CACHE_MAX) {
+                PD_HIP_CHECK(hipDeviceSynchronize());
+                (void)hipGraphExecDestroy(eng->graphs.front().second);
+                eng->graphs.erase(eng->graphs.begin());
+            }
             eng->graphs.push_back({key, exec});
         }
         PD_HIP_CHECK(hipGraphLaunch(exec, s));

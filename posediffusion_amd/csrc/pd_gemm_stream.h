@@ -57,6 +57,35 @@ __global__ __launch_bounds__(256) void pd_ln_rows_kernel(const float *__restrict
             xn[(size_t)row * D + lane + 64 * i] = o;
     }
 }
+// LayerNorm statistics only: x [M, D] -> stats [M] = (mean, 1 / sqrt(var + eps)), two-pass in registers, one wave per row.  The streamed
+// GEMM applies them while it stages its A rows (ALN): no normalised copy of the activations, and -- unlike a pre-pass inside the GEMM,
+// which every column tile of a row block repeats (24 x for the 1 536-wide QKV: measured 18 - 20 % of the GEMM at 5 120 rows,
+// profiles/round3_gemm_probe.txt) -- the rows are read once.
+template <int D>
+__global__ __launch_bounds__(256) void pd_ln_stats_kernel(const float *__restrict__ x, float2 *__restrict__ stats, int M, float eps) {
+    constexpr int PER = D / 64;
+    static_assert(D % 256 == 0, "one wave per row, float4 per lane");
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float4 *src = (const float4 *)(x + (size_t)row * D) + lane;
+    float4 v[PER / 4];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PER / 4; ++i) {
+        v[i] = src[64 * i];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s * (1.0f / D);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PER / 4; ++i)
+        q += ((v[i].x - mean) * (v[i].x - mean) + (v[i].y - mean) * (v[i].y - mean)) + ((v[i].z - mean) * (v[i].z - mean) + (v[i].w - mean) * (v[i].w - mean));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    if (lane == 0) stats[row] = make_float2(mean, 1.0f / sqrtf(q * (1.0f / D) + eps));
+}
 // W[n][k] * gamma[k] -> Wf (row-major copy with the LayerNorm scale folded in)
 static __global__ void pd_scale_cols_kernel(const float *__restrict__ W, const float *__restrict__ gamma, int K, size_t total, float *__restrict__ Wf) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
@@ -71,18 +100,15 @@ struct PdStreamArgs {
     const float *A, *W, *bias;
     float *C;
     int M, Nout, K, lda, ldw;
-    float ln_eps;          // ALN only
+    const float2 *ln_stats;   // ALN only: (mean, rstd) of every A row (pd_ln_stats_kernel)
 };
 #define PD_STREAM_KC 32
 #define PD_STREAM_LR (PD_STREAM_KC + 4)      // LDS row stride: fragment reads and staging writes both conflict free
 // staging registers are named scalars (arrays of float4 held across the K loop end up in scratch)
 #define VS_EACH(X) X(0) X(1) X(2) X(3)
 
-// ALN: A' = LayerNorm(A) without affine (gamma / beta folded into W / bias), K = the normalised width.  Every thread stages the
-// same two rows (sr, sr + 32) in every chunk, 8 threads per row: a two-pass pre-pass over those rows (L2 reads; mean, then
-// variance, summed over the row's 8 threads on the DPP network) leaves mean / rstd in registers and the staging stores apply
-// them -- no separate LayerNorm launch and no normalised copy of the activations in memory.  Every column tile repeats the
-// pre-pass of its rows (24 x for the 1536-wide QKV): ~1 us of L2 reads per workgroup against ~6 us of launch it replaces.
+// ALN: A' = LayerNorm(A) without affine (gamma / beta folded into W / bias): every thread stages the same PA rows in every chunk, so it
+// loads their (mean, rstd) from g.ln_stats once and the staging stores apply them -- no normalised copy of the activations in memory.
 template <int EPI, int WM, int WN, bool ALN = false>
 __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
     constexpr int KC = PD_STREAM_KC, LR = PD_STREAM_LR, TM = 64 * WM, TN = 64 * WN, PA = 2 * WM, PW = 2 * WN, GROUP = 2048 / TM;
@@ -128,27 +154,11 @@ __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
     VS_EACH(VS_DECL)
     float ln_mu[PA], ln_rs[PA];
     if constexpr (ALN) {
-        static_assert(!ALN || PA == 2, "LayerNorm pre-pass is written for 64-row tiles");
-        const float inv_k = 1.0f / (float)g.K;
-        const int n4 = g.K / 32;                      // float4 per thread and row (8 threads per row)
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
-            const float4 *row = (j == 0 ? ap0 : ap1);    // + sc already applied; stride 8 float4 between this thread's pieces
-            float s_ = 0.0f;
-            for (int i = 0; i < n4; i += 4) {
-                const float4 a = row[8 * i], b = row[8 * (i + 1)], c = row[8 * (i + 2)], d = row[8 * (i + 3)];
-                s_ += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w));
-            }
-            const float mu = pd_stream_sum8(s_) * inv_k;
-            float q_ = 0.0f;
-            for (int i = 0; i < n4; i += 4) {
-                const float4 a = row[8 * i], b = row[8 * (i + 1)], c = row[8 * (i + 2)], d = row[8 * (i + 3)];
-#define PD_SQ4(v) (((v.x - mu) * (v.x - mu) + (v.y - mu) * (v.y - mu)) + ((v.z - mu) * (v.z - mu) + (v.w - mu) * (v.w - mu)))
-                q_ += (PD_SQ4(a) + PD_SQ4(b)) + (PD_SQ4(c) + PD_SQ4(d));
-#undef PD_SQ4
-            }
-            ln_mu[j] = mu;
-            ln_rs[j] = 1.0f / sqrtf(pd_stream_sum8(q_) * inv_k + g.ln_eps);
+            const float2 st2 = g.ln_stats[min(m0 + sr + 32 * j, g.M - 1)];
+            ln_mu[j] = st2.x;
+            ln_rs[j] = st2.y;
         }
     }
     {
@@ -224,13 +234,14 @@ __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
 
 
 #define PD_STREAM_MIN_ROWS 1024
-// 64 x 64 tiles: 128 x 64 and 128 x 128 (WM / WN = 2) measured no faster at 31 520 rows and slower at 3 940
-// (profiles/round1_j_vit_notes.md); 64 x 128 (WN = 2) for the 1 536- / 1 024-wide denoiser GEMMs at 5 120 rows: the same bits and the
-// same time (2.37 ms per step alone, 5.72 ms for three contexts, round 2) -- so only <EPI, 1, 1> is instantiated
-template <int EPI, bool ALN = false>
+// Tile shapes, every one alone at 5 120 / 15 360 rows (profiles/round3_gemm_probe.txt, TFLOP/s): 64 x 64 is the best or equal for the
+// 512- and 1 024-wide outputs (84 - 88 at 5 120 rows, 128-row / 128-column tiles 66 - 75 there: too few workgroups); the 1 536-wide QKV
+// runs 88 -> 97 on 128 x 128 tiles (480 workgroups of four 64 x 64 quadrants: half the LDS traffic per FLOP); at 15 360 rows the large
+// tiles lead everywhere by 2 - 10 %.  The image feature extractor measured 64 x 64 best in round 1 (profiles/round1_j_vit_notes.md).
+template <int EPI, bool ALN = false, int WM = 1, int WN = 1>
 static inline void pd_gemm_stream(const float *A, int lda, const float *W, int K, const float *bias, float *C, int M, int Nout, hipStream_t s,
-                                  float ln_eps = 0.0f) {
-    PdStreamArgs g{A, W, bias, C, M, Nout, K, lda, K, ln_eps};
-    const size_t lds = (size_t)2 * 128 * PD_STREAM_LR * sizeof(float);
-    hipLaunchKernelGGL((pd_gemm_stream_kernel<EPI, 1, 1, ALN>), dim3(((M + 63) / 64) * (Nout / 64)), dim3(256), lds, s, g);
+                                  const float2 *ln_stats = nullptr) {
+    PdStreamArgs g{A, W, bias, C, M, Nout, K, lda, K, ln_stats};
+    const size_t lds = (size_t)2 * (64 * WM + 64 * WN) * PD_STREAM_LR * sizeof(float);
+    hipLaunchKernelGGL((pd_gemm_stream_kernel<EPI, WM, WN, ALN>), dim3(((M + 64 * WM - 1) / (64 * WM)) * (Nout / (64 * WN))), dim3(256), lds, s, g);
 }

@@ -1459,13 +1459,34 @@ void pd_ggs_free_seq(PdSeqHost &h) {
     memset(&h.desc, 0, sizeof(h.desc));
 }
 
+// (re)record the event a list keeps for stream `s`
+int pd_record_stream_event(std::vector<pd_engine::StreamEvent> &list, hipStream_t s) {
+    for (auto &e : list)
+        if (e.stream == s) {
+            PD_HIP_CHECK(hipEventRecord(e.event, s));
+            return PD_OK;
+        }
+    hipEvent_t ev = nullptr;
+    PD_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    list.push_back({s, ev});
+    PD_HIP_CHECK(hipEventRecord(ev, s));
+    return PD_OK;
+}
+
 // remember the point on `s` after which this engine's match tables are no longer read
 int pd_mark_use(pd_engine *eng, hipStream_t s) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
         return PD_OK;   // inside a graph capture: pd_sample_phase marks the replay instead
-    if (!eng->last_use) PD_HIP_CHECK(hipEventCreateWithFlags(&eng->last_use, hipEventDisableTiming));
-    PD_HIP_CHECK(hipEventRecord(eng->last_use, s));
+    return pd_record_stream_event(eng->uses, s);
+}
+
+// every enqueue that reads the match tables, on whatever stream it ran: waited for on the device (stream s) or on the host
+int pd_wait_uses(pd_engine *eng, hipStream_t s, bool host) {
+    for (auto &e : eng->uses) {
+        if (host) PD_HIP_CHECK(hipEventSynchronize(e.event));
+        else if (e.stream != s) PD_HIP_CHECK(hipStreamWaitEvent(s, e.event, 0));
+    }
     return PD_OK;
 }
 
@@ -1476,10 +1497,11 @@ static int upload_seq_desc(pd_engine *eng, int seq) {
 }
 
 int pd_wait_uploads(pd_engine *eng, hipStream_t s) {
-    if (!eng->upload_done) return PD_OK;
+    if (eng->uploads.empty()) return PD_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return PD_OK;   // pd_sample_phase waits before the replay
-    PD_HIP_CHECK(hipStreamWaitEvent(s, eng->upload_done, 0));
+    for (auto &e : eng->uploads)
+        if (e.stream != s) PD_HIP_CHECK(hipStreamWaitEvent(s, e.event, 0));      // (same stream: already ordered)
     return PD_OK;
 }
 
@@ -1492,8 +1514,11 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     PD_HIP_CHECK(hipSetDevice(eng->device));
     // nothing of THIS engine in flight may still read the old tables; other engines (other batches of a pipeline) keep
     // running: no device-wide synchronisation here, and the blob is re-used when the new tables fit
-    if (eng->last_use) PD_HIP_CHECK(hipEventSynchronize(eng->last_use));
-    if (eng->upload_done) PD_HIP_CHECK(hipEventSynchronize(eng->upload_done));   // a pending device-side build of this slot
+    {
+        int rc = pd_wait_uses(eng, nullptr, true);
+        if (rc) return rc;
+    }
+    for (auto &e : eng->uploads) PD_HIP_CHECK(hipEventSynchronize(e.event));   // a pending device-side build of this slot
     eng->seqs[seq].device_built = false;
     if (M == 0) {
         pd_ggs_free_seq(eng->seqs[seq]);

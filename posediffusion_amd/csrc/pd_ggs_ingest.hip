@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <string.h>
+#include <vector>
 
 #define ING_TILE 1024
 #define ING_MAX_SEQS 32          // sequences per launch (kernel-argument table); larger batches go in slices
@@ -85,11 +86,13 @@ __global__ __launch_bounds__(256) void ingest_hist_kernel(IngestArgs A) {
     const int m0 = tile * ING_TILE, m1 = min(S.M, m0 + ING_TILE);
     for (int m = m0 + threadIdx.x; m < m1; m += 256) {
         const long long a = A.i12[2 * (S.first + m)], c = A.i12[2 * (S.first + m) + 1];
-        int key = 0;
-        if (a < 0 || a >= A.N || c < 0 || c >= A.N) atomicOr(A.err_flag, 2u);   // frame index out of range
+        // a frame index out of range: error bit 1, and the match is left out of every count -- the totals then fall short of M, which
+        // ingest_tables_kernel treats like a violated hint: the slot is emptied (the synchronous path rejects such an upload outright)
+        int key = -1;
+        if (a < 0 || a >= A.N || c < 0 || c >= A.N) atomicOr(A.err_flag, 2u);
         else key = (int)(a * A.N + c);                                           // geometry_guided_sampling.py:26-27
         keys[m] = key;
-        atomicAdd(&sh_hist[key], 1);
+        if (key >= 0) atomicAdd(&sh_hist[key], 1);
     }
     __syncthreads();
     int *hist = (int *)(S.blob + L.hist) + (size_t)tile * NN;
@@ -368,8 +371,8 @@ __global__ __launch_bounds__(64) void ingest_scatter_kernel(IngestArgs A) {
     const int m0 = tile * ING_TILE, m1 = min(S.M, m0 + ING_TILE);
     for (int r0 = m0; r0 < m1; r0 += 64) {
         const int m = r0 + lane;
-        const bool act = m < m1;
-        const int key = act ? keys[m] : -1;
+        const int key = m < m1 ? keys[m] : -1;
+        const bool act = key >= 0;                        // (an out-of-range match has no row: the slot is emptied anyway)
         int dst = -1;
         unsigned long long todo = __builtin_amdgcn_ballot_w64(act);
         while (todo) {                                 // one pass per distinct key of the round (1-2 for pair-grouped input)
@@ -459,10 +462,79 @@ extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n
         pd_set_error("pd_ggs_set_matches_csr_async: negative hint");
         return PD_ERR_INVALID_ARG;
     }
-    // the engine's own in-flight work may still read the slots' tables: a DEVICE-side wait, the host does not block
-    if (eng->last_use) PD_HIP_CHECK(hipStreamWaitEvent(s, eng->last_use, 0));
+    // pass 1: validate every slice and size its capacities -- nothing is enqueued before the whole call is known to be launchable
+    struct Slice {
+        int nb, P_cap, I_cap, C_cap, LS_cap;
+        bool single;
+        size_t lds_tab;
+    };
+    std::vector<Slice> slices;
     for (int b0 = 0; b0 < n_seqs; b0 += ING_MAX_SEQS) {
-        const int nb = std::min(ING_MAX_SEQS, n_seqs - b0);
+        Slice sl;
+        sl.nb = std::min(ING_MAX_SEQS, n_seqs - b0);
+        // one capacity set for the whole slice (the kernels index the layout by it): from the largest sequence
+        long long M_max = 0;
+        for (int b = 0; b < sl.nb; ++b) {
+            const long long M = seq_offsets[b0 + b + 1] - seq_offsets[b0 + b];
+            if (M <= 0 || M > 0x7fffffff) {
+                pd_set_error("pd_ggs_set_matches_csr_async: sequence %d holds %lld matches (need 1 .. 2^31-1; clear a slot with "
+                             "pd_ggs_set_matches(M = 0))", seq_first + b0 + b, M);
+                return PD_ERR_INVALID_ARG;
+            }
+            M_max = std::max(M_max, M);
+        }
+        sl.P_cap = hint_pairs > 0 ? hint_pairs : (int)std::min<long long>((long long)N * N, M_max);
+        sl.single = hint_per_pair > 0 && hint_per_pair <= PD_ITEM_MAX_MATCHES;
+        sl.I_cap = sl.single ? sl.P_cap : sl.P_cap + (int)(M_max / PD_ITEM_MAX_MATCHES) + 1;
+        sl.C_cap = (sl.P_cap + PD_GGS_THREADS - 1) / PD_GGS_THREADS;
+        if (sl.C_cap > PD_GGS_MAX_PCHUNKS) {
+            pd_set_error("pd_ggs_set_matches_csr_async: up to %d frame pairs (max %d): pass pd_match_hints.max_pairs", sl.P_cap,
+                         PD_GGS_MAX_PCHUNKS * PD_GGS_THREADS);
+            return PD_ERR_UNSUPPORTED;
+        }
+        sl.lds_tab = tables_lds_bytes(N, sl.P_cap, sl.C_cap);
+        if (sl.lds_tab > 160 * 1024) {
+            pd_set_error("pd_ggs_set_matches_csr_async: tables need %zu B of LDS", sl.lds_tab);
+            return PD_ERR_UNSUPPORTED;
+        }
+        // lane-per-item tables: sum_p ceil(m_p / len) <= M / len + P, so the item length never exceeds ceil(M / (items - P))
+        const bool lane_ok = sl.P_cap < PD_LANE_MAX_ITEMS && sl.C_cap == 1 && N <= PD_LANE_MAX_FRAMES;
+        const int len_cap = lane_ok ? (int)((M_max + (PD_LANE_MAX_ITEMS - sl.P_cap) - 1) / (PD_LANE_MAX_ITEMS - sl.P_cap)) : 0;
+        sl.LS_cap = lane_ok ? (len_cap + 1) / 2 : 0;
+        slices.push_back(sl);
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    // the engine's own in-flight work (on whatever streams) may still read the slots' tables: a DEVICE-side wait, the host does not
+    // block; and earlier uploads on other streams are ordered before this one, so the event recorded at the end covers them too
+    if (!capturing) {
+        int rc = pd_wait_uses(eng, s, false);
+        if (rc) return rc;
+        for (auto &e : eng->uploads)
+            if (e.stream != s) PD_HIP_CHECK(hipStreamWaitEvent(s, e.event, 0));
+    }
+    // outgrown blobs whose last readers have finished
+    for (size_t i = 0; i < eng->retired_blobs.size();) {
+        if (hipEventQuery(eng->retired_blobs[i].done) == hipSuccess) {
+            (void)hipFree(eng->retired_blobs[i].ptr);
+            (void)hipEventDestroy(eng->retired_blobs[i].done);
+            eng->retired_blobs[i] = eng->retired_blobs.back();
+            eng->retired_blobs.pop_back();
+        } else {
+            ++i;
+        }
+    }
+    bool enqueued = false;
+    // every exit after the first enqueue records the upload event: later GGS launches on OTHER streams wait for it (pd_sample_phase /
+    // pd_ggs_launch), on the device
+    auto finish = [&](int rc) {
+        if (enqueued && !capturing && pd_record_stream_event(eng->uploads, s) != PD_OK && rc == PD_OK) return (int)PD_ERR_HIP;
+        return rc;
+    };
+    int b0 = 0;
+    for (const Slice &sl : slices) {
+        const int nb = sl.nb, P_cap = sl.P_cap, I_cap = sl.I_cap, C_cap = sl.C_cap;
+        const bool single = sl.single, lane_ok = sl.LS_cap > 0;
         IngestArgs A;
         memset(&A, 0, sizeof(A));
         A.kp1 = kp1;
@@ -474,38 +546,10 @@ extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n
         A.cx = (float)width / 2.0f;
         A.cy = (float)height / 2.0f;
         A.err_flag = eng->d_err;
-        // one capacity set for the whole slice (the kernels index the layout by it): from the largest sequence
-        long long M_max = 0;
-        for (int b = 0; b < nb; ++b) {
-            const long long M = seq_offsets[b0 + b + 1] - seq_offsets[b0 + b];
-            if (M <= 0 || M > 0x7fffffff) {
-                pd_set_error("pd_ggs_set_matches_csr_async: sequence %d holds %lld matches (need 1 .. 2^31-1; clear a slot with "
-                             "pd_ggs_set_matches(M = 0))", seq_first + b0 + b, M);
-                return PD_ERR_INVALID_ARG;
-            }
-            M_max = std::max(M_max, M);
-        }
-        const int P_cap = hint_pairs > 0 ? hint_pairs : (int)std::min<long long>((long long)N * N, M_max);
-        const bool single = hint_per_pair > 0 && hint_per_pair <= PD_ITEM_MAX_MATCHES;
-        const int I_cap = single ? P_cap : P_cap + (int)(M_max / PD_ITEM_MAX_MATCHES) + 1;
-        const int C_cap = (P_cap + PD_GGS_THREADS - 1) / PD_GGS_THREADS;
-        if (C_cap > PD_GGS_MAX_PCHUNKS) {
-            pd_set_error("pd_ggs_set_matches_csr_async: up to %d frame pairs (max %d): pass pd_match_hints.max_pairs", P_cap,
-                         PD_GGS_MAX_PCHUNKS * PD_GGS_THREADS);
-            return PD_ERR_UNSUPPORTED;
-        }
-        const size_t lds_tab = tables_lds_bytes(N, P_cap, C_cap);
-        if (lds_tab > 160 * 1024) {
-            pd_set_error("pd_ggs_set_matches_csr_async: tables need %zu B of LDS", lds_tab);
-            return PD_ERR_UNSUPPORTED;
-        }
         A.P_cap = P_cap;
         A.I_cap = I_cap;
         A.C_cap = C_cap;
-        // lane-per-item tables: sum_p ceil(m_p / len) <= M / len + P, so the item length never exceeds ceil(M / (items - P))
-        const bool lane_ok = P_cap < PD_LANE_MAX_ITEMS && C_cap == 1 && N <= PD_LANE_MAX_FRAMES;
-        const int len_cap = lane_ok ? (int)((M_max + (PD_LANE_MAX_ITEMS - P_cap) - 1) / (PD_LANE_MAX_ITEMS - P_cap)) : 0;
-        A.LS_cap = lane_ok ? (len_cap + 1) / 2 : 0;
+        A.LS_cap = sl.LS_cap;
         int max_tiles = 0;
         for (int b = 0; b < nb; ++b) {
             const int slot = seq_first + b0 + b;
@@ -514,12 +558,24 @@ extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n
             ingest_layout(M, N, P_cap, I_cap, C_cap, A.LS_cap, L);
             PdSeqHost &h = eng->seqs[slot];
             if (h.blob_bytes < L.total) {
-                // first use of the slot at this capacity: the only allocation (synchronous).  The old blob may still be read by
-                // work in flight, so it is parked until the engine is destroyed rather than freed here.
-                if (h.blob) eng->retired_blobs.push_back(h.blob);
+                // first use of the slot at this capacity: the only allocation (synchronous).  The old blob may still be read by work
+                // in flight: it is parked behind an event on this stream (which has just waited for every use) and freed by a later upload
+                if (h.blob) {
+                    hipEvent_t ev = nullptr;
+                    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, s) != hipSuccess) {
+                        pd_set_error("pd_ggs_set_matches_csr_async: cannot park the outgrown blob of slot %d", slot);
+                        return finish(PD_ERR_HIP);
+                    }
+                    eng->retired_blobs.push_back({h.blob, ev});
+                }
                 h.blob = nullptr;
                 h.blob_bytes = 0;
-                PD_HIP_CHECK(hipMalloc(&h.blob, L.total + L.total / 4));   // headroom for ragged batches
+                if (hipMalloc(&h.blob, L.total + L.total / 4) != hipSuccess) {   // headroom for ragged batches
+                    h.blob = nullptr;
+                    memset(&h.desc, 0, sizeof(h.desc));
+                    pd_set_error("pd_ggs_set_matches_csr_async: out of device memory for slot %d (%zu B)", slot, L.total + L.total / 4);
+                    return finish(PD_ERR_HIP);
+                }
                 h.blob_bytes = L.total + L.total / 4;
             }
             A.s[b].first = seq_offsets[b0 + b];
@@ -547,17 +603,18 @@ extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n
         }
         const size_t lds_hist = sizeof(int) * (size_t)N * N;
         hipLaunchKernelGGL(ingest_hist_kernel, dim3(max_tiles, nb), dim3(256), lds_hist, s, A);
-        hipLaunchKernelGGL(ingest_tables_kernel, dim3(nb), dim3(ING_TABLE_THREADS), lds_tab, s, A);
+        enqueued = true;
+        hipLaunchKernelGGL(ingest_tables_kernel, dim3(nb), dim3(ING_TABLE_THREADS), sl.lds_tab, s, A);
         hipLaunchKernelGGL(ingest_scatter_kernel, dim3(max_tiles, nb), dim3(64), lds_hist, s, A);
         if (A.LS_cap > 0) hipLaunchKernelGGL(ingest_lane_stream_kernel, dim3(PD_LANE_WAVES, nb), dim3(256), 0, s, A);
         hipLaunchKernelGGL(ingest_interleave_kernel, dim3(I_cap, nb), dim3(64), 0, s, A);
-        PD_HIP_CHECK(hipGetLastError());
+        if (hipGetLastError() != hipSuccess) {
+            pd_set_error("pd_ggs_set_matches_csr_async: a table kernel failed to launch");
+            return finish(PD_ERR_HIP);
+        }
+        b0 += nb;
     }
-    // later GGS launches on OTHER streams wait for this point (pd_sample_phase / pd_ggs_launch), again on the device
-    if (!eng->upload_done) PD_HIP_CHECK(hipEventCreateWithFlags(&eng->upload_done, hipEventDisableTiming));
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone) PD_HIP_CHECK(hipEventRecord(eng->upload_done, s));
-    return PD_OK;
+    return finish(PD_OK);
 }
 
 int pd_ggs_ingest_init() {

@@ -147,13 +147,23 @@ struct pd_engine {
         pd_ggs_cfg cfg;
         PdGgsPlan plan;            // match-derived launch shape baked into the captured GGS nodes
     };
-    std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
+    std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;   // most recently used last; at most PD_GRAPH_CACHE_MAX entries (LRU eviction)
     hipStream_t own_stream = nullptr;
-    // recorded after every enqueue that reads the match tables: pd_ggs_set_matches waits for THIS engine's work only
-    hipEvent_t last_use = nullptr;
-    // recorded after the ingestion kernels of pd_ggs_set_matches_csr_async: GGS launches on other streams wait for it (device side)
-    hipEvent_t upload_done = nullptr;
-    std::vector<void *> retired_blobs;   // outgrown slot blobs that in-flight work may still read; freed with the engine
+    // One event PER STREAM (an engine may be driven from several): `uses` are recorded after every enqueue that reads the match tables
+    // (uploads wait for all of them: this engine's work only), `uploads` after the ingestion kernels of pd_ggs_set_matches_csr_async
+    // (GGS launches on any stream wait for all of them, on the device).  A single re-recorded event would only remember the last stream.
+    struct StreamEvent {
+        hipStream_t stream;
+        hipEvent_t event;
+    };
+    std::vector<StreamEvent> uses, uploads;
+    // outgrown slot blobs that work in flight at retirement time may still read: freed once `done` (recorded on the retiring upload's
+    // stream after it waited for every use) has completed -- checked at the next upload, and at the latest with the engine
+    struct RetiredBlob {
+        void *ptr;
+        hipEvent_t done;
+    };
+    std::vector<RetiredBlob> retired_blobs;
 };
 
 // pd_denoiser.hip
@@ -174,3 +184,6 @@ void pd_ggs_free_seq(PdSeqHost &h);
 int pd_ggs_ingest_init();   // pd_ggs_ingest.hip
 int pd_wait_uploads(pd_engine *eng, hipStream_t s);   // device-side wait for pending asynchronous match uploads (no-op in a capture)
 int pd_mark_use(pd_engine *eng, hipStream_t s);
+int pd_record_stream_event(std::vector<pd_engine::StreamEvent> &list, hipStream_t s);   // (re)record this stream's event of the list
+int pd_wait_uses(pd_engine *eng, hipStream_t s, bool host);   // wait (device side on s, or on the host) for every recorded use
+#define PD_GRAPH_CACHE_MAX 8

@@ -61,8 +61,19 @@ class GaussianDiffusion(nn.Module):
     def p_sample_loop(self, shape, z, cond_fn=None, cond_start_step=0):
         B, N, _ = shape
         device = self.betas.device
-        eng = host.get_engine(self.model, self, B, N)
         parsed = host.parse_ggs_cond_fn(cond_fn) if cond_fn is not None else None
+        # demo.py:79-92: hloc returning no matches (kp1 is None) means sampling without GGS
+        has_ggs = False
+        if parsed is not None and cond_start_step > 0:
+            mds = parsed[0] if isinstance(parsed[0], (list, tuple)) else [parsed[0]]
+            have = [host.has_matches(m) for m in mds]
+            if any(have) and not all(have):
+                # guidance (and with it the noise schedule, gaussian_diffuser.py:270-278) is a property of the whole call: silently
+                # dropping it for every sequence because one has no matches would change the results of the others
+                raise ValueError(f"sequences {[b for b, h in enumerate(have) if not h]} of the batch have no matches: sample them in a call "
+                                 "without cond_fn (demo.py:79-92) and the others with it")
+            has_ggs = all(have)
+        eng = host.get_engine(self.model, self, B, N)
         if cond_fn is not None and parsed is None:
             # unknown guidance callable: reference control flow in Python, arithmetic on the HIP kernels
             pose = torch.randn(shape, device=device)
@@ -71,9 +82,6 @@ class GaussianDiffusion(nn.Module):
                 pose, _ = self.p_sample(pose, t, z, cond_fn=cond_fn, cond_start_step=cond_start_step)
                 process.append(pose.unsqueeze(0))
             return pose, torch.cat(process)
-        # demo.py:79-92: hloc returning no matches (kp1 is None) means sampling without GGS
-        has_ggs = parsed is not None and cond_start_step > 0 and \
-            all(host.has_matches(m) for m in (parsed[0] if isinstance(parsed[0], (list, tuple)) else [parsed[0]]))
         noise = host.draw_noise(tuple(shape), self.num_timesteps, device, cond_start_step, has_ggs)
         cfg = None
         if has_ggs:
@@ -85,7 +93,7 @@ class GaussianDiffusion(nn.Module):
             # the GGS workgroups of a sequence exchange sums through bounded spins; one that gave up (co-residency lost
             # to another process) raises here instead of returning garbage poses, and the flag is cleared for the next call
             eng.check_async()
-        if stats is not None and os.environ.get("PD_GGS_VERBOSE"):
+        if stats is not None and os.environ.get("PD_GGS_VERBOSE", "0") not in ("", "0"):
             st = stats.cpu()
             for k in range(st.shape[0]):
                 for s in range(5):

@@ -106,10 +106,16 @@ def current_engine(device) -> PoseEngine:
 
 
 def _match_fingerprint(md):
-    """Cheap content fingerprint of a matches_dict (shape + three sums): catches in-place edits of arrays the cache
-    still holds a reference to; identity alone is not enough (CPython recycles ids, arrays can be rewritten)."""
+    """Cheap content fingerprint of a matches_dict (shape, three sums and an order-sensitive hash of a strided sample):
+    catches in-place edits of arrays the cache still holds a reference to -- row permutations included, which keep the
+    sums; identity alone is not enough (CPython recycles ids, arrays can be rewritten)."""
+    import zlib
+    import numpy as np
     kp1, kp2, i12 = md["kp1"], md["kp2"], md["i12"]
-    return (tuple(kp1.shape), float(kp1.sum()), float(kp2.sum()), int(i12.sum()), tuple(int(v) for v in md["img_shape"]))
+    step = max(1, len(kp1) // 256)
+    sample = zlib.crc32(np.ascontiguousarray(kp1[::step]).tobytes()) ^ zlib.crc32(np.ascontiguousarray(kp2[::step]).tobytes()) * 3 ^ \
+        zlib.crc32(np.ascontiguousarray(i12[::step]).tobytes()) * 5
+    return (tuple(kp1.shape), float(kp1.sum()), float(kp2.sum()), int(i12.sum()), int(sample), tuple(int(v) for v in md["img_shape"]))
 
 
 def has_matches(md) -> bool:

@@ -93,6 +93,9 @@ def strong_schedule(n_steps: int, step_seqs: int, world: int, rank: int, engine_
     b_step = g1 - g0
     if b_step <= 0:
         return g0, g1, 1, []
+    if b_step > engine_batch:
+        raise ValueError(f"rank {rank} holds {b_step} sequences of every step, more than one engine pass takes ({engine_batch}): "
+                         "raise the engine batch or use more ranks")
     group = steps_per_pass(n_steps, b_step, engine_batch)
     passes = [min(group, n_steps - s0) * b_step for s0 in range(0, n_steps, group)]
     return g0, g1, group, passes

@@ -221,3 +221,23 @@ def test_strong_scaling_schedule_covers_every_sequence_once():
     assert shard.strong_schedule(20, 64, 4, 0, 256)[3] == [160, 160]
     assert shard.strong_schedule(20, 64, 8, 0, 256)[3] == [80, 80]
     assert shard.strong_schedule(24, 64, 1, 0, 256)[3] == [256] * 6
+
+
+def test_advice_round2_host_side_guards(seeded_diffuser):
+    """ADVICE.md (round 2), host side: a step shard larger than an engine pass is refused by the schedule (not by an unrelated engine
+    error later); the upload cache's fingerprint sees a row permutation (the sums alone do not); a batch in which only SOME
+    sequences have matches is refused instead of silently sampled without guidance."""
+    from functools import partial
+    with pytest.raises(ValueError, match="more than one engine pass"):
+        shard.strong_schedule(20, 64, 1, 0, 32)
+    enc = synth.make_cameras(6, seed=3)
+    md = synth.make_matches(enc, 224, 224, per_pair=40, seed=3)
+    fp = host._match_fingerprint(md)
+    perm = np.random.default_rng(0).permutation(len(md["kp1"]))
+    md2 = {"kp1": md["kp1"][perm], "kp2": md["kp2"][perm], "i12": md["i12"][perm], "img_shape": md["img_shape"]}
+    assert host._match_fingerprint(md2) != fp and host._match_fingerprint(dict(md)) == fp
+    from posediffusion_amd.dropin.util.geometry_guided_sampling import geometry_guided_sampling
+    empty = {"kp1": None, "kp2": None, "i12": None, "img_shape": md["img_shape"]}
+    cond = partial(geometry_guided_sampling, matches_dict=[md, empty], GGS_cfg=dict(synth.GGS_CFG))
+    with pytest.raises(ValueError, match="have no matches"):
+        seeded_diffuser.sample([2, 6, 9], torch.zeros(2, 6, 384), cond_fn=cond, cond_start_step=10)
