@@ -419,13 +419,15 @@ __global__ __launch_bounds__(256) void pd_attn_kernel(const float *__restrict__ 
 
 // The same attention for large batches: ONE workgroup per (sequence, head) stages K, V and all N query rows once (pd_attn_kernel
 // stages K and V ceil(N / 4) times, once per group of four query rows: 5 120 workgroups per layer at the bench shape, 9 - 15 % of the
-// denoiser's kernel time for ~1 % of its FLOPs) and its four waves walk the query rows i = wave, wave + 4, ...  Per row the arithmetic
-// is pd_attn_kernel's, instruction for instruction: the same bits.
+// denoiser's kernel time for ~1 % of its FLOPs), and every wave works on PD_ATTN_RPW query rows AT ONCE: one K (V) read from LDS serves
+// all of them and their serial fmaf chains (128 deep for a score) interleave -- a wave with one row at a time is bound by exactly that
+// chain's latency.  Per row the arithmetic is pd_attn_kernel's, operation for operation: the same bits.
+#define PD_ATTN_RPW 5
 template <bool SPLIT_OUT>
 __global__ __launch_bounds__(256) void pd_attn_seq_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int N) {
-    constexpr int LD = DH + 4;
+    constexpr int LD = DH + 4, R = PD_ATTN_RPW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *Kk = lds, *V = Kk + N * LD, *Q = V + N * LD, *P = Q + N * LD;   // P [4][64]
+    float *Kk = lds, *V = Kk + N * LD, *Q = V + N * LD, *P = Q + N * LD;   // P [4 waves][R][64]
     const int b = blockIdx.x / NH, h = blockIdx.x % NH, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float scale = 0.08838834764831845f;   // 1/sqrt(128)
     const float *base = qkv + (size_t)b * N * (3 * DM) + h * DH;
@@ -441,45 +443,67 @@ __global__ __launch_bounds__(256) void pd_attn_seq_kernel(const float *__restric
     __syncthreads();
     const int jj = lane < N ? lane : N - 1;
     const float4 *kb = (const float4 *)(Kk + jj * LD);
-    for (int i0 = 0; i0 < N; i0 += 4) {          // every wave takes part in every round (the barriers are workgroup-wide)
-        const int i = i0 + wave, ii = i < N ? i : N - 1;
-        const float4 *qa = (const float4 *)(Q + ii * LD);
-        float s = 0.0f;
-#pragma unroll 8
-        for (int d = 0; d < DH / 4; ++d) {
-            const float4 a = qa[d], c = kb[d];
-            s = fmaf(a.x, c.x, s);
-            s = fmaf(a.y, c.y, s);
-            s = fmaf(a.z, c.z, s);
-            s = fmaf(a.w, c.w, s);
+    float *pw = P + wave * (R * 64);
+    for (int i0 = 0; i0 < N; i0 += 4 * R) {       // rows i0 + wave * R + t, t < R; every wave takes part in every round (workgroup barriers)
+        const int ib = i0 + wave * R;
+        const float4 *qa[R];
+        float s[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            qa[t] = (const float4 *)(Q + min(ib + t, N - 1) * LD);
+            s[t] = 0.0f;
         }
-        const float sv = lane < N ? s : -INFINITY;
-        const float mx = pd_wave_max(sv);
-        const float e = lane < N ? expf(sv - mx) : 0.0f;
-        const float inv = 1.0f / pd_wave_sum(e);
-        P[wave * 64 + lane] = e * inv;
-        __syncthreads();
-        if (i < N) {
-            const float *p = P + wave * 64;
-            float o0 = 0.0f, o1 = 0.0f;
-            for (int j = 0; j < N; ++j) {
-                const float pj = p[j];
-                o0 = fmaf(pj, V[j * LD + lane], o0);
-                o1 = fmaf(pj, V[j * LD + 64 + lane], o1);
+#pragma unroll 4
+        for (int d = 0; d < DH / 4; ++d) {
+            const float4 c = kb[d];
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const float4 a = qa[t][d];
+                s[t] = fmaf(a.x, c.x, s[t]);
+                s[t] = fmaf(a.y, c.y, s[t]);
+                s[t] = fmaf(a.z, c.z, s[t]);
+                s[t] = fmaf(a.w, c.w, s[t]);
             }
-            float *out = ctx + (size_t)(b * N + i) * DM + h * DH;
-            if constexpr (SPLIT_OUT) {
-                ((unsigned *)out)[lane] = pd_split_word(o0);
-                ((unsigned *)out)[64 + lane] = pd_split_word(o1);
-            } else {
-                out[lane] = o0;
-                out[64 + lane] = o1;
+        }
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const float sv = lane < N ? s[t] : -INFINITY;
+            const float mx = pd_wave_max(sv);
+            const float e = lane < N ? expf(sv - mx) : 0.0f;
+            const float inv = 1.0f / pd_wave_sum(e);
+            pw[t * 64 + lane] = e * inv;
+        }
+        __syncthreads();
+        float o0[R], o1[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) o0[t] = o1[t] = 0.0f;
+        for (int j = 0; j < N; ++j) {
+            const float v0 = V[j * LD + lane], v1 = V[j * LD + 64 + lane];
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const float pj = pw[t * 64 + j];
+                o0[t] = fmaf(pj, v0, o0[t]);
+                o1[t] = fmaf(pj, v1, o1[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const int i = ib + t;
+            if (i < N) {
+                float *out = ctx + (size_t)(b * N + i) * DM + h * DH;
+                if constexpr (SPLIT_OUT) {
+                    ((unsigned *)out)[lane] = pd_split_word(o0[t]);
+                    ((unsigned *)out)[64 + lane] = pd_split_word(o1[t]);
+                } else {
+                    out[lane] = o0[t];
+                    out[64 + lane] = o1[t];
+                }
             }
         }
         __syncthreads();                          // P is rewritten by the next round
     }
 }
-static size_t attn_seq_lds(int N) { return ((size_t)3 * N * (DH + 4) + 4 * 64) * sizeof(float); }
+static size_t attn_seq_lds(int N) { return ((size_t)3 * N * (DH + 4) + 4 * PD_ATTN_RPW * 64) * sizeof(float); }
 
 // --------------------------------------------------------------------------------------------
 // tail of the head: LayerNorm(128) -> ReLU -> Linear(128 -> 9) (denoiser.py:51,74 `_last.1..3`)
@@ -687,7 +711,6 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(set_lds(pd_attn_kernel<true>, ((2 * 64 + 4) * (DH + 4) + 4 * 64) * 4));
     PD_TRY(set_lds(pd_attn_seq_kernel<false>, attn_seq_lds(64)));
     PD_TRY(set_lds(pd_attn_seq_kernel<true>, attn_seq_lds(64)));
-    PD_TRY(set_lds((pd_gemm_stream_kernel<0, 2, 2, true>), (size_t)2 * 256 * PD_STREAM_LR * sizeof(float)));
     PD_HIP_CHECK(hipDeviceSynchronize());
     return PD_OK;
 }
@@ -762,7 +785,7 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     const bool streamed = M >= PD_STREAM_MIN_ROWS && d->hn;
     if (streamed) {
         hipLaunchKernelGGL(pd_embed_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, z, d->t_table + (size_t)t * 128, N, M, d->emb);
-        pd_gemm_stream<0>(d->emb, KFIRST_PAD, d->first_wf, KFIRST_PAD, d->first_b, d->h, M, DM, s);
+        pd_gemm_dma<0>(d->emb, KFIRST_PAD, d->first_wf, KFIRST_PAD, d->first_b, d->h, M, DM, s);
     } else {
         // _first with the embedding fused into the A staging
         g.bias = d->first_b; g.C = d->h; g.Nout = DM;
@@ -790,12 +813,12 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
         if (streamed) {
             float2 *stats = (float2 *)d->hn;           // (mean, rstd) per token row; applied in the A staging of the next GEMM
             hipLaunchKernelGGL(pd_ln_stats_kernel<DM>, dim3((M + 3) / 4), dim3(256), 0, s, d->h, stats, M, 1e-5f);
-            pd_gemm_stream<0, true, 2, 2>(d->h, DM, L.qkv_wf, DM, L.qkv_b, d->qkv, M, 3 * DM, s, stats);       // LayerNorm-1; 128 x 128 tiles
+            pd_gemm_dma<0, true>(d->h, DM, L.qkv_wf, DM, L.qkv_b, d->qkv, M, 3 * DM, s, stats);                // LayerNorm-1 at the fragment reads
             hipLaunchKernelGGL(pd_attn_seq_kernel<false>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N);
-            pd_gemm_stream<2>(d->ctx, DM, L.out_wf, DM, L.out_b, d->h, M, DM, s);
+            pd_gemm_dma<2>(d->ctx, DM, L.out_wf, DM, L.out_b, d->h, M, DM, s);
             hipLaunchKernelGGL(pd_ln_stats_kernel<DM>, dim3((M + 3) / 4), dim3(256), 0, s, d->h, stats, M, 1e-5f);
-            pd_gemm_stream<1, true>(d->h, DM, L.ff1_wf, DM, L.ff1_b, d->ff, M, DFF, s, stats);                  // LayerNorm-2 likewise
-            pd_gemm_stream<2>(d->ff, DFF, L.ff2_wf, DFF, L.ff2_b, d->h, M, DM, s);
+            pd_gemm_dma<1, true>(d->h, DM, L.ff1_wf, DM, L.ff1_b, d->ff, M, DFF, s, stats);                     // LayerNorm-2 likewise
+            pd_gemm_dma<2>(d->ff, DFF, L.ff2_wf, DFF, L.ff2_b, d->h, M, DM, s);
             continue;
         }
         // x += MHA(LN1(x))
@@ -812,7 +835,7 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     }
     // _last.0 as a plain tile GEMM, then the fused LN/ReLU/Linear(128->9)/DDPM tail
     if (streamed) {
-        pd_gemm_stream<0>(d->h, DM, d->last0_wf, DM, d->last0_b, d->hid, M, HID, s);
+        pd_gemm_dma<0>(d->h, DM, d->last0_wf, DM, d->last0_b, d->hid, M, HID, s);
     } else {
         g.A = d->h; g.bias = d->last0_b; g.C = d->hid; g.Nout = HID;
         launch_gemm<DM, 0, 0>(g, d->last0_wp, MT, eng->gemm_wide_min_tiles, s);

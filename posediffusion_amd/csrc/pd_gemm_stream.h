@@ -109,7 +109,12 @@ struct PdStreamArgs {
 
 // ALN: A' = LayerNorm(A) without affine (gamma / beta folded into W / bias): every thread stages the same PA rows in every chunk, so it
 // loads their (mean, rstd) from g.ln_stats once and the staging stores apply them -- no normalised copy of the activations in memory.
-template <int EPI, int WM, int WN, bool ALN = false>
+// BARE (tools/gemm_probe.hip only; 0 in the library): 1 = no global loads / LDS stores inside the K loop, 2 = also no barrier, 3 = also no
+// fragment reads, 4 = global loads kept but never stored, 5 = LDS stores of stale registers -- bisects where the matrix pipe's idle time
+// comes from (profiles/round3_gemm_probe.txt: of ~127 TFLOP/s for the bare matrix work at the clock the chip holds under this load, the
+// fragment reads cost ~5 %, the LDS stores ~7 %, the global loads ~17 %; a second register stage, wave priorities, staggered starts and an
+// XCD-owns-column-tiles block order were each measured and changed nothing).  Results are meaningless for BARE > 0.
+template <int EPI, int WM, int WN, bool ALN = false, int BARE = 0>
 __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
     constexpr int KC = PD_STREAM_KC, LR = PD_STREAM_LR, TM = 64 * WM, TN = 64 * WN, PA = 2 * WM, PW = 2 * WN, GROUP = 2048 / TM;
     static_assert(KC == 32 && PA <= 4 && PW <= 4, "staging: 8 float4 per row, passes of 32 rows");
@@ -177,19 +182,16 @@ __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.0f;
     const int nk = g.K / KC;
     const int aoff = (wm * 32 * WM + l31) * LR + 4 * hi, boff = (wn * 32 * WN + l31) * LR + 4 * hi;
-    for (int kc = 0; kc < nk; ++kc) {
-        // the chunk after the last is the last again: loads and LDS writes stay unconditional (straight-line loop body)
-        const int nx = min(kc + 1, nk - 1) * (KC / 4);
-        VS_EACH(VS_LOAD)
-        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the matrix work
-        const float *a = As + (kc & 1) * TM * LR + aoff, *b = Ws + (kc & 1) * TN * LR + boff;
+    // the matrix work of one K chunk out of LDS buffer `buf`
+    auto mma_chunk = [&](int buf) {
+        const float *a = As + buf * TM * LR + aoff, *b = Ws + buf * TN * LR + boff;
 #pragma unroll
         for (int kk = 0; kk < KC / 8; ++kk) {
             float4 af[WM], bf[WN];
 #pragma unroll
-            for (int mi = 0; mi < WM; ++mi) af[mi] = *(const float4 *)(a + mi * 32 * LR + kk * 8);
+            for (int mi = 0; mi < WM; ++mi) af[mi] = (BARE != 3) ? *(const float4 *)(a + mi * 32 * LR + kk * 8) : make_float4(1.f + kk, 2.f, 3.f, 4.f);
 #pragma unroll
-            for (int ni = 0; ni < WN; ++ni) bf[ni] = *(const float4 *)(b + ni * 32 * LR + kk * 8);
+            for (int ni = 0; ni < WN; ++ni) bf[ni] = (BARE != 3) ? *(const float4 *)(b + ni * 32 * LR + kk * 8) : make_float4(1.f, 2.f + kk, 3.f, 4.f);
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
@@ -200,10 +202,24 @@ __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
                 }
         }
+    };
+    for (int kc = 0; kc < nk; ++kc) {
+        // the chunk after the last is the last again: loads and LDS writes stay unconditional (straight-line loop body)
+        const int nx = min(kc + 1, nk - 1) * (KC / 4);
+        if constexpr (BARE == 0 || BARE == 4) {      // (4: global loads kept, LDS stores dropped; 5: the reverse)
+            VS_EACH(VS_LOAD)
+        }
+        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the matrix work
+        mma_chunk(kc & 1);
         __builtin_amdgcn_sched_barrier(0);
         float *da = As + ((kc + 1) & 1) * TM * LR, *dw = Ws + ((kc + 1) & 1) * TN * LR;
-        VS_EACH(VS_STORE)
-        __syncthreads();
+        if constexpr (BARE == 0 || BARE == 5) {
+            VS_EACH(VS_STORE)
+        }
+        if constexpr (BARE == 4) {                   // keep the loads alive without storing them
+            asm volatile("" ::"v"(ra0.x), "v"(ra1.x), "v"(rw0.x), "v"(rw1.x));
+        }
+        if constexpr (BARE < 2 || BARE >= 4) __syncthreads();
     }
 #undef VS_DECL
 #undef VS_LOAD
@@ -232,6 +248,128 @@ __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
         }
 }
 
+
+// ---- the same GEMM with LDS-DMA staging (64 x 64 tiles) -------------------------------------------------------------------------------
+// pd_gemm_stream_kernel stages through registers: global_load -> VGPRs -> ds_write.  Bisecting it (BARE above) shows the matrix pipe idle
+// ~17 % of the time because of those global loads and ~7 % because of the LDS stores -- whatever the prefetch depth, the block order or
+// the wave priorities.  Here the K chunks go from L2 straight into LDS (global_load_lds_dwordx4: 64 lanes x 16 B land lane-linear at a
+// wave-uniform LDS address; no VGPR round trip, no ds_write).  A lane-linear image has no row padding, so the 16-byte slots of a row are
+// XOR-swizzled instead -- slot s of row r holds k-chunk s ^ ((r >> 1) & 7); a lane may fetch any 16 bytes it likes -- which keeps the
+// fragment reads (32 rows x one k-chunk per half wave) conflict free.  LayerNorm (ALN) moves from the staging stores to the fragment
+// reads: (a - mean) * rstd with the statistics of the lane's own row, the same two roundings.  Same MFMA chain as the register-staged
+// kernel: bitwise the same C.
+template <int EPI, bool ALN>
+__global__ __launch_bounds__(256) void pd_gemm_dma_kernel(PdStreamArgs g) {
+    constexpr int KC = 32, TM = 64, TN = 64, GROUP = 2048 / TM, CH = TM * KC;      // CH floats per operand and chunk (8 KiB)
+    extern __shared__ __attribute__((aligned(1024))) float lds[];
+    float *As = lds, *Ws = lds + 2 * CH;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave & 1, wn = wave >> 1;
+    const int MT = (g.M + TM - 1) / TM, NT = g.Nout / TN;
+    int mtile, ntile;
+    {
+        const int b = blockIdx.x, full = (MT / GROUP) * GROUP * NT;
+        if (b < full) {
+            const int grp = b / (NT * GROUP), r = b - grp * (NT * GROUP);
+            ntile = r / GROUP;
+            mtile = grp * GROUP + r % GROUP;
+        } else {
+            const int r = b - full, rest = MT % GROUP;
+            ntile = r / rest;
+            mtile = (MT / GROUP) * GROUP + r % rest;
+        }
+    }
+    const int m0 = mtile * TM, n0 = ntile * TN;
+    // staging: 16 pieces of 1 KiB per chunk (8 of A, 8 of W: 8 rows each); wave w moves pieces 2 w, 2 w + 1 of both.  Hand-issued (a
+    // wave-uniform 64-bit base in SGPRs + a 32-bit byte offset per lane, M0 = the LDS byte address): the compiler's own waitcnt logic
+    // cannot tell the two LDS buffers apart and would drain the DMA before the first fragment read of the chunk that hides it.
+    const int prow = lane >> 3, pslot = lane & 7;
+    unsigned oa[2], ow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 8 * (2 * wave + j) + prow;                                   // row of the tile this lane fetches
+        const int k4 = pslot ^ ((r >> 1) & 7);
+        oa[j] = (unsigned)(((size_t)min(m0 + r, g.M - 1) * g.lda + 4 * k4) * sizeof(float));
+        ow[j] = (unsigned)(((size_t)(n0 + r) * g.ldw + 4 * k4) * sizeof(float));
+    }
+    const unsigned lds_a = (unsigned)(size_t)(As + 2 * wave * 256), lds_w = (unsigned)(size_t)(Ws + 2 * wave * 256);   // LDS byte addresses (wave-uniform)
+    auto stage = [&](int kc, int buf) {
+        const float *ab = g.A + kc * KC, *wb = g.W + kc * KC;
+        const unsigned da = __builtin_amdgcn_readfirstlane(lds_a + buf * CH * 4), dw = __builtin_amdgcn_readfirstlane(lds_w + buf * CH * 4);
+        unsigned keep;
+        asm volatile("s_mov_b32 %[k], m0\n\t"
+                     "s_mov_b32 m0, %[da]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oa0], %[ab]\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oa1], %[ab]\n\t"
+                     "s_mov_b32 m0, %[dw]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[ow0], %[wb]\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[ow1], %[wb]\n\t"
+                     "s_mov_b32 m0, %[k]"
+                     : [k] "=&s"(keep)
+                     : [da] "s"(da), [dw] "s"(dw), [ab] "s"(ab), [wb] "s"(wb), [oa0] "v"(oa[0]), [oa1] "v"(oa[1]), [ow0] "v"(ow[0]), [ow1] "v"(ow[1])
+                     : "memory");
+    };
+    // fragments: lane (l31, hi) reads k-chunk 2 kk + hi of row (wave's 32 rows) + l31
+    const int arow = wm * 32 + l31, brow = wn * 32 + l31;
+    const int asw = (arow >> 1) & 7, bsw = (brow >> 1) & 7;
+    float ln_mu = 0.0f, ln_rs = 1.0f;
+    if constexpr (ALN) {
+        const float2 st2 = g.ln_stats[min(m0 + arow, g.M - 1)];
+        ln_mu = st2.x;
+        ln_rs = st2.y;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const int nk = g.K / KC;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        stage(min(kc + 1, nk - 1), (kc + 1) & 1);       // (the chunk after the last is the last again: the loop body stays straight-line)
+        const float *a = As + (kc & 1) * CH + arow * KC, *b = Ws + (kc & 1) * CH + brow * KC;
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            float4 af = *(const float4 *)(a + 4 * ((2 * kk + hi) ^ asw));
+            const float4 bf = *(const float4 *)(b + 4 * ((2 * kk + hi) ^ bsw));
+            if constexpr (ALN) {
+                af.x = (af.x - ln_mu) * ln_rs;
+                af.y = (af.y - ln_mu) * ln_rs;
+                af.z = (af.z - ln_mu) * ln_rs;
+                af.w = (af.w - ln_mu) * ln_rs;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk has landed in the other buffer
+        __syncthreads();
+    }
+    {
+        const int col = n0 + wn * 32 + l31, r0 = m0 + wm * 32 + 4 * hi;
+        const float bias = g.bias[col];
+        float res[16];
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) res[i] = g.C[(size_t)min(r0 + (i & 3) + 8 * (i >> 2), g.M - 1) * g.Nout + col];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = r0 + (i & 3) + 8 * (i >> 2);
+            float v = acc[i] + bias;
+            if constexpr (EPI == 1) v = fmaxf(v, 0.0f);
+            if constexpr (EPI == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+            if constexpr (EPI == 2) v += res[i];
+            if (row < g.M) g.C[(size_t)row * g.Nout + col] = v;
+        }
+    }
+}
+
+template <int EPI, bool ALN = false>
+static inline void pd_gemm_dma(const float *A, int lda, const float *W, int K, const float *bias, float *C, int M, int Nout, hipStream_t s,
+                               const float2 *ln_stats = nullptr) {
+    PdStreamArgs g{A, W, bias, C, M, Nout, K, lda, K, ln_stats};
+    hipLaunchKernelGGL((pd_gemm_dma_kernel<EPI, ALN>), dim3(((M + 63) / 64) * (Nout / 64)), dim3(256), (size_t)4 * 64 * 32 * sizeof(float), s, g);
+}
 
 #define PD_STREAM_MIN_ROWS 1024
 // Tile shapes, every one alone at 5 120 / 15 360 rows (profiles/round3_gemm_probe.txt, TFLOP/s): 64 x 64 is the best or equal for the
