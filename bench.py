@@ -534,7 +534,7 @@ def main():
     den_gbs = DENOISER_PARAMS * 4 / (den_ms * 1e-3) / 1e9
     den_traffic, den_src = pmc_traffic("denoiser_step", EB)
     if tokens > 50:      # the weight stream bounds the denoiser up to ~50 tokens, the exact-fp32 matrix pipe above
-        roofline_den = {"kernel": f"one denoiser step at {tokens} token rows (pd_gemm_stream_kernel / pd_gemm_kernel / pd_attn_kernel / pd_tail_kernel launches)",
+        roofline_den = {"kernel": f"one denoiser step at {tokens} token rows (pd_gemm_dma_kernel / pd_ln_stats_kernel / pd_attn_seq_kernel / pd_tail_kernel launches at >= 1 024 rows; pd_gemm_kernel / pd_attn_kernel below)",
                         "bound": "mfma", "bound_detail": "exact-fp32 matrix instruction (157.3 TFLOP/s)",
                         "achieved": den_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": den_tflops / FP32_PEAK_TFLOPS,
                         "traffic": den_traffic, "traffic_source": den_src, "step_us": den_ms * 1e3, "algorithmic_flops_per_step": den_flops,

@@ -10,7 +10,7 @@ bash tools/collect_pmc.sh > /dev/null 2>&1; cp gpurun_out/pmc_summary.json $F/pm
 mkdir -p profiles; cp gpurun_out/pmc_summary.json profiles/round3_pmc_summary.json      # bench.py reads the traffic figures from here (hash-checked)
 timeout 900 python bench.py > $F/bench_line.json 2> $F/bench.err; tail -2 $F/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout 500 rocprofv3 --kernel-trace --stats -d $R/$F/trace -o bench -- python $R/bench.py --no-per-config --no-fresh-inputs --cpu-budget-s 0 > $R/$F/bench_traced.json 2>/dev/null
+timeout 500 rocprofv3 --kernel-trace --stats -d $R/$F/trace -o bench -- python $R/bench.py --no-per-config --no-fresh-inputs --no-fast-mode --cpu-budget-s 0 > $R/$F/bench_traced.json 2>/dev/null
 cd $R; python tools/rocpd_stats.py $F/trace/bench_results.db 16 > $F/kernel_stats.txt
 python tools/coresident_from_trace.py $F/trace/bench_results.db $(python -c "import json; print(json.load(open('$F/bench_traced.json'))['roofline']['algorithmic_flops_per_launch'])") > $F/coresident.txt 2>&1; cat $F/coresident.txt; rm -rf $F/trace
 cd /tmp
