@@ -1434,11 +1434,9 @@ struct PdLaneVariant {
     void (*fn)(PdGgsParams, int, int);
     int rv, depth;
 };
-#define PD_LANE_VARIANTS 4
+#define PD_LANE_VARIANTS 2
 static const PdLaneVariant pd_lane_variants[PD_LANE_VARIANTS] = {{pd_ggs_lane_kernel<PD_LANE_RV, PD_LANE_DEPTH>, PD_LANE_RV, PD_LANE_DEPTH},
-                                                                 {pd_ggs_lane_kernel<10, 4>, 10, 4},
-                                                                 {pd_ggs_lane_kernel<10, 6>, 10, 6},
-                                                                 {pd_ggs_lane_kernel<8, 6>, 8, 6}};
+                                                                 {pd_ggs_lane_kernel<10, 6>, 10, 6}};
 static int pd_lane_variant() {
     static int v = -1;
     if (v < 0) {
@@ -1818,7 +1816,9 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
         if (ok) {
             const int rv = pd_lane_variants[pd_lane_variant()].rv;
             const int pinc_rows = 2 * std::min(PD_LANE_MAX_ITEMS, std::max(pairs, 1));
-            const int room = (int)((160 * 1024 - lane_lds_bytes(pinc_rows, 0)) / (PD_LANE_WAVES * 2048));
+            // PD_LANE_LDS_SPARE_KB (development knob): LDS left free beside the workgroup, e.g. for a denoiser GEMM workgroup of another context
+            static const int spare_kb = getenv("PD_LANE_LDS_SPARE_KB") ? atoi(getenv("PD_LANE_LDS_SPARE_KB")) : 0;
+            const int room = std::max(0, (int)((160 * 1024 - spare_kb * 1024 - (int)lane_lds_bytes(pinc_rows, 0)) / (PD_LANE_WAVES * 2048)));
             const int rl = std::max(0, std::min(room, steps - rv));
             if ((cfg->reserved & PD_GGS_CFG_LANE_ITEMS) || steps <= rv + rl) {
                 out->lane = 1;
