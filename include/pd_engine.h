@@ -63,7 +63,7 @@ typedef struct pd_weights {
     int32_t t_emb_dim;      /* 256  (TimeStepEmbedding.dim; output is dim/2 = 128)       */
     int32_t mlp_hidden;     /* 128  (Denoiser.mlp_hidden_dim)                            */
     int32_t timesteps;      /* 100                                                       */
-    int32_t reserved;
+    int32_t reserved;       /* flags; 0 = objective "pred_noise" (cfgs/default.yaml), PD_WEIGHTS_PRED_X0 = "pred_x0" */
     const float *time_w0, *time_b0;     /* time_embed.linear.0  [128,256],[128]          */
     const float *time_w2, *time_b2;     /* time_embed.linear.2  [128,128],[128]          */
     const float *first_w, *first_b;     /* _first  [d, 189+128+z_dim+1 = 702], [d]       */
@@ -78,6 +78,10 @@ typedef struct pd_weights {
     const float *posterior_mean_coef2;
     const float *posterior_log_variance_clipped;
 } pd_weights;
+
+#define PD_WEIGHTS_PRED_X0 1   /* pd_weights.reserved: GaussianDiffusion(objective="pred_x0") -- the denoiser's output IS x_start
+                                * (models/gaussian_diffuser.py:225-227); pd_p_mean / pd_sample then skip predict_start_from_noise
+                                * and pd_denoise_step still returns the raw model output */
 
 /* GGS knobs: cfgs/default.yaml:6-13 as passed through **GGS_cfg to GGS_optimize
  * (geometry_guided_sampling.py:67-81). */
@@ -127,7 +131,7 @@ int pd_denoise_step(pd_engine *eng, const float *x, const float *z, int t, int B
                     float *eps_out, void *stream);
 
 /* model_mean of p_mean_variance (gaussian_diffuser.py:231-246): runs the denoiser and
- * x0 = c_recip[t] x - c_recipm1[t] eps ; mean = coef1[t] x0 + coef2[t] x.
+ * x0 = c_recip[t] x - c_recipm1[t] eps  (or x0 = the model output under PD_WEIGHTS_PRED_X0) ; mean = coef1[t] x0 + coef2[t] x.
  * mean_out[B,N,9]; x0_out may be NULL.  DEVICE pointers. */
 int pd_p_mean(pd_engine *eng, const float *x, const float *z, int t, int B, int N,
               float *mean_out, float *x0_out, void *stream);

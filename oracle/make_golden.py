@@ -327,8 +327,60 @@ def make_guided_free(seeds=(0, 1, 2), N=8, cond_start=3, per_pair=60, name="guid
     print(name + ".npz", os.path.getsize(os.path.join(OUT, name + ".npz")))
 
 
+def make_pred_x0():
+    """tests/golden/pred_x0.npz -- GaussianDiffusion(objective="pred_x0") (models/gaussian_diffuser.py:105-108, :225-227): the
+    UNMODIFIED reference's p_sample at five steps (B = 2, N = 20), its model_predictions pair at one step and one whole
+    100-step GGS-off trajectory (B = 1, N = 8), all fp32 on the CPU, with the seeded weights of the other fixtures."""
+    torch.set_num_threads(1)
+    ref = RS.load_reference()
+    base = RS.build_reference_diffuser(seed=0)
+    synth.randomize_norm_and_bias_(base.model)
+    diff = ref.GaussianDiffusion(beta_schedule="custom", objective="pred_x0")
+    diff.model = base.model
+    diff.eval()
+    out = {"weight_checksum": weight_checksum(base.model.state_dict())}
+    B, N = 2, 20
+    x = torch.randn(B, N, 9, generator=torch.Generator().manual_seed(21))
+    z = synth.make_z(B, N, seed=1000)
+    out["x"], out["z"] = x.numpy(), z.numpy()
+    for t in (99, 50, 10, 1, 0):
+        torch.manual_seed(300 + t)
+        with torch.no_grad():
+            pred, x0 = diff.p_sample(x, t, z)
+        torch.manual_seed(300 + t)
+        noise = torch.randn_like(x) if t > 0 else torch.zeros_like(x)
+        out[f"ps_noise_t{t}"], out[f"ps_pred_t{t}"], out[f"ps_x0_t{t}"] = noise.numpy(), pred.numpy(), x0.numpy()
+    with torch.no_grad():
+        mp = diff.model_predictions(x, torch.full((B,), 50, dtype=torch.long), z)
+    out["mp_noise_t50"], out["mp_x0_t50"] = mp.pred_noise.numpy(), mp.pred_x_start.numpy()
+    N = 8
+    z8 = synth.make_z(1, N, seed=1001)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        pose, process = diff.sample([1, N, 9], z8)
+    init, noises = O.draw_reference_noise((1, N, 9), torch.Generator().manual_seed(5))
+    assert torch.equal(init, process[0]), "RNG replay does not match the reference's draw order"
+    noise = np.zeros((101, 1, N, 9), dtype=np.float32)
+    noise[0] = init.numpy()
+    for step in range(100):
+        if noises[99 - step] is not None:
+            noise[step + 1] = noises[99 - step].numpy()
+    sd64 = O.cast_state_dict(base.model.state_dict(), torch.float64)
+    with torch.no_grad():
+        p64, proc64 = O.p_sample_loop(sd64, O.diffusion_tables(dtype=torch.float64), z8.double(), init.double(),
+                                      [None if n is None else n.double() for n in noises], objective="pred_x0")
+    print(f"pred_x0 trajectory: |pose| max {float(pose.abs().max()):.3f}; reference fp32 vs fp64 oracle "
+          f"{float((process.double() - proc64).abs().max() / proc64.abs().max()):.3e}")
+    out.update({"traj_z": z8.numpy(), "traj_noise": noise, "traj_process": process.numpy(), "traj_pose": pose.numpy(),
+                "traj_process64": proc64.numpy()})
+    np.savez_compressed(os.path.join(OUT, "pred_x0.npz"), **out)
+    print("pred_x0.npz", os.path.getsize(os.path.join(OUT, "pred_x0.npz")))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "guided_free":
+    if len(sys.argv) > 1 and sys.argv[1] == "pred_x0":
+        make_pred_x0()          # only the objective="pred_x0" fixture
+    elif len(sys.argv) > 1 and sys.argv[1] == "guided_free":
         make_guided_free()      # only the free-running GGS-on fixture
     elif len(sys.argv) > 1 and sys.argv[1] == "guided_free_full":
         make_guided_free(seeds=(0,), N=20, cond_start=10, per_pair=300, name="guided_free_full")   # configs[2] at real size

@@ -179,19 +179,23 @@ def cast_state_dict(sd: Dict[str, torch.Tensor], dtype, strip_prefix: str = "") 
 # S2-S5  one reverse-diffusion step        models/gaussian_diffuser.py:190-282
 # --------------------------------------------------------------------------------------
 
-def p_mean_variance(sd, tables, x: torch.Tensor, t: int, z: torch.Tensor):
-    """-> (model_mean, posterior_log_variance_clipped[t], x_start, eps)  (:231-246, :218-229)."""
+def p_mean_variance(sd, tables, x: torch.Tensor, t: int, z: torch.Tensor, objective: str = "pred_noise"):
+    """-> (model_mean, posterior_log_variance_clipped[t], x_start, model output)  (:231-246, :218-229)."""
     tt = torch.full((x.shape[0],), t, dtype=torch.long)                               # :265
     eps = denoiser_forward(sd, x, tt, z)
-    x0 = tables["sqrt_recip_alphas_cumprod"][t] * x - tables["sqrt_recipm1_alphas_cumprod"][t] * eps   # :190-194
+    if objective == "pred_x0":                                                        # :225-227 (pred_noise is not used by sampling)
+        x0 = eps
+    else:
+        x0 = tables["sqrt_recip_alphas_cumprod"][t] * x - tables["sqrt_recipm1_alphas_cumprod"][t] * eps   # :190-194, :221-223
     mean = tables["posterior_mean_coef1"][t] * x0 + tables["posterior_mean_coef2"][t] * x              # :201-205
     return mean, tables["posterior_log_variance_clipped"][t], x0, eps
 
 
-def p_sample(sd, tables, x, t: int, z, noise: Optional[torch.Tensor], cond_fn=None, cond_start_step: int = 0):
+def p_sample(sd, tables, x, t: int, z, noise: Optional[torch.Tensor], cond_fn=None, cond_start_step: int = 0,
+             objective: str = "pred_noise"):
     """One ``p_sample`` (:248-282).  ``noise`` is the tensor the reference would draw with
     ``randn_like`` (ignored on guided steps and at t == 0, exactly as :270-278)."""
-    mean, logvar, x0, _ = p_mean_variance(sd, tables, x, t, z)
+    mean, logvar, x0, _ = p_mean_variance(sd, tables, x, t, z, objective)
     if cond_fn is not None and t < cond_start_step:                                   # :270
         mean = cond_fn(mean, t)
         nz = 0.0                                                                      # :276
@@ -201,14 +205,14 @@ def p_sample(sd, tables, x, t: int, z, noise: Optional[torch.Tensor], cond_fn=No
 
 
 def p_sample_loop(sd, tables, z: torch.Tensor, init: torch.Tensor, noises: Sequence[Optional[torch.Tensor]],
-                  cond_fn=None, cond_start_step: int = 0, num_timesteps: int = 100):
+                  cond_fn=None, cond_start_step: int = 0, num_timesteps: int = 100, objective: str = "pred_noise"):
     """``p_sample_loop`` (:284-300) with the RNG factored out: ``init`` is the ``randn(shape)`` of
     :289 and ``noises[t]`` the ``randn_like`` the reference draws at step t (None where it draws
     nothing).  Returns (pose [B,N,9], process [T+1,B,N,9])."""
     pose = init
     process = [pose]
     for t in reversed(range(num_timesteps)):
-        pose, _ = p_sample(sd, tables, pose, t, z, noises[t], cond_fn, cond_start_step)
+        pose, _ = p_sample(sd, tables, pose, t, z, noises[t], cond_fn, cond_start_step, objective)
         process.append(pose)
     return pose, torch.stack(process)
 

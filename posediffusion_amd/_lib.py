@@ -53,6 +53,7 @@ class pd_vit_weights(C.Structure):
 PD_GGS_CFG_FORCE_ONE_HOP = 1
 PD_GGS_CFG_NO_LDS_STAGING = 2
 PD_GGS_CFG_WAVES8 = 4
+PD_WEIGHTS_PRED_X0 = 1
 PD_GGS_CFG_LANE_ITEMS = 8       # lane-per-item kernel (the throughput shape) whatever the batch size
 PD_GGS_CFG_NO_LANE_ITEMS = 16   # never the lane-per-item kernel
 PD_OPT_DENOISER_SPLIT = 2

@@ -518,6 +518,7 @@ struct HeadArgs {
     float *eps_out, *mean_out, *x0_out, *xnext_out;   // each [M, 9] or null
     float c_recip, c_recipm1, coef1, coef2, sigma;
     int M;
+    int pred_x0;           // objective "pred_x0": the model output is x_start (gaussian_diffuser.py:225-227)
 };
 
 __global__ __launch_bounds__(256) void pd_tail_kernel(HeadArgs g) {
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(256) void pd_tail_kernel(HeadArgs g) {
         e += g.b3[lane];
         const size_t at = (size_t)m * 9 + lane;
         const float xv = g.x[at];
-        const float x0 = g.c_recip * xv - g.c_recipm1 * e;          // gaussian_diffuser.py:190-194
+        const float x0 = g.pred_x0 ? e : g.c_recip * xv - g.c_recipm1 * e;   // gaussian_diffuser.py:190-194, :221-227
         const float mu = g.coef1 * x0 + g.coef2 * xv;               // :201-205
         if (g.eps_out) g.eps_out[at] = e;
         if (g.x0_out) g.x0_out[at] = x0;
@@ -848,6 +849,7 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     ha.c_recip = eng->c_recip[t]; ha.c_recipm1 = eng->c_recipm1[t]; ha.coef1 = eng->coef1[t]; ha.coef2 = eng->coef2[t];
     ha.sigma = expf(0.5f * eng->logvar[t]);
     ha.M = M;
+    ha.pred_x0 = eng->pred_x0;
     hipLaunchKernelGGL(pd_tail_kernel, dim3((M + 3) / 4), dim3(256), 0, s, ha);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;

@@ -91,6 +91,10 @@ extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_en
         return PD_ERR_INVALID_ARG;
     }
     *out = nullptr;
+    if (w->reserved & ~PD_WEIGHTS_PRED_X0) {
+        pd_set_error("pd_engine_create: unknown pd_weights.reserved flags 0x%x", (unsigned)w->reserved);
+        return PD_ERR_INVALID_ARG;
+    }
     pd_engine *eng = new pd_engine();
     int rc = PD_OK;
     do {
@@ -111,6 +115,7 @@ extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_en
         eng->num_layers = w->num_layers;
         eng->z_dim = w->z_dim;
         eng->timesteps = w->timesteps;
+        eng->pred_x0 = (w->reserved & PD_WEIGHTS_PRED_X0) ? 1 : 0;
         if ((rc = fetch_table(eng->c_recip, w->sqrt_recip_alphas_cumprod, w->timesteps))) break;
         if ((rc = fetch_table(eng->c_recipm1, w->sqrt_recipm1_alphas_cumprod, w->timesteps))) break;
         if ((rc = fetch_table(eng->coef1, w->posterior_mean_coef1, w->timesteps))) break;

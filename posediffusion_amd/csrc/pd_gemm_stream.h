@@ -258,11 +258,20 @@ __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
 // fragment reads (32 rows x one k-chunk per half wave) conflict free.  LayerNorm (ALN) moves from the staging stores to the fragment
 // reads: (a - mean) * rstd with the statistics of the lane's own row, the same two roundings.  Same MFMA chain as the register-staged
 // kernel: bitwise the same C.
-template <int EPI, bool ALN>
+// one 1 KiB piece: 64 lanes x 16 B from `base` + the lane's byte offset to the wave-uniform LDS byte address `dst`
+__device__ __forceinline__ void pd_dma_piece(const float *base, unsigned off, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o], %[b]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep)
+                 : [d] "s"(dst), [b] "s"(base), [o] "v"(off)
+                 : "memory");
+}
+// (64 WM) x (64 WN) tile per workgroup, a (32 WM) x (32 WN) quadrant per wave (WM, WN in {1, 2})
+template <int EPI, bool ALN, int WM = 1, int WN = 1>
 __global__ __launch_bounds__(256) void pd_gemm_dma_kernel(PdStreamArgs g) {
-    constexpr int KC = 32, TM = 64, TN = 64, GROUP = 2048 / TM, CH = TM * KC;      // CH floats per operand and chunk (8 KiB)
+    constexpr int KC = 32, TM = 64 * WM, TN = 64 * WN, GROUP = 2048 / TM, CHA = TM * KC, CHW = TN * KC;   // floats per operand and chunk
     extern __shared__ __attribute__((aligned(1024))) float lds[];
-    float *As = lds, *Ws = lds + 2 * CH;
+    float *As = lds, *Ws = lds + 2 * CHA;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave & 1, wn = wave >> 1;
     const int MT = (g.M + TM - 1) / TM, NT = g.Nout / TN;
@@ -280,95 +289,114 @@ __global__ __launch_bounds__(256) void pd_gemm_dma_kernel(PdStreamArgs g) {
         }
     }
     const int m0 = mtile * TM, n0 = ntile * TN;
-    // staging: 16 pieces of 1 KiB per chunk (8 of A, 8 of W: 8 rows each); wave w moves pieces 2 w, 2 w + 1 of both.  Hand-issued (a
-    // wave-uniform 64-bit base in SGPRs + a 32-bit byte offset per lane, M0 = the LDS byte address): the compiler's own waitcnt logic
-    // cannot tell the two LDS buffers apart and would drain the DMA before the first fragment read of the chunk that hides it.
+    // staging: pieces of 1 KiB = 8 rows x 32 floats; a chunk has 8 WM of A and 8 WN of W, wave w moves pieces [2 WM w, 2 WM (w + 1)) of A
+    // and [2 WN w, 2 WN (w + 1)) of W.  Hand-issued (a wave-uniform 64-bit base in SGPRs + a 32-bit byte offset per lane, M0 = the LDS
+    // byte address): the compiler's own waitcnt logic cannot tell the two LDS buffers apart and would drain the DMA before the first
+    // fragment read of the chunk that hides it.
     const int prow = lane >> 3, pslot = lane & 7;
-    unsigned oa[2], ow[2];
+    unsigned oa[2 * WM], ow[2 * WN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = 8 * (2 * wave + j) + prow;                                   // row of the tile this lane fetches
-        const int k4 = pslot ^ ((r >> 1) & 7);
-        oa[j] = (unsigned)(((size_t)min(m0 + r, g.M - 1) * g.lda + 4 * k4) * sizeof(float));
-        ow[j] = (unsigned)(((size_t)(n0 + r) * g.ldw + 4 * k4) * sizeof(float));
+    for (int j = 0; j < 2 * WM; ++j) {
+        const int r = 8 * (2 * WM * wave + j) + prow;                              // row of the tile this lane fetches
+        oa[j] = (unsigned)(((size_t)min(m0 + r, g.M - 1) * g.lda + 4 * (pslot ^ ((r >> 1) & 7))) * sizeof(float));
     }
-    const unsigned lds_a = (unsigned)(size_t)(As + 2 * wave * 256), lds_w = (unsigned)(size_t)(Ws + 2 * wave * 256);   // LDS byte addresses (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < 2 * WN; ++j) {
+        const int r = 8 * (2 * WN * wave + j) + prow;
+        ow[j] = (unsigned)(((size_t)(n0 + r) * g.ldw + 4 * (pslot ^ ((r >> 1) & 7))) * sizeof(float));
+    }
+    const unsigned lds_a = (unsigned)(size_t)(As + 2 * WM * wave * 256), lds_w = (unsigned)(size_t)(Ws + 2 * WN * wave * 256);   // LDS byte addresses
     auto stage = [&](int kc, int buf) {
         const float *ab = g.A + kc * KC, *wb = g.W + kc * KC;
-        const unsigned da = __builtin_amdgcn_readfirstlane(lds_a + buf * CH * 4), dw = __builtin_amdgcn_readfirstlane(lds_w + buf * CH * 4);
-        unsigned keep;
-        asm volatile("s_mov_b32 %[k], m0\n\t"
-                     "s_mov_b32 m0, %[da]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oa0], %[ab]\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oa1], %[ab]\n\t"
-                     "s_mov_b32 m0, %[dw]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[ow0], %[wb]\n\t"
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[ow1], %[wb]\n\t"
-                     "s_mov_b32 m0, %[k]"
-                     : [k] "=&s"(keep)
-                     : [da] "s"(da), [dw] "s"(dw), [ab] "s"(ab), [wb] "s"(wb), [oa0] "v"(oa[0]), [oa1] "v"(oa[1]), [ow0] "v"(ow[0]), [ow1] "v"(ow[1])
-                     : "memory");
-    };
-    // fragments: lane (l31, hi) reads k-chunk 2 kk + hi of row (wave's 32 rows) + l31
-    const int arow = wm * 32 + l31, brow = wn * 32 + l31;
-    const int asw = (arow >> 1) & 7, bsw = (brow >> 1) & 7;
-    float ln_mu = 0.0f, ln_rs = 1.0f;
-    if constexpr (ALN) {
-        const float2 st2 = g.ln_stats[min(m0 + arow, g.M - 1)];
-        ln_mu = st2.x;
-        ln_rs = st2.y;
-    }
-    f32x16 acc;
+        const unsigned da = __builtin_amdgcn_readfirstlane(lds_a + buf * CHA * 4), dw = __builtin_amdgcn_readfirstlane(lds_w + buf * CHW * 4);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        for (int j = 0; j < 2 * WM; ++j) pd_dma_piece(ab, oa[j], da + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 2 * WN; ++j) pd_dma_piece(wb, ow[j], dw + j * 1024);
+    };
+    // fragments: lane (l31, hi) reads k-chunk 2 kk + hi of row (wave's rows) + 32 mi + l31; the swizzle term (row >> 1) & 7 is that of l31
+    const int arow = wm * 32 * WM + l31, brow = wn * 32 * WN + l31, sw = (l31 >> 1) & 7;
+    float ln_mu[WM], ln_rs[WM];
+    if constexpr (ALN) {
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+            const float2 st2 = g.ln_stats[min(m0 + arow + 32 * mi, g.M - 1)];
+            ln_mu[mi] = st2.x;
+            ln_rs[mi] = st2.y;
+        }
+    }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.0f;
     const int nk = g.K / KC;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
         stage(min(kc + 1, nk - 1), (kc + 1) & 1);       // (the chunk after the last is the last again: the loop body stays straight-line)
-        const float *a = As + (kc & 1) * CH + arow * KC, *b = Ws + (kc & 1) * CH + brow * KC;
+        const float *a = As + (kc & 1) * CHA + arow * KC, *b = Ws + (kc & 1) * CHW + brow * KC;
 #pragma unroll
         for (int kk = 0; kk < KC / 8; ++kk) {
-            float4 af = *(const float4 *)(a + 4 * ((2 * kk + hi) ^ asw));
-            const float4 bf = *(const float4 *)(b + 4 * ((2 * kk + hi) ^ bsw));
-            if constexpr (ALN) {
-                af.x = (af.x - ln_mu) * ln_rs;
-                af.y = (af.y - ln_mu) * ln_rs;
-                af.z = (af.z - ln_mu) * ln_rs;
-                af.w = (af.w - ln_mu) * ln_rs;
+            const int so = 4 * ((2 * kk + hi) ^ sw);
+            float4 af[WM], bf[WN];
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) {
+                af[mi] = *(const float4 *)(a + mi * 32 * KC + so);
+                if constexpr (ALN) {
+                    af[mi].x = (af[mi].x - ln_mu[mi]) * ln_rs[mi];
+                    af[mi].y = (af[mi].y - ln_mu[mi]) * ln_rs[mi];
+                    af[mi].z = (af[mi].z - ln_mu[mi]) * ln_rs[mi];
+                    af[mi].w = (af[mi].w - ln_mu[mi]) * ln_rs[mi];
+                }
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) bf[ni] = *(const float4 *)(b + ni * 32 * KC + so);
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+                }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk has landed in the other buffer
         __syncthreads();
     }
-    {
-        const int col = n0 + wn * 32 + l31, r0 = m0 + wm * 32 + 4 * hi;
-        const float bias = g.bias[col];
-        float res[16];
-        if constexpr (EPI == 2) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) res[i] = g.C[(size_t)min(r0 + (i & 3) + 8 * (i >> 2), g.M - 1) * g.Nout + col];
-        }
+    for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = r0 + (i & 3) + 8 * (i >> 2);
-            float v = acc[i] + bias;
-            if constexpr (EPI == 1) v = fmaxf(v, 0.0f);
-            if constexpr (EPI == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-            if constexpr (EPI == 2) v += res[i];
-            if (row < g.M) g.C[(size_t)row * g.Nout + col] = v;
+        for (int ni = 0; ni < WN; ++ni) {
+            const int col = n0 + (wn * WN + ni) * 32 + l31, r0 = m0 + (wm * WM + mi) * 32 + 4 * hi;
+            const float bias = g.bias[col];
+            float res[16];
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) res[i] = g.C[(size_t)min(r0 + (i & 3) + 8 * (i >> 2), g.M - 1) * g.Nout + col];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = r0 + (i & 3) + 8 * (i >> 2);
+                float v = acc[mi][ni][i] + bias;
+                if constexpr (EPI == 1) v = fmaxf(v, 0.0f);
+                if constexpr (EPI == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                if constexpr (EPI == 2) v += res[i];
+                if (row < g.M) g.C[(size_t)row * g.Nout + col] = v;
+            }
         }
-    }
 }
 
-template <int EPI, bool ALN = false>
+template <int EPI, bool ALN = false, int WM = 1, int WN = 1>
 static inline void pd_gemm_dma(const float *A, int lda, const float *W, int K, const float *bias, float *C, int M, int Nout, hipStream_t s,
                                const float2 *ln_stats = nullptr) {
     PdStreamArgs g{A, W, bias, C, M, Nout, K, lda, K, ln_stats};
-    hipLaunchKernelGGL((pd_gemm_dma_kernel<EPI, ALN>), dim3(((M + 63) / 64) * (Nout / 64)), dim3(256), (size_t)4 * 64 * 32 * sizeof(float), s, g);
+    hipLaunchKernelGGL((pd_gemm_dma_kernel<EPI, ALN, WM, WN>), dim3(((M + 64 * WM - 1) / (64 * WM)) * (Nout / (64 * WN))), dim3(256),
+                       (size_t)2 * (64 * WM + 64 * WN) * 32 * sizeof(float), s, g);
 }
 
 #define PD_STREAM_MIN_ROWS 1024

@@ -129,6 +129,7 @@ struct pd_engine {
     PdDenoiserDev *den = nullptr;
     // schedule tables (host copies; kernels take the per-step scalars by value)
     std::vector<float> c_recip, c_recipm1, coef1, coef2, logvar;
+    int pred_x0 = 0;                      // pd_weights.reserved & PD_WEIGHTS_PRED_X0
     // GGS
     std::vector<PdSeqHost> seqs;
     PdSeqDesc *d_seqs = nullptr;         // [max_B] device copy of the descriptors

@@ -6,6 +6,7 @@ The loop itself -- 100 denoiser evaluations, posterior updates and (when cond_fn
 GGS partial) the 7000 guided iterations -- runs as one hipGraph replay of hand-written kernels.
 Training (`forward`/`p_losses`, :308-332) is out of scope and raises."""
 import os
+from collections import namedtuple
 
 import torch
 from torch import nn
@@ -14,14 +15,21 @@ from posediffusion_amd import host
 from posediffusion_amd.schedule import BUFFER_NAMES, diffusion_buffers
 
 
+ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start"])      # gaussian_diffuser.py:34
+
+
+def _at(table, t, like):
+    """table[t] broadcast over the trailing axes of ``like`` (the reference's ``extract``, :49-52); t: int or LongTensor [B]."""
+    t = torch.as_tensor(t, device=table.device, dtype=torch.long).reshape(-1)
+    return table[t].reshape((-1,) + (1,) * (like.dim() - 1))
+
+
 class GaussianDiffusion(nn.Module):
     def __init__(self, timesteps=100, sampling_timesteps=None, beta_1=0.0001, beta_T=0.1, loss_type="l1",
                  objective="pred_noise", beta_schedule="custom", p2_loss_weight_gamma=0.0, p2_loss_weight_k=1):
         super().__init__()
         if objective not in {"pred_noise", "pred_x0"}:
             raise AssertionError("objective must be either pred_noise (predict noise) or pred_x0 (predict image start)")
-        if objective != "pred_noise":
-            raise NotImplementedError("the HIP engine implements objective='pred_noise' (cfgs/default.yaml)")
         self.objective, self.loss_type, self.beta_schedule = objective, loss_type, beta_schedule
         self.timesteps, self.beta_1, self.beta_T = timesteps, beta_1, beta_T
         bufs = diffusion_buffers(beta_schedule, timesteps, beta_1, beta_T, p2_loss_weight_gamma, p2_loss_weight_k)
@@ -33,6 +41,37 @@ class GaussianDiffusion(nn.Module):
         self.model = None          # the Denoiser, assigned after construction (pose_diffusion_model.py:61)
         self.use_graph = os.environ.get("PD_USE_GRAPH", "1") != "0"
         self.last_ggs_stats = None
+
+    # ---- schedule helpers (:190-216): elementwise on the buffers, same names and argument order; the sampler itself has these
+    # fused into pd_tail_kernel and does not call them
+    def predict_start_from_noise(self, x_t, t, noise):
+        return _at(self.sqrt_recip_alphas_cumprod, t, x_t) * x_t - _at(self.sqrt_recipm1_alphas_cumprod, t, x_t) * noise
+
+    def predict_noise_from_start(self, x_t, t, x0):
+        return (_at(self.sqrt_recip_alphas_cumprod, t, x_t) * x_t - x0) / _at(self.sqrt_recipm1_alphas_cumprod, t, x_t)
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = _at(self.posterior_mean_coef1, t, x_t) * x_start + _at(self.posterior_mean_coef2, t, x_t) * x_t
+        return mean, _at(self.posterior_variance, t, x_t), _at(self.posterior_log_variance_clipped, t, x_t)
+
+    def q_sample(self, x_start, t, noise=None):
+        noise = torch.randn_like(x_start) if noise is None else noise
+        return _at(self.sqrt_alphas_cumprod, t, x_start) * x_start + _at(self.sqrt_one_minus_alphas_cumprod, t, x_start) * noise
+
+    def model_predictions(self, x, t, z, x_self_cond=None):
+        """(:218-229) one denoiser evaluation on the engine; the pair (pred_noise, pred_x_start) by the objective."""
+        out = self.model(x, t, z)
+        if self.objective == "pred_noise":
+            return ModelPrediction(out, self.predict_start_from_noise(x, t, out))
+        return ModelPrediction(self.predict_noise_from_start(x, t, out), out)
+
+    @property
+    def loss_fn(self):                                              # :334-341
+        if self.loss_type == "l1":
+            return nn.functional.l1_loss
+        if self.loss_type == "l2":
+            return nn.functional.mse_loss
+        raise ValueError(f"invalid loss type {self.loss_type}")
 
     # ---- step-level pieces (same names as the reference) ------------------------------------
     def p_mean_variance(self, x, t, z, x_self_cond=None, clip_denoised=False):

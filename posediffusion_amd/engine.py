@@ -40,7 +40,9 @@ class PoseEngine:
     (``time_embed.linear.0.weight`` ... ``_last.3.bias``); ``tables`` the GaussianDiffusion buffers."""
 
     def __init__(self, denoiser_sd: Dict[str, torch.Tensor], tables: Dict[str, torch.Tensor], device=None,
-                 max_B: int = 8, max_N: int = 20, num_layers: int = 8, nhead: int = 4):
+                 max_B: int = 8, max_N: int = 20, num_layers: int = 8, nhead: int = 4, objective: str = "pred_noise"):
+        if objective not in ("pred_noise", "pred_x0"):                     # models/gaussian_diffuser.py:105-108
+            raise AssertionError("objective must be either pred_noise (predict noise) or pred_x0 (predict image start)")
         if not torch.cuda.is_available():
             raise RuntimeError("posediffusion_amd.PoseEngine needs an AMD GPU (torch.cuda unavailable); "
                                "there is no CPU fallback for the sampling path")
@@ -67,6 +69,8 @@ class PoseEngine:
         w.n_harmonic = 10
         w.z_dim = sd["_first.weight"].shape[1] - (9 * 21 + w.t_emb_dim // 2 + 1)
         w.timesteps = int(tables[_TABLES[0]].shape[0])
+        w.reserved = _lib.PD_WEIGHTS_PRED_X0 if objective == "pred_x0" else 0
+        self.objective = objective
         w.time_w0, w.time_b0 = dev(sd["time_embed.linear.0.weight"]), dev(sd["time_embed.linear.0.bias"])
         w.time_w2, w.time_b2 = dev(sd["time_embed.linear.2.weight"]), dev(sd["time_embed.linear.2.bias"])
         w.first_w, w.first_b = dev(sd["_first.weight"]), dev(sd["_first.bias"])

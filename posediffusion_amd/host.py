@@ -44,8 +44,9 @@ def get_engine(denoiser: torch.nn.Module, diffuser: Optional[torch.nn.Module], B
     ent = cache.get("e")
     # Denoiser.forward alone (diffuser None) never needs the schedule tables: any engine built from
     # these weights serves it.  With a diffuser the tables must match too.
+    objective = getattr(diffuser, "objective", None)           # Denoiser.forward alone does not depend on it
     if ent is not None and ent[0][0] == fp_den and (fp_diff is None or ent[0][1] == fp_diff) \
-            and ent[1].max_B >= B and ent[1].max_N >= N:
+            and ent[1].max_B >= B and ent[1].max_N >= N and objective in (None, ent[1].objective):
         return ent[1]
     if ent is not None:
         B, N = max(B, ent[1].max_B), max(N, ent[1].max_N)     # never shrink capacity on a rebuild
@@ -59,7 +60,7 @@ def get_engine(denoiser: torch.nn.Module, diffuser: Optional[torch.nn.Module], B
     layers = len(denoiser._trunk.layers)
     nhead = denoiser._trunk.layers[0].self_attn.num_heads
     eng = PoseEngine(denoiser_state(denoiser), tables, device=dev, max_B=max(B, 1), max_N=max(N, 1),
-                     num_layers=layers, nhead=nhead)
+                     num_layers=layers, nhead=nhead, objective=objective or "pred_noise")
     cache["e"] = (fp, eng)
     _ENGINES[dev.index if dev.index is not None else torch.cuda.current_device()] = eng
     return eng

@@ -120,3 +120,56 @@ def test_lane_kernel_in_the_sampler_graph_replay_and_free_running_criterion(engi
     for dev, ref_dev, gap, ref_gap in rows:
         assert dev <= 2.0 * ref_dev, rows
         assert gap <= max(0.01, 2.0 * worst_ref_gap), rows
+
+
+def test_objective_pred_x0_against_reference_fixture(golden):
+    """GaussianDiffusion(objective="pred_x0") (models/gaussian_diffuser.py:105-108, :225-227; VERDICT round 2, missing item 6) through
+    the drop-in module: p_sample at five steps and every step of the reference's own 100-step trajectory teacher-forced (2e-5), the
+    free-running sampler over the first 70 steps (after which iterating an UNTRAINED network as its own x_start amplifies rounding
+    about 10 x per step: the reference's fp32 run is 0.15 away from fp64 at step 100), model_predictions, and the engine rebuilt when
+    only the objective changes."""
+    GaussianDiffusion = synth._dropin().GaussianDiffusion
+    d = golden["pred_x0"]
+    base = synth.make_diffuser(seed=0)                   # a private copy of the fixture weights: the session's engine stays untouched
+    synth.randomize_norm_and_bias_(base.model)
+    base = base.to(DEV)
+    den = base.model
+    diff = GaussianDiffusion(beta_schedule="custom", objective="pred_x0").to(DEV)
+    diff.model = den
+    x, z = torch.from_numpy(d["x"]).to(DEV), torch.from_numpy(d["z"]).to(DEV)
+    for t in (99, 50, 10, 1, 0):
+        torch.manual_seed(0)
+        mean, _, logvar, x0 = diff.p_mean_variance(x, torch.full((2,), t, dtype=torch.long, device=DEV), z)
+        assert rel_err(x0, d[f"ps_x0_t{t}"]) < TOL
+        pred = mean.cpu().double() + np.exp(0.5 * float(logvar.reshape(-1)[0])) * torch.from_numpy(d[f"ps_noise_t{t}"]).double()
+        assert rel_err(pred, d[f"ps_pred_t{t}"]) < TOL
+    eng = den._pd_engine_cache["e"][1]
+    assert eng.objective == "pred_x0"
+    mp = diff.model_predictions(x, torch.full((2,), 50, dtype=torch.long, device=DEV), z)
+    assert rel_err(mp.pred_x_start, d["mp_x0_t50"]) < TOL and rel_err(mp.pred_noise, d["mp_noise_t50"]) < 5 * TOL
+    # teacher-forced along the reference's trajectory
+    proc, noise, zt = torch.from_numpy(d["traj_process"]).to(DEV), torch.from_numpy(d["traj_noise"]).to(DEV), torch.from_numpy(d["traj_z"]).to(DEV)
+    worst = 0.0
+    for step in range(100):
+        t = 99 - step
+        mean, _ = eng.p_mean(proc[step], zt, t)
+        nxt = eng.p_finish(mean, noise[step + 1] if t > 0 else None, t)
+        worst = max(worst, rel_err(nxt, proc[step + 1]))
+    # free-running: hipGraph replay == eager, and the chaos-free prefix against the fp64 oracle / the reference's fp32
+    pose_g, process_g, _ = eng.sample(zt, noise, use_graph=True)
+    pose_e, process_e, _ = eng.sample(zt, noise, use_graph=False)
+    eng.check_async()
+    assert torch.equal(process_g, process_e) and torch.equal(pose_g, process_g[-1])
+    p64 = torch.from_numpy(d["traj_process64"])
+    dev = (process_g.cpu().double() - p64).abs().amax(dim=(1, 2, 3))
+    ref_dev = (proc.cpu().double() - p64).abs().amax(dim=(1, 2, 3))
+    print(f"objective pred_x0: teacher-forced worst {worst:.2e}; free-running |engine - fp64| at steps 50/70/100: {dev[50]:.2e} {dev[70]:.2e} {dev[100]:.2e} "
+          f"(reference fp32: {ref_dev[50]:.2e} {ref_dev[70]:.2e} {ref_dev[100]:.2e})")
+    assert worst < TOL
+    assert dev[:71].max() <= max(2.0 * float(ref_dev[:71].max()), 1e-5)
+    # the default objective again: the cached engine must be rebuilt (the tail kernel's formula differs), and agree with its fixture
+    g = golden["denoiser"]
+    xb, zb = torch.from_numpy(g["b2n20_x"]).to(DEV), torch.from_numpy(g["b2n20_z"]).to(DEV)
+    _, _, _, x0 = base.p_mean_variance(xb, torch.full((2,), 50, dtype=torch.long, device=DEV), zb)
+    assert den._pd_engine_cache["e"][1].objective == "pred_noise" and rel_err(x0, g["ps_x0_t50"]) < TOL
+    den._pd_engine_cache["e"][1].close()

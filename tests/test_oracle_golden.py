@@ -8,6 +8,7 @@ import torch
 from conftest import rel_err
 from oracle import pd_oracle as O
 from oracle import ref_stubs as RS
+from posediffusion_amd import synth
 
 FLAGS = {"all": (True, True, True), "fl": (False, False, True), "r": (True, False, False), "t": (False, True, False)}
 
@@ -40,6 +41,41 @@ def test_p_sample_golden(golden, oracle_weights):
         pred, x0 = O.p_sample(oracle_weights, tables, x, t, z, noise if t > 0 else None)
         assert rel_err(pred, d[f"ps_pred_t{t}"]) < 5e-6
         assert rel_err(x0, d[f"ps_x0_t{t}"]) < 5e-6
+
+
+def test_objective_pred_x0_golden(golden, oracle_weights, seeded_diffuser):
+    """GaussianDiffusion(objective="pred_x0") (models/gaussian_diffuser.py:225-227): the oracle's p_sample against the reference's
+    at five steps and teacher-forced along the reference's whole trajectory; the drop-in module's schedule helpers
+    (predict_noise_from_start / predict_start_from_noise / q_posterior, :190-209) against the reference's model_predictions pair."""
+    d = golden["pred_x0"]
+    tables = O.diffusion_tables()
+    x, z = torch.from_numpy(d["x"]), torch.from_numpy(d["z"])
+    for t in (99, 50, 10, 1, 0):
+        pred, x0 = O.p_sample(oracle_weights, tables, x, t, z, torch.from_numpy(d[f"ps_noise_t{t}"]) if t > 0 else None, objective="pred_x0")
+        assert rel_err(pred, d[f"ps_pred_t{t}"]) < 5e-6 and rel_err(x0, d[f"ps_x0_t{t}"]) < 5e-6
+    proc, noise, zt = torch.from_numpy(d["traj_process"]), torch.from_numpy(d["traj_noise"]), torch.from_numpy(d["traj_z"])
+    for step in list(range(0, 100, 10)) + [99]:
+        t = 99 - step
+        nxt, _ = O.p_sample(oracle_weights, tables, proc[step], t, zt, noise[step + 1] if t > 0 else None, objective="pred_x0")
+        assert rel_err(nxt, proc[step + 1]) < 5e-6
+    # iterating an untrained network as its own x_start is chaotic over the last ~25 steps (fp32 vs fp64: 5e-6 at step 70, 0.15 at
+    # step 100): the free-running comparison of tests/test_gpu_parity_r3.py stops at step 70
+    dev = np.abs(d["traj_process"].astype(np.float64) - d["traj_process64"]).max(axis=(1, 2, 3))
+    assert dev[70] < 2e-5 and dev[100] > 1e-3
+    # the drop-in module's helpers, on the CPU (they are plain buffer arithmetic; the sampler fuses them into pd_tail_kernel)
+    GaussianDiffusion = synth._dropin().GaussianDiffusion
+    diff = GaussianDiffusion(beta_schedule="custom", objective="pred_x0")
+    tt = torch.full((x.shape[0],), 50, dtype=torch.long)
+    x0 = torch.from_numpy(d["mp_x0_t50"])
+    pn = diff.predict_noise_from_start(x, tt, x0)
+    assert rel_err(pn, d["mp_noise_t50"]) < 1e-6
+    assert rel_err(diff.predict_start_from_noise(x, tt, pn), x0) < 1e-5
+    assert rel_err(diff.predict_start_from_noise(x, 50, pn), x0) < 1e-5                     # an int t is accepted as well
+    mean, var, logvar = diff.q_posterior(x0, x, tt)
+    assert rel_err(mean, d["ps_pred_t50"] - np.exp(0.5 * float(logvar[0, 0, 0])) * d["ps_noise_t50"]) < 1e-5
+    assert mean.shape == x.shape and var.shape == (2, 1, 1) and diff.loss_fn is torch.nn.functional.l1_loss
+    xs = diff.q_sample(x0, tt, noise=torch.zeros_like(x0))
+    assert rel_err(xs, float(diff.sqrt_alphas_cumprod[50]) * x0) < 1e-6
 
 
 def _pm(g, prefix=""):

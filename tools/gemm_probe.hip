@@ -32,15 +32,16 @@ static float run(const float *A, const float *W, const float *bias, float *C, in
     return ms / reps;
 }
 
-template <int EPI, bool ALN>
+template <int EPI, bool ALN, int WM = 1, int WN = 1>
 static float run_dma(const float *A, const float *W, const float *bias, float *C, int M, int Nout, int K, int reps, hipStream_t s) {
     static float2 *stats = nullptr;
     if (!stats) (void)hipMalloc(&stats, 15360 * sizeof(float2));
     PdStreamArgs g{A, W, bias, C, M, Nout, K, K, K, stats};
     if (ALN) hipLaunchKernelGGL(pd_ln_stats_kernel<512>, dim3((M + 3) / 4), dim3(256), 0, s, A, stats, M, 1e-5f);
-    const size_t lds = (size_t)4 * 64 * 32 * sizeof(float);
-    auto kern = pd_gemm_dma_kernel<EPI, ALN>;
-    const int grid = ((M + 63) / 64) * (Nout / 64);
+    const size_t lds = (size_t)2 * (64 * WM + 64 * WN) * 32 * sizeof(float);
+    auto kern = pd_gemm_dma_kernel<EPI, ALN, WM, WN>;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int grid = ((M + 64 * WM - 1) / (64 * WM)) * (Nout / (64 * WN));
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
@@ -54,10 +55,10 @@ static float run_dma(const float *A, const float *W, const float *bias, float *C
     return ms / reps;
 }
 // C of the LDS-DMA kernel against C of the register-staged kernel on the same inputs: must be bitwise equal (EPI 0 / 1: C is not an input)
-template <int EPI, bool ALN>
+template <int EPI, bool ALN, int WM = 1, int WN = 1>
 static long long diff_dma(const float *A, const float *W, const float *bias, float *C, float *C2, int M, int Nout, int K, hipStream_t s) {
     run<EPI, 1, 1, ALN>(A, W, bias, C, M, Nout, K, 1, s);
-    run_dma<EPI, ALN>(A, W, bias, C2, M, Nout, K, 1, s);
+    run_dma<EPI, ALN, WM, WN>(A, W, bias, C2, M, Nout, K, 1, s);
     (void)hipStreamSynchronize(s);
     std::vector<float> a((size_t)M * Nout), b((size_t)M * Nout);
     (void)hipMemcpy(a.data(), C, a.size() * 4, hipMemcpyDeviceToHost);
@@ -117,6 +118,19 @@ int main(int argc, char **argv) {
         printf("LDS-DMA staging (pd_gemm_dma_kernel) vs register staging, 64x64 tiles; elements that differ: QKV+LN %lld, FF1+LN %lld, plain 512->512 %lld, ragged 5000 rows %lld\n",
                diff_dma<0, true>(A, W, bias, C, C2, 5120, 1536, 512, s), diff_dma<1, true>(A, W, bias, C, C2, 5120, 1024, 512, s),
                diff_dma<0, false>(A, W, bias, C, C2, 5120, 512, 1024, s), diff_dma<0, false>(A, W, bias, C, C2, 5000, 512, 512, s));
+        printf("LDS-DMA tiles 128x64 / 64x128 / 128x128 vs 64x64, elements that differ: %lld %lld %lld (QKV+LN), %lld (ragged 5000 rows, 128x128)\n",
+               diff_dma<0, true, 2, 1>(A, W, bias, C, C2, 5120, 1536, 512, s), diff_dma<0, true, 1, 2>(A, W, bias, C, C2, 5120, 1536, 512, s),
+               diff_dma<0, true, 2, 2>(A, W, bias, C, C2, 5120, 1536, 512, s), diff_dma<0, false, 2, 2>(A, W, bias, C, C2, 5000, 512, 512, s));
+        for (int M : {5120, 15360}) {
+            const double q = 2.0 * M * 1536 * 512 * 1e-9, f1 = 2.0 * M * 1024 * 512 * 1e-9, f2 = 2.0 * M * 512 * 1024 * 1e-9;
+            printf("  %5d rows, LDS-DMA TFLOP/s 64x64 / 128x64 / 64x128 / 128x128:  QKV+LN %5.1f %5.1f %5.1f %5.1f   FF1+LN %5.1f %5.1f %5.1f %5.1f   FF2 %5.1f %5.1f %5.1f %5.1f\n", M,
+                   q / run_dma<0, true>(A, W, bias, C, M, 1536, 512, 20, s), q / run_dma<0, true, 2, 1>(A, W, bias, C, M, 1536, 512, 20, s),
+                   q / run_dma<0, true, 1, 2>(A, W, bias, C, M, 1536, 512, 20, s), q / run_dma<0, true, 2, 2>(A, W, bias, C, M, 1536, 512, 20, s),
+                   f1 / run_dma<1, true>(A, W, bias, C, M, 1024, 512, 20, s), f1 / run_dma<1, true, 2, 1>(A, W, bias, C, M, 1024, 512, 20, s),
+                   f1 / run_dma<1, true, 1, 2>(A, W, bias, C, M, 1024, 512, 20, s), f1 / run_dma<1, true, 2, 2>(A, W, bias, C, M, 1024, 512, 20, s),
+                   f2 / run_dma<2, false>(A, W, bias, C, M, 512, 1024, 20, s), f2 / run_dma<2, false, 2, 1>(A, W, bias, C, M, 512, 1024, 20, s),
+                   f2 / run_dma<2, false, 1, 2>(A, W, bias, C, M, 512, 1024, 20, s), f2 / run_dma<2, false, 2, 2>(A, W, bias, C, M, 512, 1024, 20, s));
+        }
         for (int M : {5120, 15360}) {
             const double q = 2.0 * M * 1536 * 512 * 1e-9, f1 = 2.0 * M * 1024 * 512 * 1e-9, o = 2.0 * M * 512 * 512 * 1e-9, f2 = 2.0 * M * 512 * 1024 * 1e-9;
             printf("  %5d rows, TFLOP/s register -> LDS-DMA:  QKV+LN %5.1f -> %5.1f   FF1+LN %5.1f -> %5.1f   out %5.1f -> %5.1f   FF2 %5.1f -> %5.1f\n", M,
