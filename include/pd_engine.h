@@ -199,12 +199,18 @@ int pd_ggs_loss_grad(pd_engine *eng, const float *x, int B, int N, int update_R,
 /* ---- whole sampler ------------------------------------------------------------------------ */
 
 /* Engine options (no reference counterpart).
- *   PD_OPT_DENOISER_SPLIT  0 (default): every GEMM of the denoiser on the exact-fp32 matrix instruction.
- *        1: FAST MODE for batches of >= 1024 token rows: the four Linear layers of every encoder layer run in split precision
+ *   PD_OPT_DENOISER_SPLIT  how the four Linear layers of every encoder layer run for batches of >= 1024 token rows (smaller
+ *        batches always use the exact-fp32 matrix instruction).  Default: 2 on engines created with max_B x max_N >= 1024, else 0.
+ *        0: every GEMM of the denoiser on the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32).
+ *        1: FAST MODE: the four Linear layers of every encoder layer run in split precision
  *        on the bf16 matrix pipe (each fp32 operand as bf16 hi + bf16 lo, three products, fp32 accumulation: ~16 mantissa
  *        bits per operand); LayerNorm, softmax, residuals, `_first`, `_last` and the DDPM update stay fp32.  Narrower
  *        arithmetic than the reference's: a separately reported mode, never the default (deviation measured in
- *        tests/test_gpu_parity_r2.py and profiles/round2_denoiser_precision_study.json).  Smaller batches ignore it. */
+ *        tests/test_gpu_parity_r2.py and profiles/round2_denoiser_precision_study.json).  Smaller batches ignore it.
+ *        2: the same kernels with FP16 halves (11 + 11 = 22 mantissa bits per operand, the dropped lo*lo term is 2^-22 of a
+ *        product, fp32 accumulation) and power-of-two operand scales fixed at the switch from bounds that hold for every input
+ *        (LayerNorm output <= sqrt(d); a Linear fed by it <= sqrt(d) ||w|| + |b|): no overflow, no underflow, and results as
+ *        close to the fp64 product as the exact-fp32 instruction's (tests/test_gpu_parity_r3.py).  Same batches as 1. */
 #define PD_OPT_DENOISER_SPLIT 2
 int pd_engine_set_option(pd_engine *eng, int option, int value);
 

@@ -423,8 +423,9 @@ __global__ __launch_bounds__(256) void pd_attn_kernel(const float *__restrict__ 
 // all of them and their serial fmaf chains (128 deep for a score) interleave -- a wave with one row at a time is bound by exactly that
 // chain's latency.  Per row the arithmetic is pd_attn_kernel's, operation for operation: the same bits.
 #define PD_ATTN_RPW 5
-template <bool SPLIT_OUT>
-__global__ __launch_bounds__(256) void pd_attn_seq_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int N) {
+// SPLIT_OUT: 0 fp32, 1 bf16 split words, 2 fp16 split words of ctx * out_scale (pd_split_word_as)
+template <int SPLIT_OUT>
+__global__ __launch_bounds__(256) void pd_attn_seq_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int N, float out_scale) {
     constexpr int LD = DH + 4, R = PD_ATTN_RPW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Kk = lds, *V = Kk + N * LD, *Q = V + N * LD, *P = Q + N * LD;   // P [4 waves][R][64]
@@ -491,9 +492,9 @@ __global__ __launch_bounds__(256) void pd_attn_seq_kernel(const float *__restric
             const int i = ib + t;
             if (i < N) {
                 float *out = ctx + (size_t)(b * N + i) * DM + h * DH;
-                if constexpr (SPLIT_OUT) {
-                    ((unsigned *)out)[lane] = pd_split_word(o0[t]);
-                    ((unsigned *)out)[64 + lane] = pd_split_word(o1[t]);
+                if constexpr (SPLIT_OUT != 0) {
+                    ((unsigned *)out)[lane] = pd_split_word_as<SPLIT_OUT>(o0[t], out_scale);
+                    ((unsigned *)out)[64 + lane] = pd_split_word_as<SPLIT_OUT>(o1[t], out_scale);
                 } else {
                     out[lane] = o0[t];
                     out[64 + lane] = o1[t];
@@ -710,16 +711,95 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(set_lds(pd_gemm_kernel<DM, 0, 0, 16>, 32 * (DM + 4) * 4));
     PD_TRY(set_lds(pd_attn_kernel<false>, ((2 * 64 + 4) * (DH + 4) + 4 * 64) * 4));
     PD_TRY(set_lds(pd_attn_kernel<true>, ((2 * 64 + 4) * (DH + 4) + 4 * 64) * 4));
-    PD_TRY(set_lds(pd_attn_seq_kernel<false>, attn_seq_lds(64)));
-    PD_TRY(set_lds(pd_attn_seq_kernel<true>, attn_seq_lds(64)));
+    PD_TRY(set_lds(pd_attn_seq_kernel<0>, attn_seq_lds(64)));
+    PD_TRY(set_lds(pd_attn_seq_kernel<1>, attn_seq_lds(64)));
+    PD_TRY(set_lds(pd_attn_seq_kernel<2>, attn_seq_lds(64)));
     PD_HIP_CHECK(hipDeviceSynchronize());
     return PD_OK;
 }
 
 // The fast mode's weights: every encoder Linear split into bf16 hi / lo in MFMA fragment order (LayerNorm scale folded as for
 // the other packings).  Built when the mode is first switched on, from the row-major fp32 copies kept for the streamed GEMMs.
-int pd_denoiser_build_split(pd_engine *eng) {
+// mode 2, fp16 planes: fp16 keeps 11 bits and five exponent bits, so every operand gets a POWER-OF-TWO scale (exact to apply and
+// to undo) fixed here from bounds that hold for every input:
+//   * LayerNorm output without affine: sum of squares <= D, so |x^| <= sqrt(D) = 22.6;           scale 2^9  (<= 11 585)
+//   * a Linear fed by it:  |x^ . w + b| <= sqrt(D) ||w||_2 + |b|   (Cauchy-Schwarz) -- the V rows the attention averages
+//     (a convex combination: same bound) and the FF hidden rows after ReLU;                       scale 2^floor(log2(32768 / bound))
+//   * weights: 2^floor(log2(16384 / max |w|)).
+// Nothing can overflow (fp16 max 65 504), and hi + lo keeps 22 bits for every value above 2^-18 of its bound.
+static int floor_log2_ratio(double cap, double v) {
+    if (!(v > 0.0)) return 0;
+    int e = (int)floor(log2(cap / v));
+    return e < -60 ? -60 : (e > 60 ? 60 : e);
+}
+static int pd_denoiser_build_split_h(pd_engine *eng) {
     PdDenoiserDev *d = eng->den;
+    if (d->split_h_ready) return PD_OK;
+    std::vector<float> w, b;
+    auto fetch = [&](const float *Wf, const float *bias, int Nout, int K) -> int {
+        w.resize((size_t)Nout * K);
+        b.resize(Nout);
+        PD_HIP_CHECK(hipMemcpy(w.data(), Wf, w.size() * sizeof(float), hipMemcpyDeviceToHost));
+        PD_HIP_CHECK(hipMemcpy(b.data(), bias, b.size() * sizeof(float), hipMemcpyDeviceToHost));
+        return PD_OK;
+    };
+    auto max_abs = [&]() { double m = 0; for (float v : w) m = fmax(m, fabs((double)v)); return m; };
+    auto row_bound = [&](int r0, int r1, int K) {            // max over rows of sqrt(D) ||w_r||_2 + |b_r|
+        double bound = 0;
+        for (int r = r0; r < r1; ++r) {
+            double q = 0;
+            for (int k = 0; k < K; ++k) q += (double)w[(size_t)r * K + k] * w[(size_t)r * K + k];
+            bound = fmax(bound, sqrt((double)DM) * sqrt(q) + fabs((double)b[r]));
+        }
+        return bound;
+    };
+    auto split = [&](unsigned **dst, const float *Wf, int Nout, int K, int ew) -> int {
+        float *p = nullptr;
+        int rc = dev_alloc(d, &p, (size_t)Nout * K);
+        if (rc) return rc;
+        *dst = (unsigned *)p;
+        const size_t total = (size_t)(Nout / 32) * (K / 16) * 64;
+        hipLaunchKernelGGL(vit_frag_split_kernel, dim3(512), dim3(256), 0, 0, Wf, (const float *)nullptr, K, total, (uint4 *)p, 1, ldexpf(1.0f, ew));
+        PD_HIP_CHECK(hipGetLastError());
+        return PD_OK;
+    };
+    const int e_ln = 9;
+    for (int l = 0; l < d->num_layers; ++l) {
+        PdLayerDev &L = d->layers[l];
+        PD_TRY(fetch(L.qkv_wf, L.qkv_b, 3 * DM, DM));
+        const int e_ctx = floor_log2_ratio(32768.0, row_bound(2 * DM, 3 * DM, DM)), e_wqkv = floor_log2_ratio(16384.0, max_abs());
+        PD_TRY(split(&L.qkv_wh, L.qkv_wf, 3 * DM, DM, e_wqkv));
+        PD_TRY(fetch(L.out_wf, L.out_b, DM, DM));
+        const int e_wo = floor_log2_ratio(16384.0, max_abs());
+        PD_TRY(split(&L.out_wh, L.out_wf, DM, DM, e_wo));
+        PD_TRY(fetch(L.ff1_wf, L.ff1_b, DFF, DM));
+        const int e_ff = floor_log2_ratio(32768.0, row_bound(0, DFF, DM)), e_w1 = floor_log2_ratio(16384.0, max_abs());
+        PD_TRY(split(&L.ff1_wh, L.ff1_wf, DFF, DM, e_w1));
+        PD_TRY(fetch(L.ff2_wf, L.ff2_b, DM, DFF));
+        const int e_w2 = floor_log2_ratio(16384.0, max_abs());
+        PD_TRY(split(&L.ff2_wh, L.ff2_wf, DM, DFF, e_w2));
+        L.qkv_cs = ldexpf(1.0f, -(e_ln + e_wqkv));
+        L.out_cs = ldexpf(1.0f, -(e_ctx + e_wo));
+        L.ff1_cs = ldexpf(1.0f, -(e_ln + e_w1));
+        L.ff2_cs = ldexpf(1.0f, -(e_ff + e_w2));
+        L.ctx_scale = ldexpf(1.0f, e_ctx);
+        L.ff_scale = ldexpf(1.0f, e_ff);
+    }
+    PD_HIP_CHECK(hipDeviceSynchronize());
+    d->split_h_ready = true;
+    return PD_OK;
+}
+
+bool pd_denoiser_has_streamed_path(const pd_engine *eng) { return eng->den && eng->den->hn; }
+
+int pd_denoiser_build_split(pd_engine *eng, int mode) {
+    PdDenoiserDev *d = eng->den;
+    if (!d->hn) {
+        pd_set_error("split-precision denoiser: the engine was created for fewer than %d token rows (max_B x max_N); the mode "
+                     "applies to the streamed large-batch path only", PD_STREAM_MIN_ROWS);
+        return PD_ERR_UNSUPPORTED;
+    }
+    if (mode == 2) return pd_denoiser_build_split_h(eng);
     if (d->split_ready) return PD_OK;
     if (!d->hn) {
         pd_set_error("split-precision denoiser: the engine was created for fewer than %d token rows (max_B x max_N); the mode "
@@ -799,14 +879,26 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     // into the weights, as below).
     for (int l = 0; l < d->num_layers; ++l) {
         const PdLayerDev &L = d->layers[l];
-        if (streamed && eng->den_split && d->split_ready) {
+        if (streamed && eng->den_split == 2 && d->split_h_ready) {
+            // fp16-plane mode: the fast mode's kernels with fp16 halves and the static power-of-two scales of pd_denoiser_build_split_h
+            // (22 mantissa bits, fp32 accumulation: fp32-grade results at the three-product rate)
+            hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 2>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 512.0f);
+            pd_gemm_split<0, 1, 2, true>((const unsigned *)d->hn, DM, L.qkv_wh, DM, L.qkv_b, d->qkv, M, 3 * DM, s, L.qkv_cs);
+            hipLaunchKernelGGL(pd_attn_seq_kernel<2>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
+            pd_gemm_split<2, 1, 1, true>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 2>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 512.0f);
+            pd_gemm_split<4, 1, 2, true>((const unsigned *)d->hn, DM, L.ff1_wh, DM, L.ff1_b, d->ff, M, DFF, s, L.ff1_cs, L.ff_scale);
+            pd_gemm_split<2, 1, 1, true>((const unsigned *)d->ff, DFF, L.ff2_wh, DFF, L.ff2_b, d->h, M, DM, s, L.ff2_cs);
+            continue;
+        }
+        if (streamed && eng->den_split == 1 && d->split_ready) {
             // fast mode: the four encoder GEMMs on the bf16 matrix pipe in split precision (pd_gemm_split.h); activations
             // between them as split words -- LayerNorm, attention and the FF1 epilogue write them in place of fp32
-            hipLaunchKernelGGL((pd_ln_rows_kernel<DM, true>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 1>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 1.0f);
             pd_gemm_split<0, 1, 2>((const unsigned *)d->hn, DM, L.qkv_ws, DM, L.qkv_b, d->qkv, M, 3 * DM, s);
-            hipLaunchKernelGGL(pd_attn_seq_kernel<true>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N);
+            hipLaunchKernelGGL(pd_attn_seq_kernel<1>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N, 1.0f);
             pd_gemm_split<2, 1, 1>((const unsigned *)d->ctx, DM, L.out_ws, DM, L.out_b, d->h, M, DM, s);
-            hipLaunchKernelGGL((pd_ln_rows_kernel<DM, true>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 1>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 1.0f);
             pd_gemm_split<4, 1, 2>((const unsigned *)d->hn, DM, L.ff1_ws, DM, L.ff1_b, d->ff, M, DFF, s);
             pd_gemm_split<2, 1, 1>((const unsigned *)d->ff, DFF, L.ff2_ws, DFF, L.ff2_b, d->h, M, DM, s);
             continue;
@@ -815,7 +907,7 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
             float2 *stats = (float2 *)d->hn;           // (mean, rstd) per token row; applied in the A staging of the next GEMM
             hipLaunchKernelGGL(pd_ln_stats_kernel<DM>, dim3((M + 3) / 4), dim3(256), 0, s, d->h, stats, M, 1e-5f);
             pd_gemm_dma<0, true>(d->h, DM, L.qkv_wf, DM, L.qkv_b, d->qkv, M, 3 * DM, s, stats);                // LayerNorm-1 at the fragment reads
-            hipLaunchKernelGGL(pd_attn_seq_kernel<false>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N);
+            hipLaunchKernelGGL(pd_attn_seq_kernel<0>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N, 1.0f);
             pd_gemm_dma<2>(d->ctx, DM, L.out_wf, DM, L.out_b, d->h, M, DM, s);
             hipLaunchKernelGGL(pd_ln_stats_kernel<DM>, dim3((M + 3) / 4), dim3(256), 0, s, d->h, stats, M, 1e-5f);
             pd_gemm_dma<1, true>(d->h, DM, L.ff1_wf, DM, L.ff1_b, d->ff, M, DFF, s, stats);                     // LayerNorm-2 likewise

@@ -34,6 +34,10 @@ struct PdLayerDev {          // [0] = 32-wide-tile packing, [1] = 16-wide-tile p
     float *ff2_wp[2], *ff2_b;
     float *qkv_wf, *out_wf, *ff1_wf, *ff2_wf;   // row-major copies (LayerNorm scale folded) for the streamed GEMM at >= 1024 token rows
     unsigned *qkv_ws, *out_ws, *ff1_ws, *ff2_ws;   // split into bf16 hi / lo in MFMA fragment order (pd_gemm_split.h): the fast mode, built on demand
+    // the fp16-plane mode (PD_OPT_DENOISER_SPLIT = 2): fp16 hi / lo of w * 2^ew in the same order, and the power-of-two scales of
+    // pd_denoiser_build_split: accumulator scales 2^-(ea + ew) per GEMM, operand scales of the attention output and the FF hidden rows
+    unsigned *qkv_wh, *out_wh, *ff1_wh, *ff2_wh;
+    float qkv_cs, out_cs, ff1_cs, ff2_cs, ctx_scale, ff_scale;
 };
 
 struct PdDenoiserDev {
@@ -47,6 +51,7 @@ struct PdDenoiserDev {
     float *hn = nullptr;               // LayerNorm(h) without affine, streamed path only
     float *emb = nullptr, *first_wf = nullptr, *last0_wf = nullptr;   // streamed path: _first's input rows [rows, 704], row-major _first / _last.0 weights
     bool split_ready = false;          // the fast mode's split weights exist
+    bool split_h_ready = false;        // the fp16-plane mode's weights and scales exist
     std::vector<void *> allocs;
 };
 

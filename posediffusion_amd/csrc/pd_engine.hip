@@ -122,6 +122,13 @@ extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_en
         if ((rc = fetch_table(eng->coef2, w->posterior_mean_coef2, w->timesteps))) break;
         if ((rc = fetch_table(eng->logvar, w->posterior_log_variance_clipped, w->timesteps))) break;
         if ((rc = pd_denoiser_create(eng, w))) break;
+        // engines large enough for the streamed path (>= 1024 token rows) run its encoder GEMMs on the fp16 matrix pipe by default:
+        // fp16 hi + lo operands, static power-of-two scales, fp32 accumulation -- as close to fp64 as the exact-fp32 instruction
+        // (tests/test_gpu_parity_r3.py, profiles/round3_fp16_plane_mode_study.json); PD_OPT_DENOISER_SPLIT = 0 selects the latter
+        if (pd_denoiser_has_streamed_path(eng)) {
+            if ((rc = pd_denoiser_build_split(eng, 2))) break;
+            eng->den_split = 2;
+        }
         if ((rc = pd_ggs_init())) break;
         if ((rc = pd_ggs_ingest_init())) break;
         eng->seqs.resize(max_B);
@@ -414,13 +421,13 @@ extern "C" int pd_engine_set_option(pd_engine *eng, int option, int value) {
     }
     switch (option) {
     case PD_OPT_DENOISER_SPLIT:
-        if (value != 0 && value != 1) {
-            pd_set_error("pd_engine_set_option: PD_OPT_DENOISER_SPLIT takes 0 or 1 (got %d)", value);
+        if (value < 0 || value > 2) {
+            pd_set_error("pd_engine_set_option: PD_OPT_DENOISER_SPLIT takes 0, 1 or 2 (got %d)", value);
             return PD_ERR_INVALID_ARG;
         }
         if (value) {
             PD_HIP_CHECK(hipSetDevice(eng->device));
-            int rc = pd_denoiser_build_split(eng);
+            int rc = pd_denoiser_build_split(eng, value);
             if (rc) return rc;
         }
         eng->den_split = value;

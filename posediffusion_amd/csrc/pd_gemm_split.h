@@ -3,6 +3,13 @@
 // x * w ~= hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (16 x the rate of the f32 instruction per product, three
 // products), fp32 accumulation.  Activations between kernels are one 32-bit word per element {hi | lo << 16}
 // (pd_split_word, pd_gemm_stream.h).
+//
+// F16 (the denoiser's fp16-plane mode): the same kernel with fp16 halves (pd_split_word_h) on v_mfma_f32_32x32x16_f16 -- 11 + 11
+// mantissa bits, the dropped lo*lo term is 2^-22 of the product: with fp32 accumulation the result is as close to the fp64 product
+// as the exact-fp32 kernel's (tools/split3_probe.hip).  fp16's narrow exponent range is handled by the caller with POWER-OF-TWO
+// scales fixed at engine creation from provable bounds on every operand (pd_denoiser_build_split): A arrives as words of
+// a * 2^ea, W was split as w * 2^ew, the epilogue multiplies the accumulator by c_scale = 2^-(ea + ew) (exact) and, where it
+// writes split words itself (EPI 3 / 4), by out_scale = 2^e of the next GEMM's operand.
 #pragma once
 #include "pd_gemm_stream.h"
 
@@ -22,7 +29,9 @@ __device__ __forceinline__ float vit_gelu_fast(float v) {
 
 // W[n][k] * gamma[k] -> split and packed in MFMA fragment order: [n / 32][k / 16][hi | lo][lane] x 16 B, lane = (n % 32) +
 // 32 * ((k / 8) % 2), 8 consecutive k per lane: one wave-wide 16-byte load is 1 KB contiguous
-static __global__ void vit_frag_split_kernel(const float *__restrict__ W, const float *__restrict__ gamma, int K, size_t total, uint4 *__restrict__ out) {
+// f16: fp16 halves of w * scale instead of bf16 halves of w
+static __global__ void vit_frag_split_kernel(const float *__restrict__ W, const float *__restrict__ gamma, int K, size_t total, uint4 *__restrict__ out,
+                                             int f16 = 0, float scale = 1.0f) {
     const int KS = K / 16;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
@@ -33,7 +42,7 @@ static __global__ void vit_frag_split_kernel(const float *__restrict__ W, const 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float v = W[(size_t)n * K + k0 + e];
-            w[e] = pd_split_word(gamma ? v * gamma[k0 + e] : v);
+            w[e] = f16 ? pd_split_word_h(v * scale) : pd_split_word(gamma ? v * gamma[k0 + e] : v);
         }
         uint4 hi, lo;
         hi.x = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u); lo.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
@@ -50,12 +59,13 @@ struct VitSplitArgs {
     const float *bias;
     void *C;                    // EPI 0 / 2: fp32 [M][Nout]; EPI 3 (gelu) / 4 (relu): split words [M][Nout]
     int M, Nout, K, lda;
+    float c_scale, out_scale;   // F16 only (see the header): accumulator scale, scale of split-word outputs
 };
 
 // A rows stream through LDS (un-zipped into hi / lo fragments on the way, shared by the waves of a row block); the weight
 // fragments go straight from global memory / L2 to registers, one chunk ahead (they are already in operand order, and
 // keeping them out of LDS halves its traffic -- the LDS array, not the matrix pipe, limited the first version).
-template <int EPI, int WM, int WN>
+template <int EPI, int WM, int WN, bool F16 = false>
 __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
     constexpr int KC = PD_STREAM_KC, LR = PD_STREAM_LR, TM = 64 * WM, TN = 64 * WN, GROUP = 2048 / TM;
     static_assert(KC == 32 && WM <= 2 && WN <= 2, "staging: 4 groups of 8 per row chunk, passes of 64 rows");
@@ -119,13 +129,16 @@ __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
 // the three products of one (column tile j, k step s) against every row tile
 #define VP_MMA(j, s)                                                                                                         \
     if constexpr (j < WN) {                                                                                                  \
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, cw##j##s##h), bl = __builtin_bit_cast(bf16x8, cw##j##s##l);               \
         _Pragma("unroll") for (int mi = 0; mi < WM; ++mi) {                                                                  \
-            acc[mi][j < WN ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al##s[mi], bh, acc[mi][j < WN ? j : 0], 0, 0, 0); \
-            acc[mi][j < WN ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah##s[mi], bl, acc[mi][j < WN ? j : 0], 0, 0, 0); \
-            acc[mi][j < WN ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah##s[mi], bh, acc[mi][j < WN ? j : 0], 0, 0, 0); \
+            acc[mi][j < WN ? j : 0] = mma(al##s[mi], cw##j##s##h, acc[mi][j < WN ? j : 0]);                                    \
+            acc[mi][j < WN ? j : 0] = mma(ah##s[mi], cw##j##s##l, acc[mi][j < WN ? j : 0]);                                    \
+            acc[mi][j < WN ? j : 0] = mma(ah##s[mi], cw##j##s##h, acc[mi][j < WN ? j : 0]);                                    \
         }                                                                                                                    \
     }
+    auto mma = [](const uint4 &a, const uint4 &b, const f32x16 &c) {
+        if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
     VP_EACH(VP_DECL)
     {
         const int nx = 0, nc = 0;
@@ -149,13 +162,13 @@ __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
         VP_EACH(VP_LOAD)
         __builtin_amdgcn_sched_barrier(0);
         const unsigned *a = As + (kc & 1) * TM * LR + aoff;
-        bf16x8 ah0[WM], al0[WM], ah1[WM], al1[WM];     // 16 k per step: lanes 0-31 take group 2 s, lanes 32-63 group 2 s + 1
+        uint4 ah0[WM], al0[WM], ah1[WM], al1[WM];     // 16 k per step: lanes 0-31 take group 2 s, lanes 32-63 group 2 s + 1
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi) {
-            ah0[mi] = __builtin_bit_cast(bf16x8, *(const uint4 *)(a + mi * 32 * LR));
-            al0[mi] = __builtin_bit_cast(bf16x8, *(const uint4 *)(a + mi * 32 * LR + 4));
-            ah1[mi] = __builtin_bit_cast(bf16x8, *(const uint4 *)(a + mi * 32 * LR + 16));
-            al1[mi] = __builtin_bit_cast(bf16x8, *(const uint4 *)(a + mi * 32 * LR + 20));
+            ah0[mi] = *(const uint4 *)(a + mi * 32 * LR);
+            al0[mi] = *(const uint4 *)(a + mi * 32 * LR + 4);
+            ah1[mi] = *(const uint4 *)(a + mi * 32 * LR + 16);
+            al1[mi] = *(const uint4 *)(a + mi * 32 * LR + 20);
         }
         VP_MMA(0, 0)
         VP_MMA(1, 0)
@@ -186,13 +199,13 @@ __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = r0 + (i & 3) + 8 * (i >> 2);
-                float v = acc[mi][ni][i] + bias;
+                float v = F16 ? fmaf(acc[mi][ni][i], g.c_scale, bias) : acc[mi][ni][i] + bias;
                 if constexpr (EPI == 3) v = vit_gelu_fast(v);
                 if constexpr (EPI == 4) v = fmaxf(v, 0.0f);
                 if constexpr (EPI == 2) v += res[i];
                 if (row < g.M) {
                     if constexpr (EPI == 3 || EPI == 4)
-                        ((unsigned *)g.C)[(size_t)row * g.Nout + col] = pd_split_word(v);
+                        ((unsigned *)g.C)[(size_t)row * g.Nout + col] = pd_split_word_as<F16 ? 2 : 1>(v, g.out_scale);
                     else
                         ((float *)g.C)[(size_t)row * g.Nout + col] = v;
                 }
@@ -201,9 +214,10 @@ __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
 }
 
 static constexpr size_t pd_split_lds(int WM) { return (size_t)2 * 64 * WM * PD_STREAM_LR * sizeof(float); }
-template <int EPI, int WM, int WN>
-static inline void pd_gemm_split(const unsigned *A, int lda, const unsigned *W, int K, const float *bias, void *C, int M, int Nout, hipStream_t s) {
-    VitSplitArgs g{A, W, bias, C, M, Nout, K, lda};
+template <int EPI, int WM, int WN, bool F16 = false>
+static inline void pd_gemm_split(const unsigned *A, int lda, const unsigned *W, int K, const float *bias, void *C, int M, int Nout, hipStream_t s,
+                                 float c_scale = 1.0f, float out_scale = 1.0f) {
+    VitSplitArgs g{A, W, bias, C, M, Nout, K, lda, c_scale, out_scale};
     constexpr int TM = 64 * WM, TN = 64 * WN;
-    hipLaunchKernelGGL((vit_gemm_split_kernel<EPI, WM, WN>), dim3(((M + TM - 1) / TM) * (Nout / TN)), dim3(256), pd_split_lds(WM), s, g);
+    hipLaunchKernelGGL((vit_gemm_split_kernel<EPI, WM, WN, F16>), dim3(((M + TM - 1) / TM) * (Nout / TN)), dim3(256), pd_split_lds(WM), s, g);
 }

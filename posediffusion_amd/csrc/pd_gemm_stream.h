@@ -5,12 +5,27 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // split precision (see vit_gemm_split_kernel in pd_vit.hip): fp32 -> {hi bf16 | lo bf16 << 16}, v ~= hi + lo
 __device__ __forceinline__ unsigned pd_split_word(float v) {
     const __bf16 h = (__bf16)v;
     const __bf16 l = (__bf16)(v - (float)h);
     return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+
+// the same with fp16 halves: v ~= hi + lo to 22 mantissa bits while |lo| stays a normal fp16, i.e. |v| >= 2^-3 (below that the
+// absolute error levels off at 2^-25) -- the caller scales v by a power of two into [.., 65504) first (pd_gemm_split.h, F16)
+__device__ __forceinline__ unsigned pd_split_word_h(float v) {
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+// SPLIT (template parameter of the kernels that feed the split-precision GEMMs): 0 fp32, 1 bf16 words, 2 fp16 words of v * scale
+template <int SPLIT>
+__device__ __forceinline__ unsigned pd_split_word_as(float v, float scale) {
+    if constexpr (SPLIT == 2) return pd_split_word_h(v * scale);
+    return pd_split_word(v);
 }
 
 // sum over the 8 consecutive lanes that share an activation row in the staging of pd_gemm_stream_kernel (DPP: xor-1, xor-2
@@ -26,8 +41,8 @@ __device__ __forceinline__ float pd_stream_sum8(float v) {
 }
 
 // LayerNorm without affine (folded into the next weight): x [M, D] -> xn; one wave per row, D / 64 values per lane
-template <int D, bool SPLIT>
-__global__ __launch_bounds__(256) void pd_ln_rows_kernel(const float *__restrict__ x, float *__restrict__ xn, int M, float eps) {
+template <int D, int SPLIT>
+__global__ __launch_bounds__(256) void pd_ln_rows_kernel(const float *__restrict__ x, float *__restrict__ xn, int M, float eps, float scale) {
     constexpr int PER = D / 64;
     static_assert(D % 64 == 0, "one wave per row");
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -51,8 +66,8 @@ __global__ __launch_bounds__(256) void pd_ln_rows_kernel(const float *__restrict
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const float o = (v[i] - mean) * rstd;
-        if constexpr (SPLIT)
-            ((unsigned *)xn)[(size_t)row * D + lane + 64 * i] = pd_split_word(o);      // for vit_gemm_split_kernel
+        if constexpr (SPLIT != 0)
+            ((unsigned *)xn)[(size_t)row * D + lane + 64 * i] = pd_split_word_as<SPLIT>(o, scale);      // for vit_gemm_split_kernel
         else
             xn[(size_t)row * D + lane + 64 * i] = o;
     }

@@ -731,22 +731,22 @@ extern "C" int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, i
         const pd_vit::Layer &L = v->L[l];
         if (streamed && !v->exact_fp32) {
             const int M = (int)tokens;
-            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, true>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, 1>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f, 1.0f);
             vit_gemm_split<0, 2, 2>((const unsigned *)v->xn, VD, L.qkv_ws, VD, L.qkv_b, v->qkv, M, 3 * VD, s);
             hipLaunchKernelGGL(vit_attn_kernel<true>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
             vit_gemm_split<2, 2, 1>((const unsigned *)v->ctx, VD, L.proj_ws, VD, L.proj_b, v->x, M, VD, s);
-            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, true>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, 1>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f, 1.0f);
             vit_gemm_split<3, 2, 2>((const unsigned *)v->xn, VD, L.fc1_ws, VD, L.fc1_b, v->hid, M, VFF, s);
             vit_gemm_split<2, 2, 1>((const unsigned *)v->hid, VFF, L.fc2_ws, VFF, L.fc2_b, v->x, M, VD, s);
             continue;
         }
         if (streamed) {
             const int M = (int)tokens;
-            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, false>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, 0>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f, 1.0f);
             pd_gemm_stream<0>(v->xn, VD, L.qkv_wf, VD, L.qkv_b, v->qkv, M, 3 * VD, s);
             hipLaunchKernelGGL(vit_attn_kernel<false>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
             pd_gemm_stream<2>(v->ctx, VD, L.proj_wf, VD, L.proj_b, v->x, M, VD, s);
-            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, false>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, 0>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f, 1.0f);
             pd_gemm_stream<3>(v->xn, VD, L.fc1_wf, VD, L.fc1_b, v->hid, M, VFF, s);
             pd_gemm_stream<2>(v->hid, VFF, L.fc2_wf, VFF, L.fc2_b, v->x, M, VD, s);
             continue;

@@ -259,11 +259,12 @@ class PoseEngine:
                    "pd_sample_phase")
         return pose, process, stats
 
-    def set_split_precision(self, on: bool):
-        """Fast mode of the denoiser at >= 1024 token rows (include/pd_engine.h PD_OPT_DENOISER_SPLIT): encoder GEMMs in split
-        precision on the bf16 matrix pipe.  Not the default: narrower arithmetic than the reference's fp32."""
+    def set_split_precision(self, mode):
+        """Encoder GEMMs of the denoiser at >= 1024 token rows (include/pd_engine.h PD_OPT_DENOISER_SPLIT): 0 / False exact fp32,
+        1 / True bf16 hi + lo (fast mode, ~16 bits: narrower than the reference's fp32), 2 fp16 hi + lo with static power-of-two
+        scales (22 bits, fp32 accumulation: fp32-grade)."""
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.pd_engine_set_option(self._h, _lib.PD_OPT_DENOISER_SPLIT, int(bool(on))), "pd_engine_set_option")
+            _lib.check(self.lib.pd_engine_set_option(self._h, _lib.PD_OPT_DENOISER_SPLIT, int(mode)), "pd_engine_set_option")
 
     def pose_to_camera(self, enc: torch.Tensor):
         enc = self._f32(enc).reshape(-1, 9)

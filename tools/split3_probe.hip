@@ -1,0 +1,142 @@
+// split3_probe.hip -- the six-product bf16 GEMM (csrc/pd_gemm_split3.h) alone (development probe, not part of the library): error against
+// an fp64 CPU product on sampled rows next to the exact-fp32 MFMA kernel's, and time per tile shape at the bench's row counts.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -Iinclude tools/split3_probe.hip -o tools/split3_probe && tools/split3_probe
+#include "../posediffusion_amd/csrc/pd_gemm_split3.h"
+#include "../posediffusion_amd/csrc/pd_gemm_split.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+void pd_set_error(const char *, ...) {}
+
+static float2 *g_stats;
+static float time_it(void (*launch)(hipStream_t), int reps, hipStream_t s) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch(s);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < reps; ++i) launch(s);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+static const float *gA, *gW, *gBias;
+static const uint4 *gW3;
+static float *gC;
+static int gM, gN, gK;
+template <int EPI, bool ALN, int WM, int WN>
+static void l_split3(hipStream_t s) {
+    auto kern = pd_gemm_split3_kernel<EPI, ALN, WM, WN>;
+    (void)kern;
+    pd_gemm_split3<EPI, ALN, WM, WN>(gA, gK, gW3, gK, gBias, gC, gM, gN, s, g_stats);
+}
+static const unsigned *gW2;
+template <int EPI, int WM, int WN>
+static void l_split2(hipStream_t s) { pd_gemm_split<EPI, WM, WN>((const unsigned *)gA, gK, gW2, gK, gBias, gC, gM, gN, s); }
+template <int EPI, bool ALN>
+static void l_exact(hipStream_t s) { pd_gemm_dma<EPI, ALN>(gA, gK, gW, gK, gBias, gC, gM, gN, s, g_stats); }
+
+int main() {
+    const int Mmax = 15360, Kmax = 1024, Nmax = 1536;
+    float *A, *W, *bias, *C;
+    uint4 *W3;
+    (void)hipMalloc(&A, (size_t)Mmax * Kmax * 4);
+    (void)hipMalloc(&W, (size_t)Nmax * Kmax * 4);
+    (void)hipMalloc(&W3, pd_split3_weight_bytes(Nmax, Kmax));
+    (void)hipMalloc(&bias, Nmax * 4);
+    (void)hipMalloc(&C, (size_t)Mmax * Nmax * 4);
+    (void)hipMalloc(&g_stats, Mmax * sizeof(float2));
+    std::vector<float> hA((size_t)Mmax * Kmax), hW((size_t)Nmax * Kmax), hb(Nmax);
+    unsigned long long st = 88172645463325252ull;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; };
+    auto gauss = [&]() { return sqrt(-2.0 * log(rnd() + 1e-300)) * cos(6.283185307179586 * rnd()); };
+    for (auto &v : hA) v = (float)gauss();
+    for (auto &v : hW) v = (float)(0.02 * gauss());
+    for (auto &v : hb) v = (float)(0.1 * gauss());
+    (void)hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+    hipStream_t s;
+    (void)hipStreamCreate(&s);
+    gA = A; gW = W; gBias = bias; gC = C; gW3 = W3;
+    (void)hipFuncSetAttribute((const void *)pd_gemm_split3_kernel<0, false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_split3_lds(2));
+
+    // ---- accuracy: 512 -> 1536 and 1024 -> 512 on 1 000 rows (ragged: not a multiple of 128), against fp64 on the host
+    for (int K : {512, 1024}) {
+        const int N = K == 512 ? 1536 : 512, M = 1000;
+        gM = M; gN = N; gK = K;
+        const size_t total = (size_t)(N / 32) * (K / 16) * 64;
+        hipLaunchKernelGGL(pd_frag_split3_kernel, dim3(512), dim3(256), 0, s, W, K, total, W3);
+        std::vector<double> ref((size_t)M * N);
+        for (int m = 0; m < M; ++m)
+            for (int n = 0; n < N; ++n) {
+                double a = hb[n];
+                for (int k = 0; k < K; ++k) a += (double)hA[(size_t)m * K + k] * (double)hW[(size_t)n * K + k];
+                ref[(size_t)m * N + n] = a;
+            }
+        double rmax = 0;
+        for (double v : ref) rmax = fmax(rmax, fabs(v));
+        std::vector<float> out((size_t)M * N);
+        auto err = [&](const char *tag) {
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(out.data(), C, out.size() * 4, hipMemcpyDeviceToHost);
+            double emax = 0, e2 = 0;
+            for (size_t i = 0; i < out.size(); ++i) {
+                const double e = fabs((double)out[i] - ref[i]);
+                emax = fmax(emax, e);
+                e2 += e * e;
+            }
+            printf("  %-34s max |err| / max |C| = %.3e   rms err / max |C| = %.3e\n", tag, emax / rmax, sqrt(e2 / out.size()) / rmax);
+        };
+        printf("K = %d -> %d columns, %d rows, A ~ N(0,1), W ~ N(0, 0.02^2); error against the fp64 product:\n", K, N, M);
+        (void)hipMemsetAsync(C, 0, out.size() * 4, s); l_exact<0, false>(s); err("exact fp32 MFMA (pd_gemm_dma)");
+        (void)hipMemsetAsync(C, 0, out.size() * 4, s); l_split3<0, false, 2, 2>(s); err("bf16 x 3, six products, 128x128");
+        (void)hipMemsetAsync(C, 0, out.size() * 4, s); l_split3<0, false, 1, 1>(s); err("bf16 x 3, six products, 64x64");
+        (void)hipMemsetAsync(C, 0, out.size() * 4, s); l_split3<0, false, 2, 1>(s); err("bf16 x 3, six products, 128x64");
+        (void)hipMemsetAsync(C, 0, out.size() * 4, s); l_split3<0, false, 1, 2>(s); err("bf16 x 3, six products, 64x128");
+    }
+    // ---- time: the two-plane, three-product kernel of the fast mode (vit_gemm_split_kernel) for comparison (operands: any bits)
+    gW2 = (const unsigned *)W3;
+    (void)hipFuncSetAttribute((const void *)vit_gemm_split_kernel<2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_split_lds(2));
+    (void)hipFuncSetAttribute((const void *)vit_gemm_split_kernel<2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_split_lds(2));
+    printf("two planes, three products (vit_gemm_split_kernel, EPI 2), useful TFLOP/s by tile 64x64 / 128x64 / 64x128 / 128x128 (bf16 peak / 3 = 838):\n");
+    for (int M : {5120, 15360})
+        for (int sh = 0; sh < 4; ++sh) {
+            const int Ns[] = {1536, 1024, 512, 512}, Ks[] = {512, 512, 512, 1024};
+            gM = M; gN = Ns[sh]; gK = Ks[sh];
+            const double gf = 2.0 * M * gN * gK * 1e-9;
+            const float a = time_it(l_split2<2, 1, 1>, 20, s), b = time_it(l_split2<2, 2, 1>, 20, s), c = time_it(l_split2<2, 1, 2>, 20, s), d = time_it(l_split2<2, 2, 2>, 20, s);
+            printf("  %4d->%4d %6d rows: %5.1f(%3.0fus) %5.1f(%3.0fus) %5.1f(%3.0fus) %5.1f(%3.0fus)\n", gK, gN, M, gf / a, a * 1e3, gf / b, b * 1e3, gf / c, c * 1e3, gf / d, d * 1e3);
+        }
+    // ---- time
+    struct Shape { const char *name; int N, K; };
+    const Shape shapes[] = {{"QKV  512->1536", 1536, 512}, {"FF1  512->1024", 1024, 512}, {"out  512-> 512", 512, 512}, {"FF2 1024-> 512", 512, 1024}};
+    printf("%-16s %6s %12s | bf16 x 3: %10s %10s %10s %10s   (useful TFLOP/s = 2 M N K / time; exact-fp32 MFMA peak 157.3, bf16 peak / 6 = 419)\n", "GEMM", "rows", "exact 64x64",
+           "64x64", "128x64", "64x128", "128x128");
+    for (int M : {5120, 15360})
+        for (const Shape &sh : shapes) {
+            gM = M; gN = sh.N; gK = sh.K;
+            const size_t total = (size_t)(sh.N / 32) * (sh.K / 16) * 64;
+            hipLaunchKernelGGL(pd_frag_split3_kernel, dim3(512), dim3(256), 0, s, W, sh.K, total, W3);
+            const bool ln = sh.K == 512 && sh.N > 512;
+            if (ln) hipLaunchKernelGGL(pd_ln_stats_kernel<512>, dim3((M + 3) / 4), dim3(256), 0, s, A, g_stats, M, 1e-5f);
+            const double gf = 2.0 * M * sh.N * sh.K * 1e-9;
+            float t[5];
+            if (ln) {
+                t[0] = time_it(l_exact<0, true>, 20, s);
+                t[1] = time_it(l_split3<0, true, 1, 1>, 20, s); t[2] = time_it(l_split3<0, true, 2, 1>, 20, s);
+                t[3] = time_it(l_split3<0, true, 1, 2>, 20, s); t[4] = time_it(l_split3<0, true, 2, 2>, 20, s);
+            } else {
+                t[0] = time_it(l_exact<2, false>, 20, s);
+                t[1] = time_it(l_split3<2, false, 1, 1>, 20, s); t[2] = time_it(l_split3<2, false, 2, 1>, 20, s);
+                t[3] = time_it(l_split3<2, false, 1, 2>, 20, s); t[4] = time_it(l_split3<2, false, 2, 2>, 20, s);
+            }
+            printf("%-16s %6d %5.1f(%3.0fus) |          ", sh.name, M, gf / t[0], t[0] * 1e3);
+            for (int i = 1; i < 5; ++i) printf(" %5.1f(%3.0fus)", gf / t[i], t[i] * 1e3);
+            printf("%s\n", ln ? "  (+LN)" : "");
+        }
+    return 0;
+}
