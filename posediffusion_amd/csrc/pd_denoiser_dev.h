@@ -38,6 +38,8 @@ struct PdLayerDev {          // [0] = 32-wide-tile packing, [1] = 16-wide-tile p
     // pd_denoiser_build_split: accumulator scales 2^-(ea + ew) per GEMM, operand scales of the attention output and the FF hidden rows
     unsigned *qkv_wh, *out_wh, *ff1_wh, *ff2_wh;
     float qkv_cs, out_cs, ff1_cs, ff2_cs, ctx_scale, ff_scale;
+    int e_wqkv, e_wo, e_w1, e_w2;                  // the weights' scale exponents (pd_denoiser_build_scales)
+    unsigned *qkv_wk, *out_wk, *ff1_wk, *ff2_wk;   // the same fp16 planes in the persistent small-batch kernel's tile order (pd_den_small.inc)
 };
 
 struct PdDenoiserDev {
@@ -51,7 +53,11 @@ struct PdDenoiserDev {
     float *hn = nullptr;               // LayerNorm(h) without affine, streamed path only
     float *emb = nullptr, *first_wf = nullptr, *last0_wf = nullptr;   // streamed path: _first's input rows [rows, 704], row-major _first / _last.0 weights
     bool split_ready = false;          // the fast mode's split weights exist
-    bool split_h_ready = false;        // the fp16-plane mode's weights and scales exist
+    bool split_h_ready = false;        // the fp16-plane mode's weights exist
+    bool scales_ready = false;         // the fp16-plane scales exist (pd_denoiser_build_scales)
+    bool small_ready = false;          // the persistent small-batch kernel's weights and barrier words exist
+    float *first_wk = nullptr, *last0_wk = nullptr;   // `_first` / `_last.0` in that kernel's fp32 tile order
+    unsigned *small_bar = nullptr;     // its grid-barrier words {arrivals, arrivals at launch}
     std::vector<void *> allocs;
 };
 

@@ -346,7 +346,7 @@ extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *nois
         key.cond_start = has_ggs ? cond_start_step : 0;
         key.has_ggs = has_ggs;
         key.phase = phase;
-        key.den_split = eng->den_split;
+        key.den_split = eng->den_split | (eng->den_persistent << 8);      // both options change the captured launches
         if (has_ggs) {
             key.cfg = *ggs;
             // the GGS nodes bake the match-derived launch shape in: a re-upload with another item count must not
@@ -431,6 +431,18 @@ extern "C" int pd_engine_set_option(pd_engine *eng, int option, int value) {
             if (rc) return rc;
         }
         eng->den_split = value;
+        break;
+    case PD_OPT_DENOISER_PERSISTENT:
+        if (value != 0 && value != 1) {
+            pd_set_error("pd_engine_set_option: PD_OPT_DENOISER_PERSISTENT takes 0 or 1 (got %d)", value);
+            return PD_ERR_INVALID_ARG;
+        }
+        if (value) {
+            PD_HIP_CHECK(hipSetDevice(eng->device));
+            int rc = pd_denoiser_build_small(eng);
+            if (rc) return rc;
+        }
+        eng->den_persistent = value;
         break;
     default:
         pd_set_error("pd_engine_set_option: unknown option %d", option);
