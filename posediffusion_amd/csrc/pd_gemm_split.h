@@ -65,7 +65,9 @@ struct VitSplitArgs {
 // A rows stream through LDS (un-zipped into hi / lo fragments on the way, shared by the waves of a row block); the weight
 // fragments go straight from global memory / L2 to registers, one chunk ahead (they are already in operand order, and
 // keeping them out of LDS halves its traffic -- the LDS array, not the matrix pipe, limited the first version).
-template <int EPI, int WM, int WN, bool F16 = false>
+// BARE (tools/split3_probe.hip only): 1 no weight-fragment loads after the first chunk, 2 no A loads / LDS stores after it, 3 both,
+// 4 all of that and no barrier, 5 no MFMAs (everything else as in production) -- what bounds the kernel
+template <int EPI, int WM, int WN, bool F16 = false, int BARE = 0>
 __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
     constexpr int KC = PD_STREAM_KC, LR = PD_STREAM_LR, TM = 64 * WM, TN = 64 * WN, GROUP = 2048 / TM;
     static_assert(KC == 32 && WM <= 2 && WN <= 2, "staging: 4 groups of 8 per row chunk, passes of 64 rows");
@@ -99,6 +101,18 @@ __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
         ra##j##a = ap##j[nx];                       \
         ra##j##b = ap##j[nx + 1];                   \
     }                                               \
+    if constexpr (j < WN) {                         \
+        nw##j##0h = wq##j[(size_t)(nc * 4 + 0) * 64]; \
+        nw##j##0l = wq##j[(size_t)(nc * 4 + 1) * 64]; \
+        nw##j##1h = wq##j[(size_t)(nc * 4 + 2) * 64]; \
+        nw##j##1l = wq##j[(size_t)(nc * 4 + 3) * 64]; \
+    }
+#define VP_LOAD_A(j)                                \
+    if constexpr (j < WM) {                         \
+        ra##j##a = ap##j[nx];                       \
+        ra##j##b = ap##j[nx + 1];                   \
+    }
+#define VP_LOAD_W(j)                                \
     if constexpr (j < WN) {                         \
         nw##j##0h = wq##j[(size_t)(nc * 4 + 0) * 64]; \
         nw##j##0l = wq##j[(size_t)(nc * 4 + 1) * 64]; \
@@ -159,7 +173,9 @@ __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
     const int aoff = (wm * 32 * WM + l31) * LR + 8 * hi;
     for (int kc = 0; kc < nk; ++kc) {
         const int nc = min(kc + 1, nk - 1), nx = nc * (KC / 4);       // the chunk after the last is the last again
-        VP_EACH(VP_LOAD)
+        if constexpr (BARE == 0 || BARE == 5) { VP_EACH(VP_LOAD) }
+        else if constexpr (BARE == 1) { VP_EACH(VP_LOAD_A) }
+        else if constexpr (BARE == 2) { VP_EACH(VP_LOAD_W) }
         __builtin_amdgcn_sched_barrier(0);
         const unsigned *a = As + (kc & 1) * TM * LR + aoff;
         uint4 ah0[WM], al0[WM], ah1[WM], al1[WM];     // 16 k per step: lanes 0-31 take group 2 s, lanes 32-63 group 2 s + 1
@@ -170,18 +186,22 @@ __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
             ah1[mi] = *(const uint4 *)(a + mi * 32 * LR + 16);
             al1[mi] = *(const uint4 *)(a + mi * 32 * LR + 20);
         }
-        VP_MMA(0, 0)
-        VP_MMA(1, 0)
-        VP_MMA(0, 1)
-        VP_MMA(1, 1)
+        if constexpr (BARE != 5) {
+            VP_MMA(0, 0)
+            VP_MMA(1, 0)
+            VP_MMA(0, 1)
+            VP_MMA(1, 1)
+        }
         __builtin_amdgcn_sched_barrier(0);
         unsigned *da = As + ((kc + 1) & 1) * TM * LR;
-        VP_EACH(VP_STORE)
-        VP_EACH(VP_ROLL)
-        __syncthreads();
+        if constexpr (BARE == 0 || BARE == 1 || BARE == 5) { VP_EACH(VP_STORE) }
+        if constexpr (BARE == 0 || BARE == 2 || BARE == 5) { VP_EACH(VP_ROLL) }
+        if constexpr (BARE != 4) __syncthreads();
     }
 #undef VP_DECL
 #undef VP_LOAD
+#undef VP_LOAD_A
+#undef VP_LOAD_W
 #undef VP_ROLL
 #undef VP_STORE
 #undef VP_MMA

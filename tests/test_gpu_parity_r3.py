@@ -285,6 +285,7 @@ def test_persistent_small_batch_denoiser(seeded_diffuser, oracle_weights):
     assert steps[10] < 1e-5 and rel_err(pose_g, pose_m) < 5e-2           # (chaotic growth of a rounding-level difference, as between any two modes)
     # two engines on two streams, launches interleaved: 2 x 64 spinning workgroups must all become resident
     eng2 = PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=1, max_N=20)
+    eng2.set_persistent_denoiser(True)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     x = torch.randn(1, 20, 9, device=dev)
     ref1 = eng.denoise(x, z, 50).clone()

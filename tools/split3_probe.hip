@@ -36,6 +36,12 @@ static void l_split3(hipStream_t s) {
 static const unsigned *gW2;
 template <int EPI, int WM, int WN>
 static void l_split2(hipStream_t s) { pd_gemm_split<EPI, WM, WN>((const unsigned *)gA, gK, gW2, gK, gBias, gC, gM, gN, s); }
+template <int WM, int WN, int BARE>
+static void l_bare(hipStream_t s) {
+    VitSplitArgs g{(const unsigned *)gA, gW2, gBias, gC, gM, gN, gK, gK, 1.0f, 1.0f};
+    constexpr int TM = 64 * WM, TN = 64 * WN;
+    hipLaunchKernelGGL((vit_gemm_split_kernel<0, WM, WN, true, BARE>), dim3(((gM + TM - 1) / TM) * (gN / TN)), dim3(256), pd_split_lds(WM), s, g);
+}
 template <int EPI, bool ALN>
 static void l_exact(hipStream_t s) { pd_gemm_dma<EPI, ALN>(gA, gK, gW, gK, gBias, gC, gM, gN, s, g_stats); }
 
@@ -110,6 +116,17 @@ int main() {
             const double gf = 2.0 * M * gN * gK * 1e-9;
             const float a = time_it(l_split2<2, 1, 1>, 20, s), b = time_it(l_split2<2, 2, 1>, 20, s), c = time_it(l_split2<2, 1, 2>, 20, s), d = time_it(l_split2<2, 2, 2>, 20, s);
             printf("  %4d->%4d %6d rows: %5.1f(%3.0fus) %5.1f(%3.0fus) %5.1f(%3.0fus) %5.1f(%3.0fus)\n", gK, gN, M, gf / a, a * 1e3, gf / b, b * 1e3, gf / c, c * 1e3, gf / d, d * 1e3);
+        }
+    printf("what bounds the two-plane kernel (fp16, EPI 0), us per launch: full | no W loads | no A staging | neither | neither, no barrier | no MFMA\n");
+    for (int M : {5120, 15360})
+        for (int sh = 0; sh < 2; ++sh) {
+            const int Ns[] = {1536, 512}, Ks[] = {512, 1024};
+            gM = M; gN = Ns[sh]; gK = Ks[sh];
+            printf("  %4d->%4d %6d rows  64x128: %5.1f %5.1f %5.1f %5.1f %5.1f %5.1f   128x128: %5.1f %5.1f %5.1f %5.1f %5.1f %5.1f\n", gK, gN, M,
+                   1e3 * time_it(l_bare<1, 2, 0>, 20, s), 1e3 * time_it(l_bare<1, 2, 1>, 20, s), 1e3 * time_it(l_bare<1, 2, 2>, 20, s), 1e3 * time_it(l_bare<1, 2, 3>, 20, s),
+                   1e3 * time_it(l_bare<1, 2, 4>, 20, s), 1e3 * time_it(l_bare<1, 2, 5>, 20, s),
+                   1e3 * time_it(l_bare<2, 2, 0>, 20, s), 1e3 * time_it(l_bare<2, 2, 1>, 20, s), 1e3 * time_it(l_bare<2, 2, 2>, 20, s), 1e3 * time_it(l_bare<2, 2, 3>, 20, s),
+                   1e3 * time_it(l_bare<2, 2, 4>, 20, s), 1e3 * time_it(l_bare<2, 2, 5>, 20, s));
         }
     // ---- time
     struct Shape { const char *name; int N, K; };
