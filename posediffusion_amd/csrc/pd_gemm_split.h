@@ -233,6 +233,171 @@ __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
         }
 }
 
+// ---- the same arithmetic, operands delivered differently (round 3) ------------------------------------------------------------------
+// vit_gemm_split_kernel is bound by operand delivery, not by the matrix pipe (tools/split3_probe.hip, BARE): both waves of a row block
+// fetch the same weight fragments from L2 (104 B/clk/CU asked of a 64 B/clk port at the 64 x 128 tile) and the A rows make a
+// global -> VGPR -> v_perm -> ds_write round trip.  Here a workgroup's tile is (32 RT) rows x (128 CT) columns and every wave owns a
+// STRIP of 32 CT columns of it over all RT row tiles: no weight fragment is fetched twice (they still go L2 -> registers, one chunk ahead), and
+// the A rows -- raw split words -- go L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, hand-issued as in pd_gemm_dma_kernel, 16-byte slots
+// XOR-swizzled by (row >> 1) & 7) and are un-zipped into hi / lo fragments when they are read.  The products of an output element are
+// accumulated in the same order as in vit_gemm_split_kernel: bitwise the same C.
+// BARE (probe only): 1 no weight-fragment loads in the loop, 2 no DMA in the loop, 3 neither, 4 neither and no barrier / wait,
+// 5 everything but the MFMAs, 6 everything but the fragment reads + un-zip (the first chunk's are reused)
+template <int EPI, int RT, bool F16, int CT = 1, int BARE = 0>
+__global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
+    constexpr int KC = 32, TM = 32 * RT, TN = 128 * CT, GROUP = 2048 / TM, CHA = TM * KC;     // words of A per chunk
+    static_assert((RT == 2 || RT == 4) && (CT == 1 || CT == 2), "pieces of 8 rows, RT per wave and chunk");
+    extern __shared__ __attribute__((aligned(1024))) unsigned strip_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int MT = (g.M + TM - 1) / TM, NT = g.Nout / TN;
+    int mtile, ntile;
+    {
+        const int b = blockIdx.x, full = (MT / GROUP) * GROUP * NT;
+        if (b < full) {
+            const int grp = b / (NT * GROUP), r = b - grp * (NT * GROUP);
+            ntile = r / GROUP;
+            mtile = grp * GROUP + r % GROUP;
+        } else {
+            const int r = b - full, rest = MT % GROUP;
+            ntile = r / rest;
+            mtile = (MT / GROUP) * GROUP + r % rest;
+        }
+    }
+    const int m0 = mtile * TM, n0 = ntile * TN;
+    // staging: pieces of 1 KiB = 8 rows x 32 words; a chunk has 4 RT of them, wave w moves pieces [RT w, RT (w + 1))
+    const int prow = lane >> 3, pslot = lane & 7;
+    unsigned oa[RT];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+        const int r = 8 * (RT * wave + j) + prow;
+        oa[j] = (unsigned)(((size_t)min(m0 + r, g.M - 1) * g.lda + 4 * (pslot ^ ((r >> 1) & 7))) * sizeof(unsigned));
+    }
+    const unsigned lds_a = (unsigned)(size_t)(strip_lds + RT * wave * 256);
+    auto stage = [&](int kc, int buf) {
+        const float *ab = (const float *)(g.A + kc * KC);
+        const unsigned da = __builtin_amdgcn_readfirstlane(lds_a + buf * CHA * 4);
+#pragma unroll
+        for (int j = 0; j < RT; ++j) pd_dma_piece(ab, oa[j], da + j * 1024);
+    };
+    const int KS = g.K / 16;
+    const uint4 *wq = (const uint4 *)g.W + (size_t)(n0 / 32 + CT * wave) * KS * 128 + lane;      // this wave's first column tile; the next one KS * 128 further
+    uint4 cw[CT][2][2], nw[CT][2][2];               // [column tile][k step][hi | lo]
+    auto mma = [](const uint4 &a, const uint4 &b, const f32x16 &c) {
+        if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) cw[c][st][pl] = wq[(size_t)c * KS * 128 + (size_t)(st * 2 + pl) * 64];
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int mi = 0; mi < RT; ++mi)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][c][i] = 0.0f;
+    const int nk = g.K / KC, sw = (l31 >> 1) & 7;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int nc = min(kc + 1, nk - 1);          // the chunk after the last is the last again
+        if constexpr (BARE == 0 || BARE == 2 || BARE >= 5) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) nw[c][st][pl] = wq[(size_t)c * KS * 128 + (size_t)(nc * 4 + st * 2 + pl) * 64];
+        }
+        if constexpr (BARE == 0 || BARE == 1 || BARE >= 5) stage(nc, (kc + 1) & 1);
+        const unsigned *a = strip_lds + (BARE == 6 ? 0 : (kc & 1)) * CHA + l31 * KC;
+        uint4 ah[RT], al[RT];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if (BARE != 6 || kc == 0)
+#pragma unroll
+            for (int mi = 0; mi < RT; ++mi) {
+                const uint4 p = *(const uint4 *)(a + mi * 32 * KC + 4 * ((4 * st + 2 * hi) ^ sw));
+                const uint4 q = *(const uint4 *)(a + mi * 32 * KC + 4 * ((4 * st + 2 * hi + 1) ^ sw));
+                ah[mi] = make_uint4(__builtin_amdgcn_perm(p.y, p.x, 0x05040100u), __builtin_amdgcn_perm(p.w, p.z, 0x05040100u),
+                                    __builtin_amdgcn_perm(q.y, q.x, 0x05040100u), __builtin_amdgcn_perm(q.w, q.z, 0x05040100u));
+                al[mi] = make_uint4(__builtin_amdgcn_perm(p.y, p.x, 0x07060302u), __builtin_amdgcn_perm(p.w, p.z, 0x07060302u),
+                                    __builtin_amdgcn_perm(q.y, q.x, 0x07060302u), __builtin_amdgcn_perm(q.w, q.z, 0x07060302u));
+            }
+            // per output element: lo x hi, hi x lo, hi x hi of this step, in this order (vit_gemm_split_kernel's)
+            if constexpr (BARE != 5) {
+#pragma unroll
+                for (int mi = 0; mi < RT; ++mi)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[mi][c] = mma(al[mi], cw[c][st][0], acc[mi][c]);
+#pragma unroll
+                for (int mi = 0; mi < RT; ++mi)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[mi][c] = mma(ah[mi], cw[c][st][1], acc[mi][c]);
+#pragma unroll
+                for (int mi = 0; mi < RT; ++mi)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[mi][c] = mma(ah[mi], cw[c][st][0], acc[mi][c]);
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < RT; ++mi) acc[mi][0][st] += __uint_as_float(al[mi].x ^ ah[mi].w ^ cw[0][st][0].y ^ cw[0][st][1].z);
+            }
+        }
+        if constexpr (BARE == 0 || BARE == 2 || BARE >= 5) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) cw[c][st][pl] = nw[c][st][pl];
+        }
+        if constexpr (BARE != 4) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next chunk's rows have landed in the other buffer
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int col = n0 + (CT * wave + c) * 32 + l31;
+        const float bias = g.bias[col];
+#pragma unroll
+        for (int mi = 0; mi < RT; ++mi) {
+            const int r0 = m0 + mi * 32 + 4 * hi;
+            float res[16];
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) res[i] = ((const float *)g.C)[(size_t)min(r0 + (i & 3) + 8 * (i >> 2), g.M - 1) * g.Nout + col];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = r0 + (i & 3) + 8 * (i >> 2);
+                float v = F16 ? fmaf(acc[mi][c][i], g.c_scale, bias) : acc[mi][c][i] + bias;
+                if constexpr (EPI == 3) v = vit_gelu_fast(v);
+                if constexpr (EPI == 4) v = fmaxf(v, 0.0f);
+                if constexpr (EPI == 2) v += res[i];
+                if (row < g.M) {
+                    if constexpr (EPI == 3 || EPI == 4)
+                        ((unsigned *)g.C)[(size_t)row * g.Nout + col] = pd_split_word_as<F16 ? 2 : 1>(v, g.out_scale);
+                    else
+                        ((float *)g.C)[(size_t)row * g.Nout + col] = v;
+                }
+            }
+        }
+    }
+}
+template <int EPI, int RT, bool F16, int CT = 1>
+static inline void pd_gemm_strip(const unsigned *A, int lda, const unsigned *W, int K, const float *bias, void *C, int M, int Nout, hipStream_t s,
+                                 float c_scale = 1.0f, float out_scale = 1.0f) {
+    VitSplitArgs g{A, W, bias, C, M, Nout, K, lda, c_scale, out_scale};
+    constexpr int TM = 32 * RT;
+    hipLaunchKernelGGL((pd_gemm_strip_kernel<EPI, RT, F16, CT>), dim3(((M + TM - 1) / TM) * (Nout / (128 * CT))), dim3(256), (size_t)2 * TM * 32 * sizeof(unsigned), s, g);
+}
+
 static constexpr size_t pd_split_lds(int WM) { return (size_t)2 * 64 * WM * PD_STREAM_LR * sizeof(float); }
 template <int EPI, int WM, int WN, bool F16 = false>
 static inline void pd_gemm_split(const unsigned *A, int lda, const unsigned *W, int K, const float *bias, void *C, int M, int Nout, hipStream_t s,

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 void pd_set_error(const char *, ...) {}
 
@@ -36,6 +37,35 @@ static void l_split3(hipStream_t s) {
 static const unsigned *gW2;
 template <int EPI, int WM, int WN>
 static void l_split2(hipStream_t s) { pd_gemm_split<EPI, WM, WN>((const unsigned *)gA, gK, gW2, gK, gBias, gC, gM, gN, s); }
+template <int RT, int BARE>
+static void l_strip_bare(hipStream_t s) {
+    VitSplitArgs g{(const unsigned *)gA, gW2, gBias, gC, gM, gN, gK, gK, 0.5f, 4.0f};
+    hipLaunchKernelGGL((pd_gemm_strip_kernel<0, RT, true, 1, BARE>), dim3(((gM + 32 * RT - 1) / (32 * RT)) * (gN / 128)), dim3(256), (size_t)2 * 32 * RT * 32 * sizeof(unsigned), s, g);
+}
+template <int EPI, int RT, int CT = 1>
+static void l_strip(hipStream_t s) { pd_gemm_strip<EPI, RT, true, CT>((const unsigned *)gA, gK, gW2, gK, gBias, gC, gM, gN, s, 0.5f, 4.0f); }
+template <int EPI, int WM, int WN>
+static void l_split2h(hipStream_t s) { pd_gemm_split<EPI, WM, WN, true>((const unsigned *)gA, gK, gW2, gK, gBias, gC, gM, gN, s, 0.5f, 4.0f); }
+// C of the strip kernel against C of vit_gemm_split_kernel on the same operands (arbitrary bit patterns read as fp16 pairs are fine for
+// a bitwise comparison only if no NaN arises: the operands are made of small integers instead)
+template <int EPI, int RT, int CT = 1>
+static long long diff_strip(float *C2, int M, int N, int K, hipStream_t s) {
+    gM = M; gN = N; gK = K;
+    float *keep = gC;
+    (void)hipMemsetAsync(gC, 0, (size_t)M * N * 4, s);
+    (void)hipMemsetAsync(C2, 0, (size_t)M * N * 4, s);
+    l_split2h<EPI, 1, 2>(s);
+    gC = C2;
+    l_strip<EPI, RT, CT>(s);
+    gC = keep;
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned> a((size_t)M * N), b((size_t)M * N);
+    (void)hipMemcpy(a.data(), gC, a.size() * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(b.data(), C2, b.size() * 4, hipMemcpyDeviceToHost);
+    long long bad = 0;
+    for (size_t i = 0; i < a.size(); ++i) bad += a[i] != b[i];
+    return bad;
+}
 template <int WM, int WN, int BARE>
 static void l_bare(hipStream_t s) {
     VitSplitArgs g{(const unsigned *)gA, gW2, gBias, gC, gM, gN, gK, gK, 1.0f, 1.0f};
@@ -117,6 +147,53 @@ int main() {
             const float a = time_it(l_split2<2, 1, 1>, 20, s), b = time_it(l_split2<2, 2, 1>, 20, s), c = time_it(l_split2<2, 1, 2>, 20, s), d = time_it(l_split2<2, 2, 2>, 20, s);
             printf("  %4d->%4d %6d rows: %5.1f(%3.0fus) %5.1f(%3.0fus) %5.1f(%3.0fus) %5.1f(%3.0fus)\n", gK, gN, M, gf / a, a * 1e3, gf / b, b * 1e3, gf / c, c * 1e3, gf / d, d * 1e3);
         }
+    {
+        // operands for the bitwise comparison: split words of small multiples of 1/8 (exact in fp16, no overflow)
+        std::vector<unsigned> wa((size_t)Mmax * Kmax);
+        for (size_t i = 0; i < wa.size(); ++i) {
+            const _Float16 h = (_Float16)((float)((int)((i * 2654435761u) >> 20) % 97 - 48) * 0.125f), l = (_Float16)((float)((int)((i * 40503u) >> 7) % 31 - 15) * 0.0009765625f);
+            unsigned short hb, lb;
+            memcpy(&hb, &h, 2); memcpy(&lb, &l, 2);
+            wa[i] = (unsigned)hb | ((unsigned)lb << 16);
+        }
+        unsigned *Aw;
+        float *C2;
+        (void)hipMalloc(&Aw, wa.size() * 4);
+        (void)hipMalloc(&C2, (size_t)Mmax * Nmax * 4);
+        (void)hipMemcpy(Aw, wa.data(), wa.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy((void *)W3, wa.data(), (size_t)Nmax * Kmax * 4, hipMemcpyHostToDevice);     // the same words as weight fragments
+        const float *keepA = gA;
+        gA = (const float *)Aw;
+        printf("strip kernel vs vit_gemm_split_kernel<.., F16>, elements that differ: QKV (EPI 0, RT 4) %lld, ragged 5000 rows (EPI 0, RT 2) %lld, FF1 (EPI 4, RT 4) %lld, "
+               "FF2 (EPI 2, RT 2, K 1024) %lld, out (EPI 2, RT 4, 1000 rows) %lld\n",
+               diff_strip<0, 4>(C2, 5120, 1536, 512, s), diff_strip<0, 2>(C2, 5000, 512, 512, s), diff_strip<4, 4>(C2, 5120, 1024, 512, s),
+               diff_strip<2, 2>(C2, 5120, 512, 1024, s), diff_strip<2, 4>(C2, 1000, 512, 512, s));
+        printf("  two column tiles per wave: QKV (EPI 0, RT 2) %lld, FF1 (EPI 4, RT 4) %lld, ragged 5000 rows FF2 (EPI 2, RT 2) %lld\n",
+               diff_strip<0, 2, 2>(C2, 5120, 1536, 512, s), diff_strip<4, 4, 2>(C2, 5120, 1024, 512, s), diff_strip<2, 2, 2>(C2, 5000, 512, 1024, s));
+        printf("strip kernel, us per launch (64 x 128 | 128 x 128 | 64 x 256 | 128 x 256 tile) against vit_gemm_split_kernel 64 x 128 | 64 x 64:\n");
+        for (int M : {5120, 15360}) {
+            struct { const char *n; int N, K, epi; } sh[] = {{"QKV", 1536, 512, 0}, {"FF1", 1024, 512, 4}, {"out", 512, 512, 2}, {"FF2", 512, 1024, 2}};
+            for (auto &x : sh) {
+                gM = M; gN = x.N; gK = x.K;
+                float t[6];
+                if (x.epi == 0) { t[0] = time_it(l_strip<0, 2>, 20, s); t[1] = time_it(l_strip<0, 4>, 20, s); t[2] = time_it(l_split2h<0, 1, 2>, 20, s); t[3] = time_it(l_split2h<0, 1, 1>, 20, s); t[4] = time_it(l_strip<0, 2, 2>, 20, s); t[5] = time_it(l_strip<0, 4, 2>, 20, s); }
+                else if (x.epi == 4) { t[0] = time_it(l_strip<4, 2>, 20, s); t[1] = time_it(l_strip<4, 4>, 20, s); t[2] = time_it(l_split2h<4, 1, 2>, 20, s); t[3] = time_it(l_split2h<4, 1, 1>, 20, s); t[4] = time_it(l_strip<4, 2, 2>, 20, s); t[5] = time_it(l_strip<4, 4, 2>, 20, s); }
+                else { t[0] = time_it(l_strip<2, 2>, 20, s); t[1] = time_it(l_strip<2, 4>, 20, s); t[2] = time_it(l_split2h<2, 1, 2>, 20, s); t[3] = time_it(l_split2h<2, 1, 1>, 20, s); t[4] = time_it(l_strip<2, 2, 2>, 20, s); t[5] = time_it(l_strip<2, 4, 2>, 20, s); }
+                printf("  %s %5d rows: %5.1f | %5.1f | %5.1f | %5.1f   against %5.1f | %5.1f\n", x.n, M, t[0] * 1e3, t[1] * 1e3, t[4] * 1e3, t[5] * 1e3, t[2] * 1e3, t[3] * 1e3);
+            }
+        }
+        printf("what bounds the strip kernel (EPI 0, 64 x 128 tile), us per launch: full | no W loads | no DMA | neither | neither, no barrier | no MFMA | no fragment reads\n");
+        for (int M : {5120, 15360})
+            for (int sh = 0; sh < 2; ++sh) {
+                const int Ns[] = {1536, 512}, Ks[] = {512, 1024};
+                gM = M; gN = Ns[sh]; gK = Ks[sh];
+                printf("  %4d->%4d %6d rows: %5.1f %5.1f %5.1f %5.1f %5.1f %5.1f %5.1f\n", gK, gN, M, 1e3 * time_it(l_strip_bare<2, 0>, 20, s), 1e3 * time_it(l_strip_bare<2, 1>, 20, s),
+                       1e3 * time_it(l_strip_bare<2, 2>, 20, s), 1e3 * time_it(l_strip_bare<2, 3>, 20, s), 1e3 * time_it(l_strip_bare<2, 4>, 20, s), 1e3 * time_it(l_strip_bare<2, 5>, 20, s),
+                       1e3 * time_it(l_strip_bare<2, 6>, 20, s));
+            }
+        gA = keepA;
+        (void)hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+    }
     printf("what bounds the two-plane kernel (fp16, EPI 0), us per launch: full | no W loads | no A staging | neither | neither, no barrier | no MFMA\n");
     for (int M : {5120, 15360})
         for (int sh = 0; sh < 2; ++sh) {
