@@ -45,3 +45,33 @@ def test_ggs_kernel_variants_keep_their_register_budget(tmp_path):
         assert r["VGPRs"] <= 256 and r["Occupancy"] == 2 and r["VGPRs Spill"] <= 96 and r["ScratchSize"] <= 400, (name, r)
     two_hop = [v for k, v in kernels.items() if "pd_ggs2_kernel" in k]
     assert two_hop and two_hop[0]["VGPRs Spill"] == 0 and two_hop[0]["ScratchSize"] == 0
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not installed")
+def test_denoiser_kernels_keep_their_register_budget(tmp_path):
+    """The large-batch denoiser's GEMM kernels: the strip kernel of the fp16-plane mode lives on occupancy (>= 4 waves per
+    SIMD at the 64 x 128 tile), the LDS-DMA exact kernel on >= 6; nothing touches scratch -- nor does the persistent small-batch kernel,
+    which gets a whole SIMD's registers per wave."""
+    src = os.path.join(ROOT, "posediffusion_amd", "csrc", "pd_denoiser.hip")
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-Rpass-analysis=kernel-resource-usage",
+                          "-c", src, "-o", str(tmp_path / "pd_denoiser.o")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z /\[\]]+?): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split("[")[0].strip()] = int(m.group(2))
+    strip = {k: v for k, v in kernels.items() if "pd_gemm_strip_kernel" in k}
+    assert len(strip) == 3, sorted(kernels)                     # EPI 0 / 2 / 4 at two row tiles, fp16 planes
+    for name, r in strip.items():
+        assert r["Occupancy"] >= 4 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
+    dma = {k: v for k, v in kernels.items() if "pd_gemm_dma_kernel" in k}
+    assert len(dma) == 4, sorted(kernels)
+    for name, r in dma.items():
+        assert r["Occupancy"] >= 6 and r["ScratchSize"] == 0, (name, r)
+    small = [v for k, v in kernels.items() if "pd_den_small_kernel" in k]
+    assert len(small) == 1 and small[0]["ScratchSize"] == 0 and small[0]["VGPRs Spill"] == 0, small
