@@ -543,7 +543,7 @@ def main():
     if tokens > 50:      # the weight stream bounds the denoiser up to ~50 tokens, the exact-fp32 matrix pipe above
         split_default = tokens >= PD_STREAM_MIN_ROWS       # the fp16-plane kernels are the default there (PD_OPT_DENOISER_SPLIT = 2)
         den_peak = F16_PEAK_TFLOPS / 3.0 if split_default else FP32_PEAK_TFLOPS
-        roofline_den = {"kernel": f"one denoiser step at {tokens} token rows (pd_gemm_strip_kernel<.., F16> / pd_ln_rows_kernel / pd_attn_seq_kernel / pd_gemm_dma_kernel for _first and _last.0 / "
+        roofline_den = {"kernel": f"one denoiser step at {tokens} token rows (pd_gemm_strip_kernel<.., F16> / pd_ln_rows_kernel / pd_attn_mma_kernel / pd_gemm_dma_kernel for _first and _last.0 / "
                                   "pd_tail_kernel launches at >= 1 024 rows; pd_gemm_kernel / pd_attn_kernel below)",
                         "bound": "mfma", "bound_detail": ("fp16 matrix instruction, three products per fp32 product: 2 500 / 3 = 833 TFLOP/s of algorithmic fp32 FLOPs "
                                                           "(the kernels are bound by operand delivery from LDS / L2 well below that, DESIGN 3.1)") if split_default

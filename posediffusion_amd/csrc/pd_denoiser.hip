@@ -505,6 +505,120 @@ __global__ __launch_bounds__(256) void pd_attn_seq_kernel(const float *__restric
         __syncthreads();                          // P is rewritten by the next round
     }
 }
+// The same attention on the matrix pipe, for sequences of <= 32 frames (round 3): pd_attn_seq_kernel keeps 20 of 64 lanes busy in
+// its score loop (lane = key) and is compute-bound at 19 - 20 us per layer against a ~10 us floor for moving 31 MB of QKV.  Here
+// S = (Q / sqrt(dh)) K^T is four 16 x 16 tiles, one per wave, on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation, K = 128:
+// 32 instructions per wave); softmax runs 8 lanes per row over S in LDS (max, expf, sum: the same formulas); O = P V is 2 x 8 tiles of
+// 16 x 16, four per wave, K = 32 (32 instructions).  Rows and keys beyond N are zero / masked.  Same mathematics as pd_attn_kernel;
+// the sums are MFMA-ordered instead of fmaf chains, so results agree to fp32 rounding (tests/test_gpu_parity_r3.py), not bit for bit.
+template <int SPLIT_OUT>
+__global__ __launch_bounds__(256) void pd_attn_mma_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int N, float out_scale) {
+    constexpr int LD = DH + 4, LS = 36;
+    extern __shared__ __attribute__((aligned(16))) float sm[];                   // Q, K, V: N + 1 rows each (row N is zero: every row / key
+    const int NR = N + 1;                                                       // index beyond N reads it), S [32][36]: scores, then probabilities
+    float *Q = sm, *Kk = Q + NR * LD, *V = Kk + NR * LD, *S = V + NR * LD;
+    const int b = blockIdx.x / NH, h = blockIdx.x % NH, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float scale = 0.08838834764831845f;   // 1/sqrt(128)
+    const float *base = qkv + (size_t)b * N * (3 * DM) + h * DH;
+    for (int idx = tid; idx < NR * (DH / 4); idx += 256) {
+        const int j = idx / (DH / 4), d4 = idx % (DH / 4);
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f), k = q, v = q;
+        if (j < N) {
+            const float *row = base + (size_t)j * (3 * DM) + d4 * 4;
+            q = *(const float4 *)row;
+            k = *(const float4 *)(row + DM);
+            v = *(const float4 *)(row + 2 * DM);
+            q.x *= scale; q.y *= scale; q.z *= scale; q.w *= scale;
+        }
+        *(float4 *)(Q + j * LD + d4 * 4) = q;
+        *(float4 *)(Kk + j * LD + d4 * 4) = k;
+        *(float4 *)(V + j * LD + d4 * 4) = v;
+    }
+    __syncthreads();
+    {   // scores: wave w owns the tile rows 16 (w >> 1) .., keys 16 (w & 1) ..; lane = (row or key) % 16 + 16 g feeds k = 16 c + 4 g + e
+        const float *qa = Q + min(16 * (wave >> 1) + (lane & 15), N) * LD + 4 * (lane >> 4);
+        const float *kb = Kk + min(16 * (wave & 1) + (lane & 15), N) * LD + 4 * (lane >> 4);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < DH / 16; ++c) {
+            const float4 a = *(const float4 *)(qa + 16 * c), k = *(const float4 *)(kb + 16 * c);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, k.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, k.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, k.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, k.w, acc, 0, 0, 0);
+        }
+        const int j = 16 * (wave & 1) + (lane & 15);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[(16 * (wave >> 1) + 4 * (lane >> 4) + e) * LS + j] = acc[e];
+    }
+    __syncthreads();
+    {   // softmax: 8 lanes per row, 4 keys per lane
+        const int i = tid >> 3, sub = tid & 7;
+        float4 sv = *(const float4 *)(S + i * LS + 4 * sub);
+        const int j0 = 4 * sub;
+        sv.x = j0 + 0 < N ? sv.x : -INFINITY;
+        sv.y = j0 + 1 < N ? sv.y : -INFINITY;
+        sv.z = j0 + 2 < N ? sv.z : -INFINITY;
+        sv.w = j0 + 3 < N ? sv.w : -INFINITY;
+        float mx = fmaxf(fmaxf(sv.x, sv.y), fmaxf(sv.z, sv.w));
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+        float4 e;
+        e.x = j0 + 0 < N ? expf(sv.x - mx) : 0.0f;
+        e.y = j0 + 1 < N ? expf(sv.y - mx) : 0.0f;
+        e.z = j0 + 2 < N ? expf(sv.z - mx) : 0.0f;
+        e.w = j0 + 3 < N ? expf(sv.w - mx) : 0.0f;
+        const float inv = 1.0f / pd_sum8((e.x + e.y) + (e.z + e.w));
+        e.x *= inv; e.y *= inv; e.z *= inv; e.w *= inv;
+        *(float4 *)(S + i * LS + 4 * sub) = e;
+    }
+    __syncthreads();
+    {   // O = P V: wave w owns the output columns [32 w, 32 w + 32) (two tiles) of both row tiles; k = key j = 16 c + 4 g + e
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *pa = S + (lane & 15) * LS + 4 * (lane >> 4);
+        const float *vb = V + 32 * wave + (lane & 15);
+        const int jg = 4 * (lane >> 4);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float4 p0 = *(const float4 *)(pa + 16 * c), p1 = *(const float4 *)(pa + 16 * LS + 16 * c);
+            float v0[4], v1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v0[e] = vb[min(16 * c + jg + e, N) * LD];
+                v1[e] = vb[min(16 * c + jg + e, N) * LD + 16];
+            }
+            const float a0[4] = {p0.x, p0.y, p0.z, p0.w}, a1[4] = {p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], v0[e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], v1[e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], v0[e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], v1[e], acc[1][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 16 * rt + 4 * (lane >> 4) + e;
+                if (i < N) {
+                    float *out = ctx + (size_t)(b * N + i) * DM + h * DH + 32 * wave + (lane & 15);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        if constexpr (SPLIT_OUT != 0) ((unsigned *)out)[16 * ct] = pd_split_word_as<SPLIT_OUT>(acc[rt][ct][e], out_scale);
+                        else out[16 * ct] = acc[rt][ct][e];
+                    }
+                }
+            }
+    }
+}
+static size_t attn_mma_lds(int N) { return ((size_t)3 * (N + 1) * (DH + 4) + 32 * 36) * sizeof(float); }
 static size_t attn_seq_lds(int N) { return ((size_t)3 * N * (DH + 4) + 4 * PD_ATTN_RPW * 64) * sizeof(float); }
 
 // --------------------------------------------------------------------------------------------
@@ -716,6 +830,7 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(set_lds(pd_attn_seq_kernel<0>, attn_seq_lds(64)));
     PD_TRY(set_lds(pd_attn_seq_kernel<1>, attn_seq_lds(64)));
     PD_TRY(set_lds(pd_attn_seq_kernel<2>, attn_seq_lds(64)));
+    PD_TRY(set_lds(pd_attn_mma_kernel<2>, attn_mma_lds(32)));
     PD_HIP_CHECK(hipDeviceSynchronize());
     return PD_OK;
 }
@@ -984,7 +1099,9 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
             hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 2>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 512.0f);
             if (strip & 1) pd_gemm_strip<0, 2, true>((const unsigned *)d->hn, DM, L.qkv_wh, DM, L.qkv_b, d->qkv, M, 3 * DM, s, L.qkv_cs);
             else pd_gemm_split<0, 1, 2, true>((const unsigned *)d->hn, DM, L.qkv_wh, DM, L.qkv_b, d->qkv, M, 3 * DM, s, L.qkv_cs);
-            hipLaunchKernelGGL(pd_attn_seq_kernel<2>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
+            static const int attn_mma = getenv("PD_DEN_ATTN_MMA") ? atoi(getenv("PD_DEN_ATTN_MMA")) : 1;     // development A / B
+            if (N <= 32 && attn_mma) hipLaunchKernelGGL(pd_attn_mma_kernel<2>, dim3(B * NH), dim3(256), attn_mma_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
+            else hipLaunchKernelGGL(pd_attn_seq_kernel<2>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
             if (strip & 2) pd_gemm_strip<2, 2, true>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
             else pd_gemm_split<2, 1, 1, true>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
             hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 2>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 512.0f);

@@ -301,3 +301,29 @@ def test_persistent_small_batch_denoiser(seeded_diffuser, oracle_weights):
     assert all(torch.equal(a, ref1) and torch.equal(b, ref1) for a, b in outs)
     eng2.close()
     eng.close()
+
+
+@pytest.mark.parametrize("B,N", [(40, 32), (160, 7), (64, 17), (35, 33)])
+def test_large_batch_default_mode_shapes(seeded_diffuser, oracle_weights, B, N):
+    """>= 1 024 token rows in the default mode (fp16-plane strip GEMMs, MFMA attention for N <= 32 frames, pd_attn_seq_kernel above):
+    sequence lengths that are full / ragged in the attention's 16 x 16 tiles and row counts that are ragged in the GEMMs' 64-row tiles,
+    against the fp64 oracle next to the exact mode."""
+    from posediffusion_amd.engine import PoseEngine
+    from posediffusion_amd.host import denoiser_state
+    dev = torch.device(DEV)
+    diff = seeded_diffuser.to(dev)
+    eng = PoseEngine(denoiser_state(diff.model), {k: v for k, v in diff.named_buffers(recurse=False)}, device=dev, max_B=B, max_N=N)
+    sd64 = {k: v.double() for k, v in oracle_weights.items()}
+    g = torch.Generator().manual_seed(B * 100 + N)
+    x, z = torch.randn(B, N, 9, generator=g), synth.make_z(B, N, seed=B)
+    sub = [0, 1, B // 2, B - 1]
+    with torch.no_grad():
+        ref = O.denoiser_forward(sd64, x[sub].double(), torch.full((len(sub),), 31, dtype=torch.long), z[sub].double())
+    eng.set_split_precision(0)
+    e0 = rel_err(eng.denoise(x.to(dev), z.to(dev), 31)[sub], ref)
+    eng.set_split_precision(2)
+    out = eng.denoise(x.to(dev), z.to(dev), 31)
+    e2 = rel_err(out[sub], ref)
+    print(f"B = {B}, N = {N}: exact {e0:.2e}, default {e2:.2e}")
+    assert torch.isfinite(out).all() and e0 < TOL and e2 <= max(2.0 * e0, 2e-6)
+    eng.close()

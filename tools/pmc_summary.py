@@ -53,7 +53,7 @@ def main():
                 "pd_embed_rows_kernel": 1, "pd_gemm_dma_kernel<0, false": 2,
                 # default mode there (fp16-plane encoder GEMMs): LayerNorm rows x 16, QKV x 8, out-projection + FF2 x 16, FF1 x 8, attention x 8
                 "pd_ln_rows_kernel<512, 2>": 16, "pd_gemm_strip_kernel<0, 2, true": 8, "pd_gemm_strip_kernel<2, 2, true": 16,
-                "pd_gemm_strip_kernel<4, 2, true": 8, "pd_attn_seq_kernel<2>": 8,
+                "pd_gemm_strip_kernel<4, 2, true": 8, "pd_attn_seq_kernel<2>": 8, "pd_attn_mma_kernel<2>": 8,
                 # exact mode (PD_OPT_DENOISER_SPLIT = 0): statistics x 16, QKV / FF1 with LayerNorm at the fragment reads x 8 each, out-projection + FF2 x 16
                 "pd_ln_stats_kernel": 16, "pd_gemm_dma_kernel<0, true": 8, "pd_gemm_dma_kernel<1, true": 8, "pd_gemm_dma_kernel<2, false": 16,
                 "pd_attn_seq_kernel<0>": 8}
