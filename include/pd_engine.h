@@ -334,7 +334,8 @@ int pd_time_kernel(pd_engine *eng, int what, int B, int N, const pd_ggs_cfg *cfg
 
 /* Synchronises the device and reports (PD_ERR_STATE) what the kernels flagged asynchronously since the last check: a
  * bounded spin of the GGS cross-workgroup exchange that gave up (bit 0), an out-of-range frame index (bit 1) or violated
- * pd_match_hints (bit 2) met by pd_ggs_set_matches_csr_async.  Clears the word.  PD_OK otherwise. */
+ * pd_match_hints (bit 2) met by pd_ggs_set_matches_csr_async, a grid barrier of the opt-in persistent small-batch denoiser launch that
+ * gave up (bit 3).  Clears the word.  PD_OK otherwise. */
 int pd_check_async_error(pd_engine *eng);
 
 /* Debug aid: switch the GGS kernel's in-kernel phase cycle counters on/off and (out6 != NULL)

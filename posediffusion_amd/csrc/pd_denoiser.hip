@@ -1055,6 +1055,7 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
         a.first_w = (const float4 *)d->first_wk; a.first_b = d->first_b;
         a.last0_w = (const float4 *)d->last0_wk; a.last0_b = d->last0_b;
         a.bar = d->small_bar;
+        a.err = eng->d_err;
         HeadArgs &ha = a.head;
         ha.hid = d->hid; ha.lnw = d->last_ln_w; ha.lnb = d->last_ln_b;
         ha.w3 = d->last3_w; ha.b3 = d->last3_b; ha.x = x; ha.noise = noise;

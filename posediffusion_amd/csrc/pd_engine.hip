@@ -499,10 +499,11 @@ extern "C" int pd_check_async_error(pd_engine *eng) {
     PD_HIP_CHECK(hipDeviceSynchronize());
     PD_HIP_CHECK(hipMemcpy(&v, eng->d_err, sizeof(v), hipMemcpyDeviceToHost));
     if (v) {
-        pd_set_error("asynchronous GGS error (flag=%u):%s%s%s", v,
+        pd_set_error("asynchronous error (flag=%u):%s%s%s%s", v,
                      (v & 1u) ? " a cross-workgroup exchange spin timed out (co-resident workgroups lost?);" : "",
                      (v & 2u) ? " pd_ggs_set_matches_csr_async met a frame index outside [0, n_frames);" : "",
-                     (v & 4u) ? " pd_ggs_set_matches_csr_async: pd_match_hints violated (more pairs / matches per pair than declared): the slot was emptied;" : "");
+                     (v & 4u) ? " pd_ggs_set_matches_csr_async: pd_match_hints violated (more pairs / matches per pair than declared): the slot was emptied;" : "",
+                     (v & 8u) ? " a grid barrier of the persistent small-batch denoiser launch timed out (PD_OPT_DENOISER_PERSISTENT: its workgroups could not all become resident);" : "");
         (void)hipMemset(eng->d_err, 0, sizeof(v));
         return PD_ERR_STATE;
     }
