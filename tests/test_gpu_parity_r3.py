@@ -327,3 +327,27 @@ def test_large_batch_default_mode_shapes(seeded_diffuser, oracle_weights, B, N):
     print(f"B = {B}, N = {N}: exact {e0:.2e}, default {e2:.2e}")
     assert torch.isfinite(out).all() and e0 < TOL and e2 <= max(2.0 * e0, 2e-6)
     eng.close()
+
+
+def test_engine_options_are_validated(seeded_diffuser):
+    """pd_engine_set_option (include/pd_engine.h): unknown options / values are refused with PD_ERR_INVALID_ARG and a message; the
+    split modes need an engine created for >= 1 024 token rows; objective flags other than PD_WEIGHTS_PRED_X0 are refused at creation."""
+    import ctypes as C
+    from posediffusion_amd.engine import PoseEngine
+    from posediffusion_amd.host import denoiser_state
+    dev = torch.device(DEV)
+    diff = seeded_diffuser.to(dev)
+    tables = {k: v for k, v in diff.named_buffers(recurse=False)}
+    small = PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=1, max_N=20)
+    for opt, val in ((_lib.PD_OPT_DENOISER_SPLIT, 3), (_lib.PD_OPT_DENOISER_SPLIT, -1), (_lib.PD_OPT_DENOISER_PERSISTENT, 2), (77, 0)):
+        assert small.lib.pd_engine_set_option(small._h, opt, val) != 0
+        assert b"pd_engine_set_option" in small.lib.pd_last_error()
+    for mode in (1, 2):                                                  # 20 token rows: there is no streamed path to switch
+        with pytest.raises(RuntimeError, match="streamed large-batch path"):
+            small.set_split_precision(mode)
+    small.set_split_precision(0)
+    small.set_persistent_denoiser(True)
+    small.set_persistent_denoiser(False)
+    small.close()
+    with pytest.raises(AssertionError):
+        PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=1, max_N=20, objective="pred_v")
