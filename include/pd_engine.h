@@ -200,12 +200,15 @@ int pd_ggs_loss_grad(pd_engine *eng, const float *x, int B, int N, int update_R,
 
 /* Engine options (no reference counterpart).
  *   PD_OPT_DENOISER_SPLIT  how the four Linear layers of every encoder layer run for batches of >= 1024 token rows (smaller
- *        batches always use the exact-fp32 matrix instruction).  Default: 2 on engines created with max_B x max_N >= 1024, else 0.
+ *        batches always use the exact-fp32 matrix instruction).  Default: 2 on engines created with max_B x max_N >= 1024, else 0
+ *        -- i.e. the results of such an engine (and bench.py's `value`) are those of the fp16-plane arithmetic described under 2
+ *        (22 operand bits, fp32 accumulation), not of the exact-fp32 instruction; select 0 for the latter.  Weights that hold
+ *        inf / NaN have no static bounds: such an engine stays on 0 and an explicit request for 2 returns PD_ERR_INVALID_ARG.
  *        0: every GEMM of the denoiser on the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32).
  *        1: FAST MODE: the four Linear layers of every encoder layer run in split precision
  *        on the bf16 matrix pipe (each fp32 operand as bf16 hi + bf16 lo, three products, fp32 accumulation: ~16 mantissa
  *        bits per operand); LayerNorm, softmax, residuals, `_first`, `_last` and the DDPM update stay fp32.  Narrower
- *        arithmetic than the reference's: a separately reported mode, never the default (deviation measured in
+ *        arithmetic than the reference's: a separately reported mode, never selected by the engine itself (deviation measured in
  *        tests/test_gpu_parity_r2.py and profiles/round2_denoiser_precision_study.json).  Smaller batches ignore it.
  *        2: the same kernels with FP16 halves (11 + 11 = 22 mantissa bits per operand, the dropped lo*lo term is 2^-22 of a
  *        product, fp32 accumulation) and power-of-two operand scales fixed at the switch from bounds that hold for every input
@@ -342,6 +345,15 @@ int pd_check_async_error(pd_engine *eng);
  * read them: {P1 pair F, P2 matches, exchange, P3 backward, P4 update, iterations} of workgroup 0. */
 int pd_debug_small_clocks(pd_engine *eng, unsigned *out56);   /* 100 MHz clock at the start and after each grid barrier of the last persistent small-batch denoiser launch */
 int pd_debug_ggs_prof(pd_engine *eng, int enable, long long *out6);   /* enable = 1 + wave index to record; out6 holds 16 values */
+/* The launch shape pd_ggs_guide / pd_sample would use for (B, N, cfg) with the matches uploaded now:
+ * out8 = {workgroups per sequence, item slots per workgroup, LDS bytes, two-hop kernel, waves per workgroup, LDS-DMA staging pieces,
+ * lane-per-item kernel, its LDS-resident steps}.  Lets a test pin which kernel the engine picks by itself. */
+int pd_debug_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, int *out8);
+/* Does v_mfma_f32_32x32x16_f16 keep fp16-SUBNORMAL operands (the `lo` halves of small elements in the fp16-plane denoiser mode are
+ * subnormal)?  One 32x32x16 product per case, every element of A = a, of B = b: out4 = {C[0][0] for (a, b) = (2^-20, 2^10): 2^-6 if kept;
+ * (2^10, 2^-20): 2^-6; (2^-20, 2^-4): 2^-20 (a subnormal times a normal, result far below fp16's range: fp32 accumulation);
+ * (1, 1): 16 (control)}; a flushed operand gives 0.  Runs on `stream` and synchronises it. */
+int pd_debug_mfma_f16_subnormal(float *out4_host, void *stream);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,8 @@ SIGNATURES = {
     "pd_check_async_error": (_i, [_vp]),
     "pd_debug_small_clocks": (_i, [_vp, C.POINTER(C.c_uint)]),
     "pd_debug_ggs_prof": (_i, [_vp, _i, C.POINTER(C.c_longlong)]),
+    "pd_debug_ggs_plan": (_i, [_vp, _i, _i, C.POINTER(pd_ggs_cfg), C.POINTER(C.c_int)]),
+    "pd_debug_mfma_f16_subnormal": (_i, [C.POINTER(C.c_float), _vp]),
 }
 
 _lib = None

@@ -844,10 +844,11 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
 //     (a convex combination: same bound) and the FF hidden rows after ReLU;                       scale 2^floor(log2(32768 / bound))
 //   * weights: 2^floor(log2(16384 / max |w|)).
 // Nothing can overflow (fp16 max 65 504), and hi + lo keeps 22 bits for every value above 2^-18 of its bound.
-static int floor_log2_ratio(double cap, double v) {
+static int floor_log2_ratio(double cap, double v) {       // v finite (pd_denoiser_build_scales rejects anything else)
     if (!(v > 0.0)) return 0;
-    int e = (int)floor(log2(cap / v));
-    return e < -60 ? -60 : (e > 60 ? 60 : e);
+    double e = floor(log2(cap / v));                       // clamped as a double: the cast below is always defined
+    e = e < -60.0 ? -60.0 : (e > 60.0 ? 60.0 : e);
+    return (int)e;
 }
 static int pd_denoiser_build_scales(pd_engine *eng) {
     PdDenoiserDev *d = eng->den;
@@ -860,13 +861,17 @@ static int pd_denoiser_build_scales(pd_engine *eng) {
         PD_HIP_CHECK(hipMemcpy(b.data(), bias, b.size() * sizeof(float), hipMemcpyDeviceToHost));
         return PD_OK;
     };
-    auto max_abs = [&]() { double m = 0; for (float v : w) m = fmax(m, fabs((double)v)); return m; };
+    // a checkpoint with inf / NaN has no static bound: the fp16-plane mode is refused (PD_ERR_INVALID_ARG) and the engine stays on
+    // the exact-fp32 kernels, which propagate the values like the reference does
+    bool finite = true;
+    auto max_abs = [&]() { double m = 0; for (float v : w) { finite = finite && isfinite(v); m = fmax(m, fabs((double)v)); } return m; };
     auto row_bound = [&](int r0, int r1, int K) {            // max over rows of sqrt(D) ||w_r||_2 + |b_r|
         double bound = 0;
         for (int r = r0; r < r1; ++r) {
             double q = 0;
             for (int k = 0; k < K; ++k) q += (double)w[(size_t)r * K + k] * w[(size_t)r * K + k];
             bound = fmax(bound, sqrt((double)DM) * sqrt(q) + fabs((double)b[r]));
+            finite = finite && isfinite(q) && isfinite(b[r]);
         }
         return bound;
     };
@@ -890,6 +895,11 @@ static int pd_denoiser_build_scales(pd_engine *eng) {
         L.ff2_cs = ldexpf(1.0f, -(e_ff + L.e_w2));
         L.ctx_scale = ldexpf(1.0f, e_ctx);
         L.ff_scale = ldexpf(1.0f, e_ff);
+        if (!finite) {
+            pd_set_error("denoiser: encoder layer %d holds non-finite weights or biases: no static operand bound exists, the fp16-plane "
+                         "mode (PD_OPT_DENOISER_SPLIT = 2) is not available for these weights", l);
+            return PD_ERR_INVALID_ARG;
+        }
     }
     d->scales_ready = true;
     return PD_OK;
@@ -1048,8 +1058,8 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
         a.x = x; a.z = z; a.temb = d->t_table + (size_t)t * 128;
         a.M = M; a.N = N; a.num_layers = d->num_layers;
         {
-            static const char *dbg = getenv("PD_SMALL_DBG");
-            a.dbg = dbg ? atoi(dbg) : 0;
+            static const int dbg = pd_dev_knob("PD_SMALL_DBG", 0);
+            a.dbg = dbg;
         }
         a.emb = d->emb; a.h = d->h; a.qkv = d->qkv; a.ctx = d->ctx; a.ff = d->ff; a.hid = d->hid;
         a.first_w = (const float4 *)d->first_wk; a.first_b = d->first_b;
@@ -1096,11 +1106,11 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
             // (22 mantissa bits, fp32 accumulation: fp32-grade results at the three-product rate)
             // GEMM kernel per shape: the strip kernel (A by LDS-DMA, no weight fragment fetched twice) or the round-1 two-plane kernel;
             // bitwise the same results (tools/split3_probe.hip).  PD_DEN_STRIP = bit mask {QKV, out, FF1, FF2} (development A / B)
-            static const int strip = getenv("PD_DEN_STRIP") ? atoi(getenv("PD_DEN_STRIP")) : 15;
+            static const int strip = pd_dev_knob("PD_DEN_STRIP", 15);
             hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 2>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 512.0f);
             if (strip & 1) pd_gemm_strip<0, 2, true>((const unsigned *)d->hn, DM, L.qkv_wh, DM, L.qkv_b, d->qkv, M, 3 * DM, s, L.qkv_cs);
             else pd_gemm_split<0, 1, 2, true>((const unsigned *)d->hn, DM, L.qkv_wh, DM, L.qkv_b, d->qkv, M, 3 * DM, s, L.qkv_cs);
-            static const int attn_mma = getenv("PD_DEN_ATTN_MMA") ? atoi(getenv("PD_DEN_ATTN_MMA")) : 1;     // development A / B
+            static const int attn_mma = pd_dev_knob("PD_DEN_ATTN_MMA", 1);     // development A / B
             if (N <= 32 && attn_mma) hipLaunchKernelGGL(pd_attn_mma_kernel<2>, dim3(B * NH), dim3(256), attn_mma_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
             else hipLaunchKernelGGL(pd_attn_seq_kernel<2>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
             if (strip & 2) pd_gemm_strip<2, 2, true>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
@@ -1167,3 +1177,44 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }
+
+// ---- probe: fp16-subnormal operands on the fp16 matrix pipe (pd_engine.h pd_debug_mfma_f16_subnormal) ----------------------------
+__global__ __launch_bounds__(64) void pd_mfma_f16_subnormal_kernel(float *out) {
+    const float av[4] = {9.5367431640625e-07f, 1024.0f, 9.5367431640625e-07f, 1.0f};      // 2^-20 is an fp16 subnormal (min normal 2^-14)
+    const float bv[4] = {1024.0f, 9.5367431640625e-07f, 0.0625f, 1.0f};
+    for (int c = 0; c < 4; ++c) {
+        f16x8 a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[e] = (_Float16)av[c];
+            b[e] = (_Float16)bv[c];
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+        if (threadIdx.x == 0) {
+            out[c] = acc[0];
+            out[4 + c] = (float)a[0];       // what the conversion itself kept of the operand
+        }
+    }
+}
+extern "C" int pd_debug_mfma_f16_subnormal(float *out4_host, void *stream) {
+    if (!out4_host) return PD_ERR_INVALID_ARG;
+    float *d = nullptr;
+    PD_HIP_CHECK(hipMalloc((void **)&d, 8 * sizeof(float)));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pd_mfma_f16_subnormal_kernel, dim3(1), dim3(64), 0, s, d);
+    float h[8];
+    hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        pd_set_error("pd_debug_mfma_f16_subnormal: %s", hipGetErrorString(e));
+        return PD_ERR_HIP;
+    }
+    for (int i = 0; i < 4; ++i) out4_host[i] = h[i];
+    if (h[4] == 0.0f) out4_host[0] = -1.0f;   // the fp32 -> fp16 conversion itself flushed 2^-20 (would make the probe meaningless)
+    return PD_OK;
+}
+

@@ -125,9 +125,13 @@ extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_en
         // engines large enough for the streamed path (>= 1024 token rows) run its encoder GEMMs on the fp16 matrix pipe by default:
         // fp16 hi + lo operands, static power-of-two scales, fp32 accumulation -- as close to fp64 as the exact-fp32 instruction
         // (tests/test_gpu_parity_r3.py, profiles/round3_fp16_plane_mode_study.json); PD_OPT_DENOISER_SPLIT = 0 selects the latter
+        // (weights with inf / NaN have no static bounds: such an engine stays on the exact-fp32 kernels, which propagate them as
+        // the reference does -- only an EXPLICIT request for the mode fails, pd_engine_set_option)
         if (pd_denoiser_has_streamed_path(eng)) {
-            if ((rc = pd_denoiser_build_split(eng, 2))) break;
-            eng->den_split = 2;
+            rc = pd_denoiser_build_split(eng, 2);
+            if (rc == PD_OK) eng->den_split = 2;
+            else if (rc == PD_ERR_INVALID_ARG) rc = PD_OK;
+            else break;
         }
         if ((rc = pd_ggs_init())) break;
         if ((rc = pd_ggs_ingest_init())) break;
@@ -521,3 +525,14 @@ extern "C" int pd_debug_ggs_prof(pd_engine *eng, int enable, long long *out6) {
     }
     return PD_OK;
 }
+
+extern "C" int pd_debug_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, int *out8) {
+    if (!eng || !cfg || !out8) return PD_ERR_INVALID_ARG;
+    PdGgsPlan plan;
+    int rc = pd_ggs_plan(eng, B, N, cfg, &plan);
+    if (rc) return rc;
+    const int v[8] = {plan.k, plan.n_slots, plan.lds, plan.two_hop, plan.waves, plan.stage_p, plan.lane, plan.lane_rl};
+    for (int i = 0; i < 8; ++i) out8[i] = v[i];
+    return PD_OK;
+}
+

@@ -1438,13 +1438,8 @@ struct PdLaneVariant {
 static const PdLaneVariant pd_lane_variants[PD_LANE_VARIANTS] = {{pd_ggs_lane_kernel<PD_LANE_RV, PD_LANE_DEPTH>, PD_LANE_RV, PD_LANE_DEPTH},
                                                                  {pd_ggs_lane_kernel<10, 6>, 10, 6}};
 static int pd_lane_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("PD_LANE_VARIANT");
-        v = e ? atoi(e) : 0;
-        if (v < 0 || v >= PD_LANE_VARIANTS) v = 0;
-    }
-    return v;
+    static const int v0 = pd_dev_knob("PD_LANE_VARIANT", 0);
+    return (v0 < 0 || v0 >= PD_LANE_VARIANTS) ? 0 : v0;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1817,7 +1812,7 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
             const int rv = pd_lane_variants[pd_lane_variant()].rv;
             const int pinc_rows = 2 * std::min(PD_LANE_MAX_ITEMS, std::max(pairs, 1));
             // PD_LANE_LDS_SPARE_KB (development knob): LDS left free beside the workgroup, e.g. for a denoiser GEMM workgroup of another context
-            static const int spare_kb = getenv("PD_LANE_LDS_SPARE_KB") ? atoi(getenv("PD_LANE_LDS_SPARE_KB")) : 0;
+            static const int spare_kb = pd_dev_knob("PD_LANE_LDS_SPARE_KB", 0);
             const int room = std::max(0, (int)((160 * 1024 - spare_kb * 1024 - (int)lane_lds_bytes(pinc_rows, 0)) / (PD_LANE_WAVES * 2048)));
             const int rl = std::max(0, std::min(room, steps - rv));
             if ((cfg->reserved & PD_GGS_CFG_LANE_ITEMS) || steps <= rv + rl) {
@@ -1832,6 +1827,11 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
             }
         }
     }
+    // k > 1: every workgroup publishes one exchange line per work item in the sequence's [epoch][item] region of d_xchg
+    // (pd_ggs_kernel, `xchg + epoch * xchg_stride + item * PD_XCHG_LINE`): a sequence with more items than the region holds
+    // (2 max_N^2 + 512 lines, pd_engine_create) would write into the other epoch's lines or the next slot's -- one workgroup
+    // per sequence then (no exchange at all).  The two-hop kernel checks its own, smaller line count below.
+    if (k > 1 && (size_t)max_items * PD_XCHG_LINE > eng->xchg_granules) k = 1;
     // many frames (several chunks of pairs): the two-hop kernel distributes the backward over the workgroups instead of
     // replicating it -- needs one work item per pair and room for its exchange lines; it keeps only a workgroup's own
     // item sums in LDS, so it also covers item counts whose full table would not fit
@@ -1884,6 +1884,11 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
     }
     if (lds > 160 * 1024) {
         pd_set_error("pd_ggs: %d work items need %zu B of LDS per workgroup (> 160 KiB) at B=%d", max_items, lds, B);
+        return PD_ERR_UNSUPPORTED;
+    }
+    if (k > 1 && !two_hop && (size_t)max_items * PD_XCHG_LINE > eng->xchg_granules) {   // (k grew again because one workgroup's LDS image did not fit)
+        pd_set_error("pd_ggs: %d work items per sequence exceed the exchange region (%zu lines) and do not fit one workgroup's LDS at B=%d",
+                     max_items, eng->xchg_granules / PD_XCHG_LINE, B);
         return PD_ERR_UNSUPPORTED;
     }
     // three waves per SIMD for the staged match pass at one workgroup per sequence with several rounds of items per wave (the

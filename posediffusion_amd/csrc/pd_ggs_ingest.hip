@@ -197,7 +197,7 @@ __global__ __launch_bounds__(ING_TABLE_THREADS) void ingest_tables_kernel(Ingest
             atomicOr(&flags[0], 4);
     }
     __syncthreads();
-    const bool bad = flags[0] != 0;
+    bool bad = flags[0] != 0;                          // (block-uniform; the lane-stream capacity check below may still set it)
     const int np = bad ? 0 : n_pairs;
     if (!bad && tid == 0) pair_item_off[n_pairs] = n_items;
     // (3) incidence positions.  Thread (c, n): c < n_pchunks walks chunk c's pairs for frame n (positions among the chunk's
@@ -313,9 +313,10 @@ __global__ __launch_bounds__(ING_TABLE_THREADS) void ingest_tables_kernel(Ingest
             base += scratch[w] * 128;
             l_steps = max(l_steps, scratch[w]);
         }
-        if (l_steps > A.LS_cap) {                              // cannot happen within the hints; never write past the blob
-            n_litems = 0;
-            n_lwaves = 0;
+        if (l_steps > A.LS_cap) {                              // cannot happen within the hints; never write past the blob -- and fail
+            n_litems = 0;                                      // CLOSED: the slot is emptied and the asynchronous error word raised, like every
+            n_lwaves = 0;                                      // other violated hint (the host descriptor still advertises lane tables, so a
+            bad = true;                                        // lane-kernel launch must find nothing to do rather than unwritten LDS rows)
         }
         __syncthreads();
     }
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(ING_TABLE_THREADS) void ingest_tables_kernel(Ingest
         D.l_item_len = l_len;
         D.l_max_steps = l_steps;
         D.M = bad ? 1 : S.M;                 // (M only scales 1 / M; never 0: the kernels divide by it)
-        D.n_pairs = np;
+        D.n_pairs = bad ? 0 : np;
         D.n_items = bad ? 0 : n_items;
         D.n_frames = N;
         D.sc = A.sc;

@@ -29,6 +29,20 @@
 
 void pd_set_error(const char *fmt, ...);
 
+// Development A / B switches (environment variables read once per process: PD_DEN_STRIP, PD_DEN_ATTN_MMA, PD_SMALL_DBG,
+// PD_LANE_VARIANT, PD_LANE_LDS_SPARE_KB).  They change which kernels a captured hipGraph bakes in and are not part of the
+// graph key, so the product build compiles them OUT (every knob is its default, a constant); `make EXTRA=-DPD_DEV_KNOBS`
+// brings them back for the probes under tools/.
+#ifdef PD_DEV_KNOBS
+#include <stdlib.h>
+static inline int pd_dev_knob(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+#define pd_dev_knob(name, dflt) (dflt)
+#endif
+
 #define PD_HIP_CHECK(expr)                                                                     \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \

@@ -132,7 +132,8 @@ class GaussianDiffusion(nn.Module):
             # the GGS workgroups of a sequence exchange sums through bounded spins; one that gave up (co-residency lost
             # to another process) raises here instead of returning garbage poses, and the flag is cleared for the next call
             eng.check_async()
-        if stats is not None and os.environ.get("PD_GGS_VERBOSE", "0") not in ("", "0"):
+        # (the reference prints these lines unconditionally, geometry_guided_sampling.py:124; PD_GGS_VERBOSE=0 mutes them)
+        if stats is not None and os.environ.get("PD_GGS_VERBOSE", "1") not in ("", "0"):
             st = stats.cpu()
             for k in range(st.shape[0]):
                 for s in range(5):

@@ -22,7 +22,7 @@ def geometry_guided_sampling(model_mean: torch.Tensor, t: int, matches_dict, GGS
     upload_matches(engine, matches_dict, model_mean.shape[0])
     out, stats = engine.ggs_guide(model_mean, t, make_ggs_cfg(GGS_cfg))
     engine.check_async()      # a bounded cross-workgroup spin that gave up must raise, not return garbage (and is cleared)
-    if os.environ.get("PD_GGS_VERBOSE", "0") not in ("", "0"):
+    if os.environ.get("PD_GGS_VERBOSE", "1") not in ("", "0"):     # the reference prints unconditionally (:124); PD_GGS_VERBOSE=0 mutes
         for b in range(stats.shape[0]):
             for s in stats[b].tolist():
                 print(f"t={t:02d} | sampson={s[0]:05f}")                         # geometry_guided_sampling.py:124

@@ -33,9 +33,7 @@ def run(script: str, overrides=()):
         if not os.path.abspath(getattr(sys.modules[name], "__file__", "") or "").startswith(DROPIN_PATH):
             del sys.modules[name]
     install_shims()
-    # the reference prints `t=.. | sampson=..` after each of the five optimisations of a guided step (geometry_guided_sampling.py:124):
-    # a demo.py user sees those lines, so the drop-in prints them too when it runs the reference's own entry point (PD_GGS_VERBOSE=0 mutes)
-    os.environ.setdefault("PD_GGS_VERBOSE", "1")
+    # (the drop-in prints the reference's `t=.. | sampson=..` lines, geometry_guided_sampling.py:124, by itself; PD_GGS_VERBOSE=0 mutes them)
     old_argv = sys.argv
     sys.argv = [script] + list(overrides)
     try:

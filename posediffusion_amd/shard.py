@@ -23,13 +23,14 @@ def partition(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
+def init_distributed(backend: str | None = None, force: bool = False) -> Tuple[int, int, int]:
     """-> (rank, world_size, local_rank); initialises torch.distributed when WORLD_SIZE > 1
-    (backend "nccl" = RCCL on ROCm; "gloo" for the CPU tests)."""
+    (backend "nccl" = RCCL on ROCm; "gloo" for the CPU tests).  ``force``: initialise a process group of ONE rank too
+    (bench.py --dry-dist: the RCCL call sites of the N > 1 path then execute on a single-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             # PD_DIST_BACKEND=gloo: several ranks on ONE GPU (functional check of the N > 1 path on a 1-GPU box; RCCL needs
             # a device per rank)
@@ -42,10 +43,11 @@ def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
-def gather_poses(local: torch.Tensor, n_total: int) -> torch.Tensor:
+def gather_poses(local: torch.Tensor, n_total: int, force_collective: bool = False) -> torch.Tensor:
     """all_gather of the per-rank [B_local, N, 9] results into [n_total, N, 9] in global sequence
-    order (ranks may hold different B_local; shorter shards are padded for the collective)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    order (ranks may hold different B_local; shorter shards are padded for the collective).
+    ``force_collective``: run the collective in a group of one rank as well (bench.py --dry-dist)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return local
     world = dist.get_world_size()
     sizes = [partition(n_total, world, r) for r in range(world)]
@@ -60,16 +62,16 @@ def gather_poses(local: torch.Tensor, n_total: int) -> torch.Tensor:
     return torch.cat([bufs[r][: b - a] for r, (a, b) in enumerate(sizes)], dim=0).to(dev)
 
 
-def max_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def max_over_ranks(value: float, device, force_collective: bool = False) -> float:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return value
     t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+def barrier(force_collective: bool = False):
+    if dist.is_initialized() and (dist.get_world_size() > 1 or force_collective):
         dist.barrier()
 
 

@@ -1,4 +1,4 @@
-// pd_gemm_split3.h -- fp32-grade GEMM on the bf16 matrix pipe: every fp32 operand is carried as THREE bf16 values
+// pd_gemm_split3.h (tools/: a measured alternative, not part of libpd_engine.so; used by split3_probe.hip only) -- fp32-grade GEMM on the bf16 matrix pipe: every fp32 operand is carried as THREE bf16 values
 // (x = hi + mid + lo exactly to 24 mantissa bits: each of the two differences below is exact in fp32), and
 //     x * w ~= hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid)
 // -- the six products whose weight is >= 2^-16 of the leading one; the three dropped ones (mid*lo, lo*mid, lo*lo) are <= 2^-24 of it,
@@ -10,7 +10,7 @@
 // into LDS (LayerNorm applied first where the GEMM follows one); the weights are split once, at engine creation, into MFMA fragment
 // order and go from L2 straight to registers one k-chunk ahead.
 #pragma once
-#include "pd_gemm_stream.h"
+#include "../posediffusion_amd/csrc/pd_gemm_stream.h"
 
 #define PD_S3_LR 52      // LDS row stride in 32-bit words: 4 groups of 8 k x (hi | mid | lo) x 4 words, + 4: fragment reads conflict free
 

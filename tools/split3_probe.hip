@@ -1,7 +1,7 @@
-// split3_probe.hip -- the six-product bf16 GEMM (csrc/pd_gemm_split3.h) alone (development probe, not part of the library): error against
+// split3_probe.hip -- the six-product bf16 GEMM (tools/pd_gemm_split3.h) alone (development probe, not part of the library): error against
 // an fp64 CPU product on sampled rows next to the exact-fp32 MFMA kernel's, and time per tile shape at the bench's row counts.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -Iinclude tools/split3_probe.hip -o tools/split3_probe && tools/split3_probe
-#include "../posediffusion_amd/csrc/pd_gemm_split3.h"
+#include "pd_gemm_split3.h"
 #include "../posediffusion_amd/csrc/pd_gemm_split.h"
 #include <math.h>
 #include <stdio.h>
