@@ -111,6 +111,9 @@ typedef struct pd_ggs_cfg {
                                        * <= 40 matches per lane item).  Same valid sets and formulas as the wave-per-item kernels, another
                                        * (fixed) summation order: results agree to rounding (~1e-6), not bit for bit */
 #define PD_GGS_CFG_NO_LANE_ITEMS 16   /* pd_ggs_cfg.reserved: never pick the lane-per-item kernel (comparison / testing) */
+#define PD_GGS_CFG_XCHG_SPREAD 32     /* pd_ggs_cfg.reserved: with several workgroups per sequence, do NOT place a sequence's workgroups on one XCD
+                                       * (where the engine would: at most 32 of them per XCD) -- the exchange then goes through write-through
+                                       * agent-scope stores as in rounds 1-3; bitwise the same results -- comparison / testing */
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
 

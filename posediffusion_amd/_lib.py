@@ -57,6 +57,7 @@ PD_OPT_DENOISER_PERSISTENT = 3
 PD_WEIGHTS_PRED_X0 = 1
 PD_GGS_CFG_LANE_ITEMS = 8       # lane-per-item kernel (the throughput shape) whatever the batch size
 PD_GGS_CFG_NO_LANE_ITEMS = 16   # never the lane-per-item kernel
+PD_GGS_CFG_XCHG_SPREAD = 32     # k > 1: no XCD-local placement of a sequence's workgroups (comparison)
 PD_OPT_DENOISER_SPLIT = 2
 
 

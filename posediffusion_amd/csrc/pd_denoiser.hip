@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
         else row = m0 + 16 * (reg >> 2) + 4 * (lane >> 4) + (reg & 3);
         if (row < g.M) {
             float *cp = g.C + (size_t)row * g.Nout + col;
-            if constexpr (EPI == 1) v = fmaxf(v, 0.0f);
+            if constexpr (EPI == 1) v = pd_relu(v);
             if constexpr (EPI == 2) v += *cp;
             *cp = v;
         }
@@ -646,8 +646,8 @@ __global__ __launch_bounds__(256) void pd_tail_kernel(HeadArgs g) {
     const float mean = pd_wave_sum(v0 + v1) * (1.0f / HID);
     const float d0 = v0 - mean, d1 = v1 - mean;
     const float rstd = 1.0f / sqrtf(pd_wave_sum(d0 * d0 + d1 * d1) * (1.0f / HID) + 1e-5f);
-    const float a0 = fmaxf(d0 * rstd * g.lnw[lane] + g.lnb[lane], 0.0f);
-    const float a1 = fmaxf(d1 * rstd * g.lnw[64 + lane] + g.lnb[64 + lane], 0.0f);
+    const float a0 = pd_relu(d0 * rstd * g.lnw[lane] + g.lnb[lane]);
+    const float a1 = pd_relu(d1 * rstd * g.lnw[64 + lane] + g.lnb[64 + lane]);
     float e = 0.0f;
 #pragma unroll
     for (int o = 0; o < 9; ++o) {

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
                 const int row = r0 + (i & 3) + 8 * (i >> 2);
                 float v = F16 ? fmaf(acc[mi][ni][i], g.c_scale, bias) : acc[mi][ni][i] + bias;
                 if constexpr (EPI == 3) v = vit_gelu_fast(v);
-                if constexpr (EPI == 4) v = fmaxf(v, 0.0f);
+                if constexpr (EPI == 4) v = pd_relu(v);
                 if constexpr (EPI == 2) v += res[i];
                 if (row < g.M) {
                     if constexpr (EPI == 3 || EPI == 4)
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
                 const int row = r0 + (i & 3) + 8 * (i >> 2);
                 float v = F16 ? fmaf(acc[mi][c][i], g.c_scale, bias) : acc[mi][c][i] + bias;
                 if constexpr (EPI == 3) v = vit_gelu_fast(v);
-                if constexpr (EPI == 4) v = fmaxf(v, 0.0f);
+                if constexpr (EPI == 4) v = pd_relu(v);
                 if constexpr (EPI == 2) v += res[i];
                 if (row < g.M) {
                     if constexpr (EPI == 3 || EPI == 4)

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
             for (int i = 0; i < 16; ++i) {
                 const int row = r0 + (i & 3) + 8 * (i >> 2);
                 float v = acc[mi][ni][i] + bias;
-                if constexpr (EPI == 1) v = fmaxf(v, 0.0f);
+                if constexpr (EPI == 1) v = pd_relu(v);
                 if constexpr (EPI == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
                 if constexpr (EPI == 2) v += res[i];
                 if (row < g.M) g.C[(size_t)row * g.Nout + col] = v;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void pd_gemm_dma_kernel(PdStreamArgs g) {
             for (int i = 0; i < 16; ++i) {
                 const int row = r0 + (i & 3) + 8 * (i >> 2);
                 float v = acc[mi][ni][i] + bias;
-                if constexpr (EPI == 1) v = fmaxf(v, 0.0f);
+                if constexpr (EPI == 1) v = pd_relu(v);
                 if constexpr (EPI == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
                 if constexpr (EPI == 2) v += res[i];
                 if (row < g.M) g.C[(size_t)row * g.Nout + col] = v;

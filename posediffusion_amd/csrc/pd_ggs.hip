@@ -380,7 +380,8 @@ __device__ __forceinline__ void sampson_stepW(const v2f (&u1)[W], const v2f (&v1
 }
 
 // LDS carve (floats).  Everything lives in the one dynamic region (guide G17).
-#define PD_GGS_LDS_FIXED (64 * 9 + 64 * 3 + 64 * 2 + 64 * 2 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8 + 64 * 16 + 2 * 64 * 9)   // + pinc_rows * 16
+#define PD_GGS_PSUM_FLOATS (PD_GGS_FAST_FRAMES * 48 > 64 * 16 ? PD_GGS_FAST_FRAMES * 48 : 64 * 16)
+#define PD_GGS_LDS_FIXED (64 * 9 + 64 * 3 + 64 * 2 + 64 * 2 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8 + 32 + PD_GGS_PSUM_FLOATS + 2 * 64 * 9)   // + pinc_rows * 16
 struct Lds {
     float *Rc;     // [64*9]  R_cv per frame  (opencv_from_cameras_projection)
     float *tc;     // [64*3]
@@ -391,11 +392,16 @@ struct Lds {
     float *gR;     // [64*9]  per-frame dL/dR  (PyTorch3D R, un-normalised)
     float *gA;     // [64*4]  per-frame partial dL/dA {00,02,11,12}
     float *ctl;    // [8]     ctl[0] = stage done flag, ctl[1] = abort
+    long long *prof;   // [16] phase cycle counters of the one wave that records them (pd_debug_ggs_prof): in LDS, not in 20 registers of every wave
     float *xst;    // [64*9]  pose parameters per frame (lane = frame in P4) -- in LDS, not in registers: wave 0 touches them once per
     float *mst;    // [64*9]  iteration, and 18 VGPRs held by every wave for the whole launch is what the match pass cannot spare
     float *pinc;   // [pinc_rows*16] backward results of the current chunk of pairs, one row per (pair, side), frame-sorted
                    //   (pinc_rows = 2 x pairs per chunk, at most PD_GGS_PINC_ROWS; the two-hop kernel always carves the maximum)
-    float *psum;   // [64*16]  per-frame partial sums across chunks (N > 32 only)
+    float *psum;   // [PD_GGS_PSUM_FLOATS] general serial path (more than PD_GGS_FAST_FRAMES frames or several chunks of pairs): per-frame
+                   //   partial sums across chunks [64*16]
+    float *W;      // = psum, fast serial path: per frame the 4 x 9 Jacobian d(R entries)/d(quaternion) of the CURRENT parameters, rows
+                   //   padded to 12 floats [PD_GGS_FAST_FRAMES*48] (jac_all)
+    float *gq;     // = gR: [64*8] per frame {dL/dq (4), dL/dT (3), -} as P4 reads them (un-normalised: not yet divided by n_valid)
     int4 *itab;    // [n_slots] (first match, count, i, j) of the local items
     int *incoff;   // [PD_GGS_MAX_PCHUNKS][68] per chunk of pairs: CSR offsets of its incidences per frame
     float *F;      // [n_slots*PD_F_STRIDE]
@@ -414,11 +420,14 @@ __device__ __forceinline__ Lds carve(float *base, int n_slots, int pinc_rows, in
     L.gR = L.gT + 64 * 3;
     L.gA = L.gR + 64 * 9;
     L.ctl = L.gA + 64 * 4;
-    L.xst = L.ctl + 8;
+    L.prof = (long long *)(L.ctl + 8);
+    L.xst = L.ctl + 8 + 32;
     L.mst = L.xst + 64 * 9;
     L.pinc = L.mst + 64 * 9;
     L.psum = L.pinc + pinc_rows * 16;
-    L.itab = (int4 *)(L.psum + 64 * 16);
+    L.W = L.psum;
+    L.gq = L.gR;
+    L.itab = (int4 *)(L.psum + PD_GGS_PSUM_FLOATS);
     L.incoff = (int *)(L.itab + n_slots);
     L.F = (float *)(L.incoff + PD_GGS_MAX_PCHUNKS * 68);
     L.item = L.F + n_slots * PD_F_STRIDE;
@@ -434,9 +443,9 @@ static size_t ggs_lds_bytes(int n_slots, int n_items, int pinc_rows, int stage_p
 }
 
 // decode one frame's 9-vector into R_cv, t_cv, focal (camera_transform.py:80-97 + pytorch3d
-// quaternion_to_matrix + opencv_from_cameras_projection); executed by lane n of wave 0.
-__device__ __forceinline__ void decode_frame(const float *x, float *Rc, float *tc, float &flx, float &fly,
-                                             float &px, float &py) {
+// quaternion_to_matrix + opencv_from_cameras_projection); executed by lane n of wave 0.  In three parts, so that a stage
+// that leaves R / T / the focal lengths alone (geometry_guided_sampling.py:144-151) does not recompute them.
+__device__ __forceinline__ void decode_frame_r(const float *x, float *Rc) {
     const float r = x[3], i = x[4], j = x[5], k = x[6];
     const float two_s = 2.0f * pd_rcp(r * r + i * i + j * j + k * k);
     float R[9];
@@ -454,21 +463,37 @@ __device__ __forceinline__ void decode_frame(const float *x, float *Rc, float *t
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int c = 0; c < 3; ++c) Rc[a * 3 + c] = (a < 2 ? -1.0f : 1.0f) * R[c * 3 + a];
+}
+__device__ __forceinline__ void decode_frame_t(const float *x, float *tc) {
     tc[0] = -x[0];
     tc[1] = -x[1];
     tc[2] = x[2];
+}
+__device__ __forceinline__ void decode_frame_fl(const float *x, float &flx, float &fly, float &px, float &py) {
     const float fx = __expf(x[7] + 1.8f), fy = __expf(x[8] + 1.8f);
     px = (fx >= 0.1f && fx <= 20.0f) ? 1.0f : 0.0f;   // torch.clamp backward passes min <= v <= max
     py = (fy >= 0.1f && fy <= 20.0f) ? 1.0f : 0.0f;
     flx = fminf(fmaxf(fx, 0.1f), 20.0f);
     fly = fminf(fmaxf(fy, 0.1f), 20.0f);
 }
+__device__ __forceinline__ void decode_frame(const float *x, float *Rc, float *tc, float &flx, float &fly,
+                                             float &px, float &py) {
+    decode_frame_r(x, Rc);
+    decode_frame_t(x, tc);
+    decode_frame_fl(x, flx, fly, px, py);
+}
 
-// wave 0: publish the decoded cameras of the current parameters to LDS
-__device__ __forceinline__ void decode_all(const Lds &L, const float *xr, int lane, int N, const PdSeqDesc &D) {
+// wave 0: publish the decoded cameras of the current parameters to LDS (do_*: the parts whose parameters changed)
+__device__ __forceinline__ void decode_all(const Lds &L, const float *xr, int lane, int N, const PdSeqDesc &D, bool do_r = true,
+                                           bool do_t = true, bool do_fl = true) {
+    if (lane < N) {
+        if (do_r) decode_frame_r(xr, &L.Rc[lane * 9]);
+        if (do_t) decode_frame_t(xr, &L.tc[lane * 3]);
+    }
+    if (!do_fl) return;                               // (wave-uniform)
     float flx = 0.f, fly = 0.f, px = 0.f, py = 0.f;
     if (lane < N) {
-        decode_frame(xr, &L.Rc[lane * 9], &L.tc[lane * 3], flx, fly, px, py);
+        decode_frame_fl(xr, flx, fly, px, py);
         L.fl[lane * 2] = flx;
         L.fl[lane * 2 + 1] = fly;
         L.flp[lane * 2] = px;
@@ -485,6 +510,58 @@ __device__ __forceinline__ void decode_all(const Lds &L, const float *xr, int la
         L.cam[3] = -D.cy * a1;
         L.cam[4] = fbx;
         L.cam[5] = fby;
+    }
+}
+
+// lane `K` of this lane's 16-lane row (DPP row_newbcast); the whole row must be active
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, false));
+}
+
+// The chain rule from dL/dR (PyTorch3D R = I + two_s Pm(q), two_s = 2 / |q|^2) to the un-normalised quaternion is LINEAR in dL/dR:
+// dL/dq_x = sum_c J[x][c] dL/dR[c], J[x][c] = two_s dPm_c/dq_x - two_s^2 q_x Pm_c.  J depends on the parameters only, so an idle wave
+// (lane = frame) forms it while the others compute the next F's -- off the critical path -- and the per-frame sums of the backward
+// phase turn into dL/dq with nine multiply-adds per quaternion component.  Stored for the ORDER those sums come in:
+// S[m], m = a * 3 + b, = D[a] dL/dRc[a][b] = dL/dR[b][a]  ->  W[frame][x][m] = J[x][b * 3 + a]   (rows padded to 12 floats).
+__device__ __forceinline__ void jac_row(const float (&q)[4], const float (&dPx)[9], float qx, float (&w)[9]) {
+    const float r = q[0], i = q[1], j = q[2], k = q[3];
+    const float rn2 = pd_rcp(r * r + i * i + j * j + k * k);
+    const float ts = 2.0f * rn2, qs = ts * ts * qx;
+    const float Pm[9] = {-(j * j + k * k), i * j - k * r, i * k + j * r, i * j + k * r, -(i * i + k * k), j * k - i * r, i * k - j * r, j * k + i * r, -(i * i + j * j)};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) w[a * 3 + b2] = ts * dPx[b2 * 3 + a] - qs * Pm[b2 * 3 + a];
+}
+// row x of the Jacobian of the quaternion q (x is a compile-time constant in jac_all's unrolled loop, a lane value in the general path)
+__device__ __forceinline__ void jac_row_x(const float (&q)[4], int x, float (&w)[9]) {
+    const float r = q[0], i = q[1], j = q[2], k = q[3];
+    if (x == 0) {
+        const float d[9] = {0.0f, -k, j, k, 0.0f, -i, -j, i, 0.0f};
+        jac_row(q, d, r, w);
+    } else if (x == 1) {
+        const float d[9] = {0.0f, j, k, j, -2.0f * i, -r, k, r, -2.0f * i};
+        jac_row(q, d, i, w);
+    } else if (x == 2) {
+        const float d[9] = {-2.0f * j, i, r, i, 0.0f, k, -r, k, -2.0f * j};
+        jac_row(q, d, j, w);
+    } else {
+        const float d[9] = {-2.0f * k, -r, i, r, -2.0f * k, j, i, j, 0.0f};
+        jac_row(q, d, k, w);
+    }
+}
+__device__ __forceinline__ void jac_all(const Lds &L, int lane, int N) {
+    if (lane >= N || N > PD_GGS_FAST_FRAMES) return;
+    const float q[4] = {L.xst[lane * 9 + 3], L.xst[lane * 9 + 4], L.xst[lane * 9 + 5], L.xst[lane * 9 + 6]};
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        float w[9];
+        jac_row_x(q, x, w);
+        float4 *dst = (float4 *)(L.W + (lane * 4 + x) * 12);
+        dst[0] = make_float4(w[0], w[1], w[2], w[3]);
+        dst[1] = make_float4(w[4], w[5], w[6], w[7]);
+        dst[2] = make_float4(w[8], 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -678,7 +755,8 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
     static_assert(!(RESIDENT && SINGLE) && (NW == PD_GGS_WAVES || STAGE_P > 0), "12 waves: the staged variants only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x % B, wg = blockIdx.x / B;   // XCD-aware: see header comment
+    const int b = blockIdx.x % B, wg = blockIdx.x / B;   // XCD-aware: see header comment (B: the launch's sequences, padded to 8 if P.xchg_local)
+    if (b >= P.n_seqs) return;                           // (padding blocks of the XCD-local placement)
     const PdSeqDesc D = P.seqs[b];
     const int N = P.N, k = P.k;
     const int nW = k * PD_GGS_WAVES;
@@ -712,6 +790,7 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
     if (tid == 0) {
         L.ctl[0] = 0.0f;
         L.ctl[1] = 0.0f;
+        L.ctl[3] = 0.0f;
     }
     if (wave == 0) {
         float xr0[9];
@@ -720,6 +799,38 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
         decode_all(L, xr0, lane, N, D);
     }
     __syncthreads();
+    // k > 1, XCD-local placement (P.xchg_local: the launch maps block -> (sequence, workgroup) so that the dispatcher's round-robin puts
+    // all workgroups of a sequence on one XCD): the per-iteration exchange can then stay in that XCD's L2 -- plain stores instead of
+    // write-through agent-scope ones, 1.1 us instead of 1.9 us per exchange of 24 workgroups (tools/xchg_probe.hip).  The placement is
+    // the dispatcher's habit, not a guarantee, so it is VERIFIED once per launch: every workgroup publishes its XCC_ID the safe way
+    // (agent scope) and all of them read all of them; only if they agree do the stores stay local.  Same answer in every workgroup.
+    bool xl = false;
+    if (k > 1 && P.xchg_local) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 15u;
+        u64 *ids = xchg + (size_t)P.xchg_stride - 256;          // the last 256 granules of the sequence's first slot (pd_ggs_plan keeps them free)
+        if (tid == 0) __hip_atomic_store(ids + wg, (0x7fffffffull << 32) | (u64)(xcc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool same = true, fail = false;
+        if (tid < k) {
+            unsigned spins = 0;
+            u64 v;
+            for (;;) {
+                v = __hip_atomic_load(ids + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 32) == 0x7fffffffull) break;
+                if (++spins > (1u << 20)) {
+                    fail = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            same = !fail && (unsigned)(v & 0xffffffffull) == xcc + 1;
+        }
+        if (fail) atomicOr(P.err_flag, 1u);
+        if (!same) L.ctl[3] = 1.0f;                              // (zeroed before the barrier above; no static LDS: the dynamic region is the whole 160 KiB)
+        __syncthreads();
+        xl = L.ctl[3] == 0.0f;
+    }
     // matches of this wave's first item stay in registers for the whole launch when every wave owns
     // at most one item (the k = ceil(items/8) regime): no per-iteration match traffic at all
     constexpr bool resident = RESIDENT;
@@ -774,39 +885,51 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
     };
     if (staged) stage_item(wave, 0);
 
-    // P3b role of this thread, constant for the launch: thread (fb_n, fb_c) sums component fb_c of the
-    // incidences of frame fb_n (frames 0..31 in one pass) and owns the matching gradient slot
+    // ---- geometry of the serial phases ------------------------------------------------------------------------------------------
+    // FAST (<= PD_GGS_FAST_FRAMES frames, one chunk of pairs -- every BASELINE config of this kernel): the rows of the pair backward are
+    // laid out per frame at a FIXED stride `cap` (the largest number of pairs incident to a frame, rounded up to 4; unused rows stay
+    // zero for the whole launch), thread (fb_n, fb_c) = (frame, component) of the first 16 N threads sums its column without index
+    // clamps or selects, turns the nine dL/dR sums into dL/dq inside its 16-lane row (row_bcast + the Jacobian of jac_all) and hands P4
+    // seven numbers per frame; waves 6 and 7 form the dL/dA and loss totals beside them.
+    // GENERAL (more frames or several chunks of pairs): CSR rows, partial sums carried across chunks in LDS, as before.
     const int fb_n = tid >> 4, fb_c = tid & 15;
-    const int fb_lo = fb_n < N ? L.incoff[fb_n] : 0, fb_hi = fb_n < N ? L.incoff[fb_n + 1] : 0;
-    float *fb_dst;
-    float fb_sign;
-    if (fb_c < 9) {          // value = dL/dRc[aa][bb]; gR[b][a] = D[a] gRc[a][b]
-        const int aa = fb_c / 3, bb = fb_c % 3;
-        fb_dst = &L.gR[fb_n * 9 + bb * 3 + aa];
-        fb_sign = aa < 2 ? -1.0f : 1.0f;
-    } else if (fb_c < 12) {  // dL/dT = D dL/dtc
-        fb_dst = &L.gT[fb_n * 3 + (fb_c - 9)];
-        fb_sign = (fb_c - 9) < 2 ? -1.0f : 1.0f;
-    } else {
-        fb_dst = &L.gA[fb_n * 4 + (fb_c - 12)];
-        fb_sign = 1.0f;
+    const float fb_sign = (fb_c < 9) ? (fb_c < 6 ? -1.0f : 1.0f) : ((fb_c < 11) ? -1.0f : 1.0f);   // D = diag(-1,-1,1): rows a < 2 of dL/dRc, entries < 2 of dL/dtc
+    int cap = 0;
+    if (D.n_pchunks == 1 && N <= PD_GGS_FAST_FRAMES) {
+        int dmax = 0;
+        for (int n = 0; n < N; ++n) dmax = max(dmax, L.incoff[n + 1] - L.incoff[n]);
+        cap = (dmax + 3) & ~3;
     }
-    const bool small_n = N <= PD_GGS_THREADS / 16;              // every frame has its own thread group
-    const bool spare_wave = N * 16 <= (PD_GGS_WAVES - 1) * 64;   // the last wave is entirely idle in P3b
+    // a frame's rows start `rstride` = cap + 1 rows apart: with cap % 4 == 0 the four frames a wave sums then sit 16 banks apart -- 64 lanes
+    // on 64 distinct LDS banks (at a stride of cap rows all four would share 16 banks: every column load a four-way conflict)
+    const int rstride = cap + 1;
+    const bool fast34 = cap > 0 && N * rstride <= pinc_rows;    // (block-uniform)
+    const int n_row_waves = (N * 16 + 63) >> 6;                 // waves that hold (frame, component) threads in the fast path (<= 6)
+    const int ga_parts = fast34 ? n_row_waves : 1;              // dL/dA partials P4 adds up (fast: one per row wave; general: the totals)
+    constexpr int W_LOSS = PD_GGS_WAVES - 1;                    // idle in the fast backward phase: forms the loss totals meanwhile
     // pair-level backward in chunks of PD_GGS_THREADS pairs (one chunk up to N = 32); chunk 0's table entry is hoisted
-    const int4 my_pair = (p3t && tid < D.n_pairs) ? D.ptab[tid] : make_int4(0, 0, 0, 0);
+    int4 my_pair = (p3t && tid < D.n_pairs) ? D.ptab[tid] : make_int4(0, 0, 0, 0);
+    if (fast34) {
+        if (p3t && tid < D.n_pairs) {       // CSR positions -> fixed-stride rows
+            const int pi = my_pair.x & 0xff, pj = my_pair.x >> 8;
+            const int r0 = pi * rstride + ((my_pair.w & 0xffff) - L.incoff[pi]), r1 = pj * rstride + ((my_pair.w >> 16) - L.incoff[pj]);
+            my_pair.w = r0 | (r1 << 16);
+        }
+        for (int q = tid; q < N * rstride * 4; q += NT) ((float4 *)L.pinc)[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (wave == PD_GGS_WAVES - 1 && fast34) jac_all(L, lane, N);   // (L.xst was published before the barrier above; first read two barriers from here)
     unsigned epoch = 0;
     int trace_row = 0;
     // the in-kernel cycle counters cost 24 VGPRs for the whole launch: compiled out of the 12-wave variants, which run at the
     // 168-register limit (build with -DPD_GGS_PROF12 to study those; pd_ggs_plan keeps 8 waves while profiling is on otherwise)
     constexpr bool HAS_PROF = !SINGLE || PD_GGS_PROF12;
     const bool prof = HAS_PROF && P.prof != nullptr && blockIdx.x == 0 && wave == (P.prof_wave & 7);   // one wave of WG 0
-    #ifdef PD_GGS_PROF2   // build with -DPD_GGS_PROF2 for the timers INSIDE the match pass (claim / DMA issue / wait / pass / reduce)
-    long long pt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pc = 0, pq = 0;
-#else
-    long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pc = 0, pq = 0;
-#endif
-#define PD_PROF(i) do { if (prof) { const long long _n = __builtin_readcyclecounter(); pt[i] += _n - pc; pc = _n; } } while (0)
+    // (build with -DPD_GGS_PROF2 for the timers INSIDE the match pass: claim / DMA issue / wait / pass / reduce -> counters 10..14)
+    long long pc = 0, pq = 0;
+    if (prof && lane == 0) {
+        for (int i = 0; i < 16; ++i) L.prof[i] = 0;
+    }
+#define PD_PROF(i) do { if (prof) { const long long _n = __builtin_readcyclecounter(); if (lane == 0) L.prof[i] += _n - pc; pc = _n; } } while (0)
     const float inv_M = 1.0f / (float)D.M;
     for (int st = 0; st < P.n_stages; ++st) {
         const PdGgsStage S = P.stages[st];
@@ -817,6 +940,8 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
             // ---- P1: F for the pairs of this workgroup's items -------------------------------
             const Cam cam = {L.cam[0], L.cam[1], L.cam[2], L.cam[3]};
             if (tid == 0) *q_ctr = NW;                    // first slot the match pass hands out dynamically
+            // an idle wave: the quaternion Jacobian of the parameters the previous iteration left (read two barriers from here)
+            if (wave == PD_GGS_WAVES - 1 && S.update_R && fast34) jac_all(L, lane, N);
             for (int s = tid; s < n_slots; s += NT) {
                 const int4 e = L.itab[s];
                 if (e.y > 0) {
@@ -855,7 +980,7 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
             for (int s = wave; s < n_local;) {
                 const int item = wg * PD_GGS_WAVES + (s & 7) + (s >> 3) * nW;
 #ifdef PD_GGS_PROF2
-#define PD_PROF2(i) do { if (prof) { const long long _n = __builtin_readcyclecounter(); pt[i] += _n - pq; pq = _n; } } while (0)
+#define PD_PROF2(i) do { if (prof) { const long long _n = __builtin_readcyclecounter(); if (lane == 0) L.prof[i] += _n - pq; pq = _n; } } while (0)
                 if (prof) pq = __builtin_readcyclecounter();
 #else
 #define PD_PROF2(i) do { } while (0)
@@ -924,8 +1049,9 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
                         L.item[item * PD_ITEM_VALS + slot] = tot;
                     } else {
                         u64 *g = xchg + (size_t)(epoch & 1) * P.xchg_stride + (size_t)item * PD_XCHG_LINE + slot;
-                        __hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(tot), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                        const u64 gv = ((u64)epoch << 32) | (u64)__float_as_uint(tot);
+                        if (xl) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(g), "v"(gv) : "memory");   // stays in this XCD's L2 (the readers' sc1 loads find it there)
+                        else __hip_atomic_store(g, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
                 PD_PROF2(14);
@@ -992,18 +1118,34 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
             }
             PD_PROF(2);
 
-            // ---- P3a: pair backward, one (frame, incident pair) per thread, flat over the workgroup ----
-            // chunks of PD_GGS_THREADS incidences (one chunk at N = 20); results go to LDS [chunk][16]:
-            // 9 dL/dRc_side + 3 dL/dtc_side + 4 dL/dA partials, then P3b sums them per frame in fixed order
+            // ---- P3a: pair backward, one thread per frame pair, in chunks of PD_GGS_THREADS pairs (one chunk up to 32 frames) ----
+            // results go to LDS rows of 16 floats per (pair, side): 9 dL/dRc_side + 3 dL/dtc_side + the pair's 4 dL/dA partials (side 0;
+            // zeros on side 1).  P3b sums the first twelve per frame in fixed order; of the last four only the sum over ALL rows is needed
+            // (the focal length is the mean over frames, geometry_guided_sampling.py:142): an idle wave forms it
             const bool need_rt = S.update_R || S.update_T;
-            float fsum = 0.0f;                       // P3b accumulator of thread (frame, component)
+            // totals over all items by one wave: one 16-byte read per item gets {dF22, sum(s valid), n_valid, sum(min(s, max))}
+            auto loss_totals = [&]() {
+                float s_sum = 0.0f, s_cnt = 0.0f, s_cl = 0.0f;
+                for (int q2 = lane; q2 < n_items; q2 += 64) {
+                    const float4 v4 = *(const float4 *)&L.item[q2 * PD_ITEM_VALS + 8];
+                    s_sum += v4.y;
+                    s_cnt += v4.z;
+                    s_cl += v4.w;
+                }
+                s_sum = wave_allsum(s_sum);
+                s_cnt = wave_allsum(s_cnt);
+                s_cl = wave_allsum(s_cl);
+                if (lane == 0) {
+                    L.cam[6] = s_sum;
+                    L.cam[7] = s_cnt;
+                    L.ctl[2] = s_cl;
+                }
+            };
             for (int ck = 0; ck < D.n_pchunks; ++ck) {
-                const int *coff = L.incoff + ck * 68;   // this chunk's incidences by frame (positions within L.pinc)
+                const int *coff = L.incoff + ck * 68;   // this chunk's incidences by frame (CSR positions within L.pinc; general path)
                 {
-                    // ---- P3a (pair level): ONE thread per frame pair runs the shared backward chain once and
-                    // writes both sides' results straight into their incidence slots.  190 threads = 3 waves, one
-                    // per SIMD: cost is per wave-instruction, so this halves the critical path of the per-incidence
-                    // form (6 waves, two SIMDs carrying two waves each).
+                    // ONE thread per frame pair runs the shared backward chain once and writes both sides' results straight into
+                    // their rows.  190 threads = 3 waves, one per SIMD: the cost is per wave-instruction.
                     const int pair = ck * PD_GGS_THREADS + tid;
                     if (p3t && pair < D.n_pairs) {
                         const int4 mp = (ck == 0) ? my_pair : D.ptab[pair];
@@ -1017,39 +1159,55 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
 #include "pd_ggs_pairbwd.inc"
                     }
                 }
-                if (prof) { pq = __builtin_readcyclecounter(); pt[6] += pq - pc; }
+                if (prof) { pq = __builtin_readcyclecounter(); if (lane == 0) L.prof[6] += pq - pc; }
                 __syncthreads();
-                if (prof) { const long long n_ = __builtin_readcyclecounter(); pt[7] += n_ - pq; pq = n_; }
-                // ---- P3b: per-frame sums over the incidences of this chunk, fixed (ascending) order ----
-                if (small_n) {   // N <= 32: one chunk holds every pair, thread (fb_n, fb_c) owns its sum for the whole launch
-                    if (fb_n < N) {
-                        float acc2 = 0.0f;
-                        for (int e = fb_lo; e < fb_hi; e += 24) {   // 24 LDS loads in flight, summed in order
-                            float t24[24];
+                if (prof) { const long long n_ = __builtin_readcyclecounter(); if (lane == 0) L.prof[7] += n_ - pq; pq = n_; }
+                // ---- P3b: per-frame sums over the rows of this chunk, fixed (ascending) order ----
+                if (fast34) {
+                    if (wave < n_row_waves) {            // (wave-uniform: every lane of these waves runs along, rows past N on frame 0's data)
+                        const bool row_ok = fb_n < N;
+                        // column fb_c of frame fb_n's `cap` rows (rows past the frame's pairs are zero): 24 loads issued back to back --
+                        // an LDS round trip per group of four is what this phase would otherwise consist of --, summed in row order
+                        const float *src = L.pinc + ((row_ok ? fb_n : 0) * rstride) * 16 + fb_c;
+                        float acc = 0.0f;
+                        for (int e0 = 0; e0 < cap; e0 += 24) {
+                            float t[24];
 #pragma unroll
-                            for (int u = 0; u < 24; ++u) t24[u] = L.pinc[min(e + u, fb_hi - 1) * 16 + fb_c];
+                            for (int u = 0; u < 24; ++u) t[u] = src[(e0 + u) * 16];      // (past `cap`: the next frame's rows or the tables behind the rows; never added)
 #pragma unroll
-                            for (int u = 0; u < 24; ++u) acc2 += (e + u < fb_hi) ? t24[u] : 0.0f;
+                            for (int u = 0; u < 24; u += 4)
+                                if (e0 + u < cap) {                                       // block-uniform, cap % 4 == 0
+                                    acc += t[u];
+                                    acc += t[u + 1];
+                                    acc += t[u + 2];
+                                    acc += t[u + 3];
+                                }
                         }
-                        fsum = acc2;
-                    } else if (spare_wave && wave == PD_GGS_WAVES - 1) {
-                        // totals over all items by an otherwise idle wave: one 16-byte read per item gets
-                        // {dF22, sum(s valid), n_valid, sum(min(s, max))}
-                        float s_sum = 0.0f, s_cnt = 0.0f, s_cl = 0.0f;
-                        for (int q2 = lane; q2 < n_items; q2 += 64) {
-                            const float4 v4 = *(const float4 *)&L.item[q2 * PD_ITEM_VALS + 8];
-                            s_sum += v4.y;
-                            s_cnt += v4.z;
-                            s_cl += v4.w;
+                        const float fs = row_ok ? fb_sign * acc : 0.0f;   // lanes 0..8: dL/dR[b][a] at m = 3 a + b; 9..11: dL/dT; 12..15: the frame's dL/dA partials
+                        // dL/dq_x (lanes x = 0..3 of the row) = sum_m W[frame][x][m] fs[lane m]: the sums come over the row's DPP
+                        // broadcast, the Jacobian row from LDS (jac_all); the other lanes run along on a clamped row
+                        const float *Wr = L.W + ((row_ok ? fb_n : 0) * 4 + (fb_c & 3)) * 12;
+                        const float4 w0 = *(const float4 *)Wr, w1 = *(const float4 *)(Wr + 4);
+                        const float w8 = Wr[8];
+                        float gq = row_bcast<0>(fs) * w0.x;
+                        gq = __builtin_fmaf(row_bcast<1>(fs), w0.y, gq);
+                        gq = __builtin_fmaf(row_bcast<2>(fs), w0.z, gq);
+                        gq = __builtin_fmaf(row_bcast<3>(fs), w0.w, gq);
+                        gq = __builtin_fmaf(row_bcast<4>(fs), w1.x, gq);
+                        gq = __builtin_fmaf(row_bcast<5>(fs), w1.y, gq);
+                        gq = __builtin_fmaf(row_bcast<6>(fs), w1.z, gq);
+                        gq = __builtin_fmaf(row_bcast<7>(fs), w1.w, gq);
+                        gq = __builtin_fmaf(row_bcast<8>(fs), w8, gq);
+                        // dL/dA: only the sum over ALL frames is needed (the focal length is the mean over frames, :142): the four rows of
+                        // the wave add up on the cross-lane network, P4 adds the waves' partials in wave order
+                        const float ga_w = add_xor32(add_xor16(fs));
+                        if (row_ok) {
+                            if (fb_c < 4) L.gq[fb_n * 8 + fb_c] = S.update_R ? gq : 0.0f;
+                            else if (fb_c >= 9 && fb_c < 12) L.gq[fb_n * 8 + fb_c - 5] = S.update_T ? fs : 0.0f;
+                            else if (fb_c >= 12 && lane < 16) L.gA[wave * 4 + fb_c - 12] = ga_w;
                         }
-                        s_sum = wave_allsum(s_sum);
-                        s_cnt = wave_allsum(s_cnt);
-                        s_cl = wave_allsum(s_cl);
-                        if (lane == 0) {
-                            L.cam[6] = s_sum;
-                            L.cam[7] = s_cnt;
-                            L.ctl[2] = s_cl;
-                        }
+                    } else if (wave == W_LOSS) {
+                        loss_totals();
                     }
                 } else {         // several passes over the frames, partial sums carried across chunks in LDS
                     for (int n0 = 0; n0 < N; n0 += PD_GGS_THREADS / 16) {
@@ -1068,52 +1226,47 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
                         }
                     }
                 }
-                if (prof) { const long long n_ = __builtin_readcyclecounter(); pt[8] += n_ - pq; pq = n_; }
-                if (ck + 1 < D.n_pchunks) __syncthreads();   // pinc is rewritten by the next chunk
+                if (prof) { const long long n_ = __builtin_readcyclecounter(); if (lane == 0) L.prof[8] += n_ - pq; pq = n_; }
+                if (ck + 1 < D.n_pchunks) __syncthreads();   // the rows (and the dL/dA slots) are rewritten by the next chunk
             }
-            if (!spare_wave && wave == 0) {
-                float s_sum = 0.0f, s_cnt = 0.0f, s_cl = 0.0f;
-                for (int q2 = lane; q2 < n_items; q2 += 64) {
-                    const float4 v4 = *(const float4 *)&L.item[q2 * PD_ITEM_VALS + 8];
-                    s_sum += v4.y;
-                    s_cnt += v4.z;
-                    s_cl += v4.w;
-                }
-                s_sum = wave_allsum(s_sum);
-                s_cnt = wave_allsum(s_cnt);
-                s_cl = wave_allsum(s_cl);
-                if (lane == 0) {
-                    L.cam[6] = s_sum;
-                    L.cam[7] = s_cnt;
-                    L.ctl[2] = s_cl;
-                }
-            }
-            // scatter the per-frame totals: back through tc = D T and Rc[a][b] = D[a] R[b][a]
-            if (small_n) {
-                if (fb_n < N) *fb_dst = fb_sign * fsum;
-            } else {
-                for (int n0 = 0; n0 < N; n0 += PD_GGS_THREADS / 16) {
-                    const int n = n0 + fb_n;
-                    if (p3t && n < N) {
-                        const float v = L.psum[n * 16 + fb_c];
-                        if (fb_c < 9) {
-                            const int aa = fb_c / 3, bb = fb_c % 3;
-                            L.gR[n * 9 + bb * 3 + aa] = (aa < 2 ? -v : v);
-                        } else if (fb_c < 12) {
-                            L.gT[n * 3 + (fb_c - 9)] = (fb_c - 9 < 2 ? -v : v);
-                        } else {
-                            L.gA[n * 4 + (fb_c - 12)] = v;
+            if (!fast34) {
+                if (wave == W_LOSS) loss_totals();
+                __syncthreads();                         // every frame's sums are complete
+                // the same seven numbers per frame as the fast path hands to P4: dL/dq through the Jacobian, dL/dT (signs: D = diag(-1,-1,1))
+                for (int q = tid; q < N * 8; q += NT) {
+                    const int n = q >> 3, x = q & 7;
+                    float v = 0.0f;
+                    if (x < 4) {
+                        if (S.update_R) {
+                            const float qn[4] = {L.xst[n * 9 + 3], L.xst[n * 9 + 4], L.xst[n * 9 + 5], L.xst[n * 9 + 6]};
+                            float Wr[9];
+                            jac_row_x(qn, x, Wr);
+                            const float *ps = L.psum + n * 16;
+#pragma unroll
+                            for (int m = 0; m < 9; ++m) v = __builtin_fmaf(m < 6 ? -ps[m] : ps[m], Wr[m], v);
+                        }
+                    } else if (x < 7) {
+                        if (S.update_T) {
+                            const float t = L.psum[n * 16 + 9 + (x - 4)];
+                            v = (x - 4 < 2) ? -t : t;
                         }
                     }
+                    L.gq[q] = v;
+                }
+                // dL/dA totals over the frames, in frame order
+                if (tid < 4) {
+                    float v = 0.0f;
+                    for (int n = 0; n < N; ++n) v += L.psum[n * 16 + 12 + tid];
+                    L.gA[tid] = v;
                 }
             }
             __syncthreads();
             PD_PROF(3);
 
-#include "pd_ggs_p4.inc"
+#include "pd_ggs_p4q.inc"
             __syncthreads();
             PD_PROF(4);
-            if (prof) pt[5] += 1;
+            if (prof && lane == 0) L.prof[5] += 1;
             if (L.ctl[0] != 0.0f) break;
         }
         if (wave == 0 && lane == 0 && wg == 0 && P.stats) {
@@ -1126,7 +1279,7 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
         if (P.eval_only) break;
     }
     if (prof && lane == 0) {
-        for (int i = 0; i < (int)(sizeof(pt) / sizeof(pt[0])); ++i) P.prof[i] = pt[i];
+        for (int i = 0; i < 16; ++i) P.prof[i] = L.prof[i];
     }
     if (own && wg == 0 && !P.eval_only) {
 #pragma unroll
@@ -1187,6 +1340,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x % B, wg = blockIdx.x / B;
+    if (b >= P.n_seqs) return;
     const PdSeqDesc D = P.seqs[b];
     const int N = P.N, k = P.k;
     const int nW = k * PD_GGS_WAVES;
@@ -1599,6 +1753,15 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
             ptab[p] = make_int4(pair_ij[p].x | (pair_ij[p].y << 8), pair_item_off[p], pair_item_off[p + 1] - pair_item_off[p],
                                 pos0[p] | (pos1[p] << 16));
     }
+    int max_deg = 0;                       // most pairs incident to one frame: the row stride of the fast per-frame sums (pd_ggs_kernel)
+    {
+        std::vector<int> deg(N, 0);
+        for (int p = 0; p < n_pairs; ++p) {
+            deg[pair_ij[p].x]++;
+            deg[pair_ij[p].y]++;
+        }
+        for (int n = 0; n < N; ++n) max_deg = std::max(max_deg, deg[n]);
+    }
     // the same positions among ALL incidences (two-hop kernel: one exchange line per (pair, side), grouped by frame)
     std::vector<int2> gpos(n_pairs);
     std::vector<int> ginc_off(N + 1, 0);
@@ -1745,6 +1908,7 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     h.desc.cx = (float)width / 2.0f;
     h.desc.cy = (float)height / 2.0f;
     h.max_item_len = max_item_len;
+    h.max_deg = max_deg;
     return upload_seq_desc(eng, seq);
 }
 
@@ -1847,7 +2011,22 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
         max_pairs = std::max(max_pairs, eng->seqs[b].desc.n_pairs);
         max_len = std::max(max_len, eng->seqs[b].max_item_len);
     }
-    const int pinc_one_hop = std::min(PD_GGS_PINC_ROWS, 2 * std::min(PD_GGS_THREADS, std::max(max_pairs, 1)));
+    int pinc_one_hop = std::min(PD_GGS_PINC_ROWS, 2 * std::min(PD_GGS_THREADS, std::max(max_pairs, 1)));
+    // fast serial phases (<= PD_GGS_FAST_FRAMES frames, one chunk of pairs): rows at a fixed stride per frame -- N x (largest degree,
+    // rounded up to 4, + 1) rows; about 2 x pairs for the complete graph of hloc's exhaustive pairs.  The kernel decides from the actual
+    // tables; here only the room is made (dropped again below if the LDS image would not fit).
+    int pinc_fast = 0;
+    if (N <= PD_GGS_FAST_FRAMES) {
+        int deg = 0;
+        bool one_chunk = true;
+        for (int b = 0; b < B; ++b) {
+            deg = std::max(deg, eng->seqs[b].max_deg);
+            one_chunk = one_chunk && eng->seqs[b].desc.n_pchunks <= 1;
+        }
+        if (one_chunk && deg > 0) pinc_fast = N * (((deg + 3) & ~3) + 1);     // (+ 1: the bank-conflict-free row stride, pd_ggs_kernel)
+    }
+    const int pinc_general = pinc_one_hop;
+    if (pinc_fast <= PD_GGS_PINC_ROWS) pinc_one_hop = std::max(pinc_one_hop, pinc_fast);
     int stage_want = 0;
     if (!(cfg->reserved & PD_GGS_CFG_NO_LDS_STAGING) && max_len > 0) {
         const int pieces = (max_len + 63) / 64;
@@ -1855,6 +2034,21 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
     }
     int n_slots = 0, pinc_rows = PD_GGS_PINC_ROWS, stage_p = 0;
     size_t lds = 0;
+    // LDS image of a candidate shape; three waves per SIMD (12 waves, ONE staging buffer per wave) for the staged match pass at one
+    // workgroup per sequence with several rounds of items per wave (the bench shape; A/B switch PD_GGS_CFG_WAVES8 keeps 8 waves)
+    int waves = PD_GGS_WAVES;
+    auto image = [&](int rows, int sp, int kk_, int slots, int &w_out) -> size_t {
+        w_out = PD_GGS_WAVES;
+        const size_t l8 = ggs_lds_bytes(slots, two_hop ? slots : max_items, rows, sp, PD_GGS_WAVES * 2);
+        if (!two_hop && sp > 0 && kk_ == 1 && slots >= 3 * 12 && !(cfg->reserved & PD_GGS_CFG_WAVES8) && (PD_GGS_PROF12 || !eng->ggs_prof_on)) {
+            const size_t l12 = ggs_lds_bytes(slots, max_items, rows, sp, 12);
+            if (l12 <= 160 * 1024) {
+                w_out = 12;
+                return l12;
+            }
+        }
+        return l8;
+    };
     for (int pass = 0; pass < 2; ++pass) {
         int kk = k;
         for (;;) {
@@ -1862,10 +2056,14 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
             n_slots = rounds * PD_GGS_WAVES;
             pinc_rows = two_hop ? PD_GGS_PINC_ROWS : pinc_one_hop;
             stage_p = (!two_hop && rounds > 1) ? stage_want : 0;     // one item per wave: matches are register resident
-            lds = ggs_lds_bytes(n_slots, two_hop ? n_slots : max_items, pinc_rows, stage_p);
+            lds = image(pinc_rows, stage_p, kk, n_slots, waves);
+            if (lds > 160 * 1024 && !two_hop && pinc_rows > pinc_general) {   // the wider rows of the fast serial phases are optional
+                pinc_one_hop = pinc_rows = pinc_general;
+                lds = image(pinc_rows, stage_p, kk, n_slots, waves);
+            }
             if (lds > 160 * 1024 && stage_p > 0) {                   // staging is optional: without it first
                 stage_p = 0;
-                lds = ggs_lds_bytes(n_slots, two_hop ? n_slots : max_items, pinc_rows, 0);
+                lds = image(pinc_rows, 0, kk, n_slots, waves);
             }
             if (lds <= 160 * 1024 || kk >= device_cus / B) break;
             ++kk;
@@ -1891,16 +2089,12 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
                      max_items, eng->xchg_granules / PD_XCHG_LINE, B);
         return PD_ERR_UNSUPPORTED;
     }
-    // three waves per SIMD for the staged match pass at one workgroup per sequence with several rounds of items per wave (the
-    // bench shape): A/B switch PD_GGS_CFG_WAVES8 keeps the 8-wave kernel
-    int waves = PD_GGS_WAVES;
-    if (!two_hop && stage_p > 0 && k == 1 && n_slots >= 3 * 12 && !(cfg->reserved & PD_GGS_CFG_WAVES8) && (PD_GGS_PROF12 || !eng->ggs_prof_on)) {
-        const size_t lds12 = ggs_lds_bytes(n_slots, max_items, pinc_rows, stage_p, 12);
-        if (lds12 <= 160 * 1024) {
-            waves = 12;
-            lds = lds12;
-        }
-    }
+    // XCD-local placement of the exchange (k > 1, one-hop kernel): block b of a launch runs on XCD b % 8, so with the block -> (sequence,
+    // workgroup) mapping padded to a multiple of 8 sequences all workgroups of a sequence share an XCD -- if its 32 CUs can hold them all at
+    // once (they spin on each other: co-residency) and the handshake granules fit behind the items' lines.  PD_GGS_CFG_XCHG_SPREAD: A / B.
+    const int seq_per_xcd = (B + 7) / 8;
+    out->xchg_local = (k > 1 && !two_hop && device_cus == 256 && seq_per_xcd * k <= 32 && k <= 256 &&
+                       (size_t)max_items * PD_XCHG_LINE + 256 <= eng->xchg_granules && !(cfg->reserved & PD_GGS_CFG_XCHG_SPREAD)) ? 1 : 0;
     out->waves = waves;
     out->pinc_rows = pinc_rows;
     out->stage_p = stage_p;
@@ -1951,6 +2145,9 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     P.err_flag = eng->d_err;
     P.prof = eng->ggs_prof_on ? (long long *)(eng->d_err + 2) : nullptr;
     P.prof_wave = eng->ggs_prof_on > 0 ? (eng->ggs_prof_on - 1) & 0x107 : 1;
+    P.n_seqs = B;
+    P.xchg_local = plan.xchg_local;
+    const int B_map = plan.xchg_local ? ((B + 7) & ~7) : B;     // the kernels' block -> (sequence, workgroup) mapping
     if (k > 1) {
         // tags restart at 1 every launch: zero every polled word first (guide G16 "re-initialise every call")
         const size_t n_zero = 2 * eng->xchg_granules * B;
@@ -1970,7 +2167,7 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
             : plan.stage_p == 5 ? pd_ggs_kernel<5, false>
             : plan.stage_p == 3 ? pd_ggs_kernel<3, false>
                                 : pd_ggs_kernel<0, false>;
-        hipLaunchKernelGGL(kern, dim3(B * k), dim3(plan.waves * 64), lds, s, P, B, n_slots, pinc_rows, items_cap);
+        hipLaunchKernelGGL(kern, dim3(B_map * k), dim3(plan.waves * 64), lds, s, P, B_map, n_slots, pinc_rows, items_cap);
     }
     PD_HIP_CHECK(hipGetLastError());
     return pd_mark_use(eng, s);

@@ -600,6 +600,7 @@ extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n
             h.desc.cx = A.cx;
             h.desc.cy = A.cy;
             h.max_item_len = single ? hint_per_pair : PD_ITEM_MAX_MATCHES;
+            h.max_deg = std::min(P_cap, 2 * (N - 1));          // an upper bound (the host never learns the pair list): every pair of both orders
             h.device_built = true;
         }
         const size_t lds_hist = sizeof(int) * (size_t)N * N;

@@ -26,6 +26,8 @@
 #define PD_LANE_MAX_ITEMS PD_LANE_THREADS   // one lane item per thread
 #define PD_LANE_MAX_FRAMES 48               // 16 threads per frame in the per-frame sums
 #define PD_LANE_ITEM_VALS 10                // 9 dL/dF sums + sum(s valid) per lane item
+#define PD_GGS_FAST_FRAMES 24               // one-hop kernel: up to this many frames the per-frame sums take 16 lanes per frame (6 waves) and two
+                                            //   idle waves form the totals beside them (pd_ggs_kernel, "fast serial phases")
 
 void pd_set_error(const char *fmt, ...);
 
@@ -42,6 +44,10 @@ static inline int pd_dev_knob(const char *name, int dflt) {
 #else
 #define pd_dev_knob(name, dflt) (dflt)
 #endif
+
+// ReLU as torch computes it (clamp_min semantics: NaN propagates).  fmaxf / v_max_f32 return the OTHER operand for a NaN, which turned
+// a network full of NaN (non-finite checkpoint) into finite garbage -- the `_last` MLP's ReLU zeroed them and the output was its bias.
+__device__ __forceinline__ float pd_relu(float v) { return v < 0.0f ? 0.0f : v; }
 
 #define PD_HIP_CHECK(expr)                                                                     \
     do {                                                                                       \
@@ -102,6 +108,9 @@ struct PdGgsParams {
     unsigned int *err_flag;    // device word: nonzero = a bounded spin gave up
     long long *prof;           // optional phase cycle counters (debug), else null
     int prof_wave;             // which wave of workgroup 0 records them
+    int n_seqs;                // sequences of the launch (the kernels' `B` argument is this, or this rounded up to 8: xchg_local)
+    int xchg_local;            // one-hop kernel, k > 1: the launch places all workgroups of a sequence on ONE XCD (block -> sequence mapping
+                               //   padded to a multiple of 8); the kernel verifies it and then keeps its exchange stores in that XCD's L2
 };
 
 // launch shape of one GGS launch (pd_ggs_plan): everything a captured graph node bakes in besides its arguments
@@ -118,6 +127,7 @@ struct PdGgsPlan {
     int pinc_rows, stage_p;    // one-hop kernel: LDS rows of the pair backward; LDS-DMA staging pieces per item (0 = through registers)
     int waves;                 // one-hop kernel: waves per workgroup (8, or 12 for the staged k = 1 shape)
     int lane, lane_rl;         // lane-per-item kernel chosen; its LDS-resident steps per wave
+    int xchg_local;            // one-hop kernel: XCD-local placement of a sequence's workgroups (see PdGgsParams)
 };
 
 // lane items of one frame pair with m matches at lane-item length len: ceil(m / len) items of balanced size (host and device builders)
@@ -129,6 +139,7 @@ struct PdSeqHost {
     PdSeqDesc desc{};          // host shadow; for device-built slots (pd_ggs_set_matches_csr_async) the counts are CAPACITIES
     int n_local_max_k1 = 0;
     int max_item_len = 0;      // longest work item (matches); for device-built slots the per-pair hint (or the 512 maximum)
+    int max_deg = 0;           // most frame pairs incident to one frame (host-built: exact; device-built: an upper bound from the capacities)
     bool device_built = false; // tables + descriptor were written by the ingestion kernels; the host never saw the counts
 };
 
