@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpd_engine.so")
+# PD_ENGINE_LIB: another build of the same C-ABI (same-box A / B of two libraries: tools/ab_ggs.py, bench.py); default = the in-tree build
+LIB_PATH = os.environ.get("PD_ENGINE_LIB") or os.path.join(_HERE, "lib", "libpd_engine.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "include", "pd_engine.h"))
 
@@ -137,6 +138,8 @@ def load():
     import torch  # noqa: F401  (loads the HIP runtime first)
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("PD_ENGINE_LIB") and not hasattr(lib, name):
+            continue              # an older build under A / B lacks the newest debug exports
         fn = getattr(lib, name)   # AttributeError here = library does not match the header
         fn.restype = res
         fn.argtypes = args

@@ -42,6 +42,10 @@
 #ifndef PD_GGS_PROF12
 #define PD_GGS_PROF12 0
 #endif
+#ifndef PD_GGS_ABLATE
+#define PD_GGS_ABLATE 0   // development (tools/ab_ggs.py): bit mask of phases whose work is SKIPPED (1 P1, 2 P3a, 4 P3b, 8 P4, 16 match pass, 32 exchange
+#endif                    // gather) -- garbage results, honest timing of what is left: the difference is a phase's share of the critical path
+
 #ifndef PD_GGS_MIN_WAVES_PER_SIMD
 #define PD_GGS_MIN_WAVES_PER_SIMD 2      // one 512-thread workgroup per CU; 4 = experiment: two workgroups per CU (<= 128 VGPRs)
 #endif
@@ -142,6 +146,20 @@ __device__ __forceinline__ float wave_reduce12_transpose(const float (&a)[PD_ITE
     v = add_xor32(v);
     slot = ((lane & 4) ? 8 : 0) + ((lane & 8) ? 4 : 0) + (b0 ? 2 : 0) + (b1 ? 1 : 0);
     return v;
+}
+
+// two 64-lane sums for little more than the price of one: v_permlane32_swap folds a's upper half onto its lower half and b's lower
+// half onto its upper half (one swap + one add), then ONE five-step DPP chain sums both 32-lane halves; a in lane 31, b in lane 63.
+__device__ __forceinline__ void wave_allsum2(float a, float b, float &sa, float &sb) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(a), __float_as_int(b), false, false);
+    float v = __int_as_float(r[0]) + __int_as_float(r[1]);   // lanes < 32: a[l] + a[l + 32]; lanes >= 32: b[l - 32] + b[l]
+    v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);   // row_mirror
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 -> rows 1, 3
+    sa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    sb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 struct Cam {   // shared intrinsics of the step: A = K^-1 = [[a0,0,c0],[0,a1,c1],[0,0,1]]
@@ -381,20 +399,20 @@ __device__ __forceinline__ void sampson_stepW(const v2f (&u1)[W], const v2f (&v1
 
 // LDS carve (floats).  Everything lives in the one dynamic region (guide G17).
 #define PD_GGS_PSUM_FLOATS (PD_GGS_FAST_FRAMES * 48 > 64 * 16 ? PD_GGS_FAST_FRAMES * 48 : 64 * 16)
-#define PD_GGS_LDS_FIXED (64 * 9 + 64 * 3 + 64 * 2 + 64 * 2 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8 + 32 + PD_GGS_PSUM_FLOATS + 2 * 64 * 9)   // + pinc_rows * 16
+#define PD_FR_STRIDE 12   // floats per frame in L.Rc: R_cv (9, row-major) | t_cv (3) -- three 16-byte LDS accesses per frame
+#define PD_XS_STRIDE 12   // floats per frame in L.xst / L.mst: the 9 parameters / momenta (+ 3 unused), 16-byte accesses too
+#define PD_GGS_LDS_FIXED (64 * PD_FR_STRIDE + 64 * 4 + 8 + 64 * 3 + 64 * 9 + 64 * 4 + 8 + 32 + PD_GGS_PSUM_FLOATS + 2 * 64 * PD_XS_STRIDE)   // + pinc_rows * 16
 struct Lds {
-    float *Rc;     // [64*9]  R_cv per frame  (opencv_from_cameras_projection)
-    float *tc;     // [64*3]
-    float *fl;     // [64*2]  clamped focal per frame
-    float *flp;    // [64*2]  clamp pass-through mask (1/0)
+    float *Rc;     // [64*12] per frame R_cv (9) | t_cv (3)  (opencv_from_cameras_projection)
+    float *fl;     // [64*4]  per frame clamped focal (x, y) | clamp pass-through mask (1/0: x, y)
     float *cam;    // [8]     a0,a1,c0,c1,fbar_x,fbar_y
     float *gT;     // [64*3]  per-frame dL/dT  (un-normalised: not yet divided by n_valid)
     float *gR;     // [64*9]  per-frame dL/dR  (PyTorch3D R, un-normalised)
     float *gA;     // [64*4]  per-frame partial dL/dA {00,02,11,12}
     float *ctl;    // [8]     ctl[0] = stage done flag, ctl[1] = abort
     long long *prof;   // [16] phase cycle counters of the one wave that records them (pd_debug_ggs_prof): in LDS, not in 20 registers of every wave
-    float *xst;    // [64*9]  pose parameters per frame (lane = frame in P4) -- in LDS, not in registers: wave 0 touches them once per
-    float *mst;    // [64*9]  iteration, and 18 VGPRs held by every wave for the whole launch is what the match pass cannot spare
+    float *xst;    // [64*12] pose parameters per frame (lane = frame in P4) -- in LDS, not in registers: wave 0 touches them once per
+    float *mst;    // [64*12] iteration, and 18 VGPRs held by every wave for the whole launch is what the match pass cannot spare
     float *pinc;   // [pinc_rows*16] backward results of the current chunk of pairs, one row per (pair, side), frame-sorted
                    //   (pinc_rows = 2 x pairs per chunk, at most PD_GGS_PINC_ROWS; the two-hop kernel always carves the maximum)
     float *psum;   // [PD_GGS_PSUM_FLOATS] general serial path (more than PD_GGS_FAST_FRAMES frames or several chunks of pairs): per-frame
@@ -412,18 +430,16 @@ struct Lds {
 __device__ __forceinline__ Lds carve(float *base, int n_slots, int pinc_rows, int n_items_cap) {
     Lds L;
     L.Rc = base;
-    L.tc = L.Rc + 64 * 9;
-    L.fl = L.tc + 64 * 3;
-    L.flp = L.fl + 64 * 2;
-    L.cam = L.flp + 64 * 2;
+    L.fl = L.Rc + 64 * PD_FR_STRIDE;
+    L.cam = L.fl + 64 * 4;
     L.gT = L.cam + 8;
     L.gR = L.gT + 64 * 3;
     L.gA = L.gR + 64 * 9;
     L.ctl = L.gA + 64 * 4;
     L.prof = (long long *)(L.ctl + 8);
     L.xst = L.ctl + 8 + 32;
-    L.mst = L.xst + 64 * 9;
-    L.pinc = L.mst + 64 * 9;
+    L.mst = L.xst + 64 * PD_XS_STRIDE;
+    L.pinc = L.mst + 64 * PD_XS_STRIDE;
     L.psum = L.pinc + pinc_rows * 16;
     L.W = L.psum;
     L.gq = L.gR;
@@ -440,6 +456,28 @@ static size_t ggs_lds_bytes(int n_slots, int n_items, int pinc_rows, int stage_p
                (size_t)n_slots * 16;
     if (stage_p > 0) b = ((b + 1023) & ~(size_t)1023) + (size_t)stage_bufs * stage_p * 1024;   // 8 waves x 2 buffers, or 12 x 1
     return b;
+}
+
+// per-frame tables in LDS, 16 bytes at a time
+__device__ __forceinline__ void frame_load(const Lds &L, int n, float (&R)[9], float (&t)[3]) {
+    const float4 *p = (const float4 *)(L.Rc + n * PD_FR_STRIDE);
+    const float4 a = p[0], b = p[1], c = p[2];
+    R[0] = a.x; R[1] = a.y; R[2] = a.z; R[3] = a.w;
+    R[4] = b.x; R[5] = b.y; R[6] = b.z; R[7] = b.w;
+    R[8] = c.x; t[0] = c.y; t[1] = c.z; t[2] = c.w;
+}
+__device__ __forceinline__ void params_load(const float *tab, int n, float (&x)[9]) {     // tab = L.xst or L.mst
+    const float4 *p = (const float4 *)(tab + n * PD_XS_STRIDE);
+    const float4 a = p[0], b = p[1];
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+    x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    x[8] = tab[n * PD_XS_STRIDE + 8];
+}
+__device__ __forceinline__ void params_store(float *tab, int n, const float (&x)[9]) {
+    float4 *p = (float4 *)(tab + n * PD_XS_STRIDE);
+    p[0] = make_float4(x[0], x[1], x[2], x[3]);
+    p[1] = make_float4(x[4], x[5], x[6], x[7]);
+    tab[n * PD_XS_STRIDE + 8] = x[8];
 }
 
 // decode one frame's 9-vector into R_cv, t_cv, focal (camera_transform.py:80-97 + pytorch3d
@@ -487,21 +525,30 @@ __device__ __forceinline__ void decode_frame(const float *x, float *Rc, float *t
 __device__ __forceinline__ void decode_all(const Lds &L, const float *xr, int lane, int N, const PdSeqDesc &D, bool do_r = true,
                                            bool do_t = true, bool do_fl = true) {
     if (lane < N) {
-        if (do_r) decode_frame_r(xr, &L.Rc[lane * 9]);
-        if (do_t) decode_frame_t(xr, &L.tc[lane * 3]);
+        float *dst = L.Rc + lane * PD_FR_STRIDE;
+        if (do_r) {
+            float Rc[9];
+            decode_frame_r(xr, Rc);
+            ((float4 *)dst)[0] = make_float4(Rc[0], Rc[1], Rc[2], Rc[3]);
+            ((float4 *)dst)[1] = make_float4(Rc[4], Rc[5], Rc[6], Rc[7]);
+            dst[8] = Rc[8];
+        }
+        if (do_t) decode_frame_t(xr, dst + 9);
     }
     if (!do_fl) return;                               // (wave-uniform)
     float flx = 0.f, fly = 0.f, px = 0.f, py = 0.f;
     if (lane < N) {
         decode_frame_fl(xr, flx, fly, px, py);
-        L.fl[lane * 2] = flx;
-        L.fl[lane * 2 + 1] = fly;
-        L.flp[lane * 2] = px;
-        L.flp[lane * 2 + 1] = py;
+        *(float4 *)&L.fl[lane * 4] = make_float4(flx, fly, px, py);
     }
     // focal_length.mean(dim=0) over all cameras (geometry_guided_sampling.py:142)
-    const float rN = pd_rcp((float)N);
-    const float fbx = wave_allsum(flx) * rN, fby = wave_allsum(fly) * rN;
+    int n_op = N;
+    asm volatile("" : "+s"(n_op));                   // formed here every time: hoisted out of the iteration loop the reciprocal becomes a register held
+    const float rN = pd_rcp((float)n_op);            // for the whole launch -- in the 168-register variants a spill, reloaded from scratch on the critical path
+    float fbx, fby;
+    wave_allsum2(flx, fly, fbx, fby);
+    fbx *= rN;
+    fby *= rN;
     if (lane == 0) {
         const float a0 = pd_rcp(fbx * D.sc), a1 = pd_rcp(fby * D.sc);
         L.cam[0] = a0;
@@ -553,7 +600,7 @@ __device__ __forceinline__ void jac_row_x(const float (&q)[4], int x, float (&w)
 }
 __device__ __forceinline__ void jac_all(const Lds &L, int lane, int N) {
     if (lane >= N || N > PD_GGS_FAST_FRAMES) return;
-    const float q[4] = {L.xst[lane * 9 + 3], L.xst[lane * 9 + 4], L.xst[lane * 9 + 5], L.xst[lane * 9 + 6]};
+    const float q[4] = {L.xst[lane * PD_XS_STRIDE + 3], L.xst[lane * PD_XS_STRIDE + 4], L.xst[lane * PD_XS_STRIDE + 5], L.xst[lane * PD_XS_STRIDE + 6]};
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
         float w[9];
@@ -754,7 +801,9 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
     constexpr bool SINGLE = NW > PD_GGS_WAVES;        // one staging buffer per wave
     static_assert(!(RESIDENT && SINGLE) && (NW == PD_GGS_WAVES || STAGE_P > 0), "12 waves: the staged variants only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = tid >> 6;       // (kept a vector value: readfirstlane would move what derives from it to SGPRs, of which the kernel has
+                                     //  none to spare -- measured 0.1 us per iteration slower at several workgroups per sequence, equal at one)
     const int b = blockIdx.x % B, wg = blockIdx.x / B;   // XCD-aware: see header comment (B: the launch's sequences, padded to 8 if P.xchg_local)
     if (b >= P.n_seqs) return;                           // (padding blocks of the XCD-local placement)
     const PdSeqDesc D = P.seqs[b];
@@ -771,8 +820,8 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
     if (wave == 0) {
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
-            L.xst[lane * 9 + c] = own ? xg[lane * 9 + c] : 0.0f;
-            L.mst[lane * 9 + c] = 0.0f;
+            L.xst[lane * PD_XS_STRIDE + c] = own ? xg[lane * 9 + c] : 0.0f;
+            L.mst[lane * PD_XS_STRIDE + c] = 0.0f;
         }
     }
     // local item table -> LDS (slot = wave + 8 * round <-> item = wg*8 + wave + round * nW)
@@ -794,8 +843,7 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
     }
     if (wave == 0) {
         float xr0[9];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) xr0[c] = L.xst[lane * 9 + c];
+        params_load(L.xst, lane, xr0);
         decode_all(L, xr0, lane, N, D);
     }
     __syncthreads();
@@ -869,9 +917,8 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
     const float4 *stage_ptr = (const float4 *)(L.stage + wave * ((SINGLE ? 1 : 2) * STAGE_P * 256));
     int pb = 0;                                   // buffer that holds (or is receiving) the item computed next
     // byte offsets of this lane's match in each piece (lane + 64 q), clamped per item to its last match
-    unsigned lane_off[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) lane_off[q] = (unsigned)(lane + 64 * q) * 16u;
+    // (the byte offsets lane * 16 + 1024 q are formed where they are used: six registers held across the whole launch are six spills in the
+    // 168-register variants, whose reloads from scratch land in the serial phases)
     auto stage_item = [&](int slot, int buf) {
         int4 e = L.itab[slot];
         const int first = __builtin_amdgcn_readfirstlane(e.x);
@@ -879,7 +926,7 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
         if constexpr (STAGE_P > 0) {
             unsigned off[6];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) off[q] = min(lane_off[q], last16);     // no predicated loads: a clamped copy of the last match
+            for (int q = 0; q < 6; ++q) off[q] = min((unsigned)lane * 16u + 1024u * q, last16);     // no predicated loads: a clamped copy of the last match
             pd_glds_item<STAGE_P>(D.pts + first, off, stage_lds + (unsigned)(buf * STAGE_P) * 1024u);
         }
     };
@@ -908,6 +955,7 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
     const int ga_parts = fast34 ? n_row_waves : 1;              // dL/dA partials P4 adds up (fast: one per row wave; general: the totals)
     constexpr int W_LOSS = PD_GGS_WAVES - 1;                    // idle in the fast backward phase: forms the loss totals meanwhile
     // pair-level backward in chunks of PD_GGS_THREADS pairs (one chunk up to N = 32); chunk 0's table entry is hoisted
+    // (held for the whole launch in THREE registers: frames i | j << 8 and the item count share one -- pd_ggs_set_matches bounds both to 16 bits)
     int4 my_pair = (p3t && tid < D.n_pairs) ? D.ptab[tid] : make_int4(0, 0, 0, 0);
     if (fast34) {
         if (p3t && tid < D.n_pairs) {       // CSR positions -> fixed-stride rows
@@ -917,6 +965,7 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
         }
         for (int q = tid; q < N * rstride * 4; q += NT) ((float4 *)L.pinc)[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
+    const int my_pair_xz = (my_pair.x & 0xffff) | (my_pair.z << 16), my_pair_y = my_pair.y, my_pair_w = my_pair.w;
     if (wave == PD_GGS_WAVES - 1 && fast34) jac_all(L, lane, N);   // (L.xst was published before the barrier above; first read two barriers from here)
     unsigned epoch = 0;
     int trace_row = 0;
@@ -934,7 +983,12 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
     for (int st = 0; st < P.n_stages; ++st) {
         const PdGgsStage S = P.stages[st];
         int stepped = 0;
-        float last_print = __int_as_float(0x7fc00000), last_cnt = 0.0f, last_loss = __int_as_float(0x7fc00000);
+        // {printed statistic, valid count, loss} of the stage's last iteration: LDS (L.ctl[5..7], written by P4's lane 0), not three registers
+        if (tid == 0) {
+            L.ctl[5] = __int_as_float(0x7fc00000);
+            L.ctl[6] = 0.0f;
+            L.ctl[7] = __int_as_float(0x7fc00000);
+        }
         for (int it = 0; it < S.iters; ++it) {
             if (prof) pc = __builtin_readcyclecounter();
             // ---- P1: F for the pairs of this workgroup's items -------------------------------
@@ -942,20 +996,12 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
             if (tid == 0) *q_ctr = NW;                    // first slot the match pass hands out dynamically
             // an idle wave: the quaternion Jacobian of the parameters the previous iteration left (read two barriers from here)
             if (wave == PD_GGS_WAVES - 1 && S.update_R && fast34) jac_all(L, lane, N);
-            for (int s = tid; s < n_slots; s += NT) {
+            for (int s = tid; s < n_slots && !(PD_GGS_ABLATE & 1); s += NT) {
                 const int4 e = L.itab[s];
                 if (e.y > 0) {
                     float Ri[9], Rj[9], ti[3], tj[3];
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) {
-                        Ri[c] = L.Rc[e.z * 9 + c];
-                        Rj[c] = L.Rc[e.w * 9 + c];
-                    }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        ti[c] = L.tc[e.z * 3 + c];
-                        tj[c] = L.tc[e.w * 3 + c];
-                    }
+                    frame_load(L, e.z, Ri, ti);
+                    frame_load(L, e.w, Rj, tj);
                     PairFwd f;
                     pair_forward(Ri, ti, Rj, tj, f);
                     float F[9];
@@ -977,7 +1023,7 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
                 if (lane == 0 && wave < n_local) t0 = atomicAdd(q_ctr, 1);
                 s_next = __builtin_amdgcn_readfirstlane(t0);
             }
-            for (int s = wave; s < n_local;) {
+            for (int s = wave; s < n_local && !(PD_GGS_ABLATE & 16);) {
                 const int item = wg * PD_GGS_WAVES + (s & 7) + (s >> 3) * nW;
 #ifdef PD_GGS_PROF2
 #define PD_PROF2(i) do { if (prof) { const long long _n = __builtin_readcyclecounter(); if (lane == 0) L.prof[i] += _n - pq; pq = _n; } } while (0)
@@ -1065,7 +1111,7 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
                 bool fail = false;
                 // each item is one 128-byte line of 16 granules (12 used); a thread fetches 16-byte pieces
                 // (2 granules) with write-through-coherent (sc1) loads, up to 3 pieces in flight per pass
-                const int n_piece = n_items * 6;
+                const int n_piece = (PD_GGS_ABLATE & 32) ? 0 : n_items * 6;
                 for (int p0 = tid; p0 < n_piece; p0 += 3 * NT) {
                     const u64 *a[3];
                     int pi_[3];
@@ -1147,8 +1193,8 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
                     // ONE thread per frame pair runs the shared backward chain once and writes both sides' results straight into
                     // their rows.  190 threads = 3 waves, one per SIMD: the cost is per wave-instruction.
                     const int pair = ck * PD_GGS_THREADS + tid;
-                    if (p3t && pair < D.n_pairs) {
-                        const int4 mp = (ck == 0) ? my_pair : D.ptab[pair];
+                    if (p3t && pair < D.n_pairs && !(PD_GGS_ABLATE & 2)) {
+                        const int4 mp = (ck == 0) ? make_int4(my_pair_xz & 0xffff, my_pair_y, (int)((unsigned)my_pair_xz >> 16), my_pair_w) : D.ptab[pair];
                         const int pi = mp.x & 0xff, pj = mp.x >> 8, nit = mp.z;
                         float G[9];
 #pragma unroll
@@ -1163,7 +1209,8 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
                 __syncthreads();
                 if (prof) { const long long n_ = __builtin_readcyclecounter(); if (lane == 0) L.prof[7] += n_ - pq; pq = n_; }
                 // ---- P3b: per-frame sums over the rows of this chunk, fixed (ascending) order ----
-                if (fast34) {
+                if (PD_GGS_ABLATE & 4) {
+                } else if (fast34) {
                     if (wave < n_row_waves) {            // (wave-uniform: every lane of these waves runs along, rows past N on frame 0's data)
                         const bool row_ok = fb_n < N;
                         // column fb_c of frame fb_n's `cap` rows (rows past the frame's pairs are zero): 24 loads issued back to back --
@@ -1238,7 +1285,7 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
                     float v = 0.0f;
                     if (x < 4) {
                         if (S.update_R) {
-                            const float qn[4] = {L.xst[n * 9 + 3], L.xst[n * 9 + 4], L.xst[n * 9 + 5], L.xst[n * 9 + 6]};
+                            const float qn[4] = {L.xst[n * PD_XS_STRIDE + 3], L.xst[n * PD_XS_STRIDE + 4], L.xst[n * PD_XS_STRIDE + 5], L.xst[n * PD_XS_STRIDE + 6]};
                             float Wr[9];
                             jac_row_x(qn, x, Wr);
                             const float *ps = L.psum + n * 16;
@@ -1271,10 +1318,10 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
         }
         if (wave == 0 && lane == 0 && wg == 0 && P.stats) {
             float *so = P.stats + ((size_t)b * P.n_stages + st) * 4;
-            so[0] = last_print;
+            so[0] = L.ctl[5];
             so[1] = (float)stepped;
-            so[2] = last_cnt;
-            so[3] = last_loss;
+            so[2] = L.ctl[6];
+            so[3] = L.ctl[7];
         }
         if (P.eval_only) break;
     }
@@ -1283,7 +1330,7 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
     }
     if (own && wg == 0 && !P.eval_only) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) xg[lane * 9 + c] = L.xst[lane * 9 + c];
+        for (int c = 0; c < 9; ++c) xg[lane * 9 + c] = L.xst[lane * PD_XS_STRIDE + c];
     }
     if (STAGE_P > 0) pd_vmcnt<0>();   // the look-ahead LDS-DMA of the last item must land before the LDS is handed on
 }
@@ -1361,8 +1408,8 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
     if (wave == 0) {
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
-            L.xst[lane * 9 + c] = own ? xg[lane * 9 + c] : 0.0f;
-            L.mst[lane * 9 + c] = 0.0f;
+            L.xst[lane * PD_XS_STRIDE + c] = own ? xg[lane * 9 + c] : 0.0f;
+            L.mst[lane * PD_XS_STRIDE + c] = 0.0f;
         }
     }
     for (int s = tid; s < n_slots; s += PD_GGS_THREADS) {
@@ -1386,8 +1433,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
     }
     if (wave == 0) {
         float xr0[9];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) xr0[c] = L.xst[lane * 9 + c];
+        params_load(L.xst, lane, xr0);
         decode_all(L, xr0, lane, N, D);
     }
     __syncthreads();
@@ -1419,16 +1465,8 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                 const int4 e = L.itab[s];
                 if (e.y > 0) {
                     float Ri[9], Rj[9], ti[3], tj[3];
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) {
-                        Ri[c] = L.Rc[e.z * 9 + c];
-                        Rj[c] = L.Rc[e.w * 9 + c];
-                    }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        ti[c] = L.tc[e.z * 3 + c];
-                        tj[c] = L.tc[e.w * 3 + c];
-                    }
+                    frame_load(L, e.z, Ri, ti);
+                    frame_load(L, e.w, Rj, tj);
                     PairFwd f;
                     pair_forward(Ri, ti, Rj, tj, f);
                     float F[9];
@@ -1578,7 +1616,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
     }
     if (own && wg == 0 && !P.eval_only) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) xg[lane * 9 + c] = L.xst[lane * 9 + c];
+        for (int c = 0; c < 9; ++c) xg[lane * 9 + c] = L.xst[lane * PD_XS_STRIDE + c];
     }
 }
 

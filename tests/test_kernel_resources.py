@@ -35,7 +35,7 @@ def test_ggs_kernel_variants_keep_their_register_budget(tmp_path):
             assert r["VGPRs"] <= 168 and r["Occupancy"] == 3, (name, r)
             assert r["VGPRs Spill"] <= 16 and r["ScratchSize"] <= 64, (name, r)     # launch constants of the serial phases only
         else:
-            assert r["VGPRs"] <= 256 and r["Occupancy"] == 2, (name, r)
+            assert r["VGPRs"] <= 256 and r["Occupancy"] >= 2, (name, r)
             assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
     # the lane-per-item kernel: 6 waves of up to 256 registers (two per SIMD on half of the SIMDs), most of them holding matches for the
     # whole launch; what is spilled are launch constants and up to three of the twelve resident steps (reloaded once per iteration)

@@ -29,7 +29,10 @@ def child(lib):
     for s in range(4):
         enc = synth.make_cameras(N, seed=2000 + s)
         mds.append((enc, synth.make_matches(enc, 224, 224, per_pair=300, seed=2000 + s)))
-    for B, wgs, flags in SHAPES:
+    shapes = [(1, 0, 0), (64, 1, 0)] if os.environ.get("PD_AB_ABLATION") else SHAPES      # ablated libraries (PD_GGS_ABLATE): no early exit on garbage sums
+    if os.environ.get("PD_AB_SHAPES"):                                                   # "B,wgs,flags;B,wgs,flags;..."
+        shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["PD_AB_SHAPES"].split(";")]
+    for B, wgs, flags in shapes:
         eng = PoseEngine(denoiser_state(diff.model), {k: v for k, v in diff.named_buffers(recurse=False)}, device=dev, max_B=B, max_N=N)
         x0 = []
         for b in range(B):
@@ -37,7 +40,7 @@ def child(lib):
             eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
             x0.append(synth.perturb_pose(enc, seed=7 + b))
         x0 = torch.cat(x0).to(dev)
-        cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=wgs, reserved=flags)
+        cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=wgs, reserved=flags, **({"min_matches": 0} if os.environ.get("PD_AB_ABLATION") else {}))
         eng.ggs_guide(x0, 0, cfg)
         best, iters = 1e9, 0
         for rep in range(3):
