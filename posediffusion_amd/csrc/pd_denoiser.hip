@@ -178,6 +178,11 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
     float4 w0[BATCH];
 #pragma unroll
     for (int c = 0; c < BATCH; ++c) w0[c] = wp[(size_t)c * 64];
+    // ... and the bias the epilogue adds (requested behind the two barriers below it is a dependent L2 round trip at the very end: -3.5 us per
+    // step at B = 1).  The residual values (EPI 2) stay where they are: requested up here they cost +4 us per kernel (measured, tools/den_ab.py).
+    constexpr int RPW = NACC / 4;          // accumulator registers finished per wave
+    const int col = n0 + ((NT == 32) ? (lane & 31) : (lane & 15));
+    const float bias = g.bias[col];
 
     // ---- stage the 32 activation rows (fused LN / embedding); no predicated loads ---------------
     {
@@ -330,9 +335,6 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < NACC; ++i) red[(wave * NACC + i) * 64 + lane] = accv[i];
     __syncthreads();
-    constexpr int RPW = NACC / 4;          // accumulator registers finished per wave
-    const int col = n0 + ((NT == 32) ? (lane & 31) : (lane & 15));
-    const float bias = g.bias[col];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int reg = wave * RPW + i;
@@ -643,6 +645,10 @@ __global__ __launch_bounds__(256) void pd_tail_kernel(HeadArgs g) {
     if (m >= g.M) return;
     const float *row = g.hid + (size_t)m * HID;
     const float v0 = row[lane], v1 = row[64 + lane];
+    // everything the last nine lanes add at the end is requested now (clamped lane: no predicated loads), not behind the reductions
+    const int l9 = lane < 9 ? lane : 8;
+    const size_t at = (size_t)m * 9 + l9;
+    const float b3v = g.b3[l9], xv = g.x[at], nz = g.noise ? g.noise[at] : 0.0f;
     const float mean = pd_wave_sum(v0 + v1) * (1.0f / HID);
     const float d0 = v0 - mean, d1 = v1 - mean;
     const float rstd = 1.0f / sqrtf(pd_wave_sum(d0 * d0 + d1 * d1) * (1.0f / HID) + 1e-5f);
@@ -655,15 +661,13 @@ __global__ __launch_bounds__(256) void pd_tail_kernel(HeadArgs g) {
         e = (lane == o) ? part : e;
     }
     if (lane < 9) {
-        e += g.b3[lane];
-        const size_t at = (size_t)m * 9 + lane;
-        const float xv = g.x[at];
+        e += b3v;
         const float x0 = g.pred_x0 ? e : g.c_recip * xv - g.c_recipm1 * e;   // gaussian_diffuser.py:190-194, :221-227
         const float mu = g.coef1 * x0 + g.coef2 * xv;               // :201-205
         if (g.eps_out) g.eps_out[at] = e;
         if (g.x0_out) g.x0_out[at] = x0;
         if (g.mean_out) g.mean_out[at] = mu;
-        if (g.xnext_out) g.xnext_out[at] = g.noise ? mu + g.sigma * g.noise[at] : mu;   // :280
+        if (g.xnext_out) g.xnext_out[at] = g.noise ? mu + g.sigma * nz : mu;   // :280
     }
 }
 
