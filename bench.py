@@ -65,7 +65,7 @@ FP32_PEAK_TFLOPS = 157.3             # MI355X fp32 vector ALU = dense fp32 MFMA 
 F16_PEAK_TFLOPS = 2500.0            # dense fp16 / bf16 MFMA peak (same guide; the sparsity figure is never used)
 HBM_PEAK_GBS = 8000.0
 MATCH_BYTES = 16                     # kp1, kp2: 2 x float2 per match (pair indices are per work item)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round3_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round4_pmc_summary.json")
 
 
 # ------------------------------------------------------------------------------------------------------------ inputs
@@ -307,6 +307,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    from posediffusion_amd import _lib
     from posediffusion_amd.engine import PoseEngine, make_ggs_cfg
     from posediffusion_amd.host import denoiser_state, get_engine, pack_matches
     from posediffusion_amd.pipeline import SamplingPipeline
@@ -334,7 +335,10 @@ def main():
     want_fresh = not args.no_fresh_inputs
     inputs = [make_batch_inputs(engines[j], diff, EB, dev, seed0=100_000 * rank + j * EB, keep_host=want_fresh) for j in range(depth)]
     wgs = args.ggs_wgs if args.ggs_wgs > 0 else pipe.wgs_per_seq(EB)
-    cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=wgs, reserved=int(os.environ.get("PD_GGS_RESERVED", "0")))   # A/B switch, pd_engine.h
+    flags = int(os.environ.get("PD_GGS_RESERVED", "0"))                                                          # A/B switch, pd_engine.h
+    if wgs == 1 and not (flags & _lib.PD_GGS_CFG_NO_LANE_ITEMS):
+        flags |= _lib.PD_GGS_CFG_LANE_ITEMS       # one workgroup per sequence: the lane-per-item kernel (SamplingPipeline.make_cfg does the same)
+    cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=wgs, reserved=flags)
     use_graph = not args.no_graph
     torch.cuda.synchronize()
 
@@ -476,7 +480,7 @@ def main():
             zc, nc, mds = inputs[j]
             kp1, kp2, i12, off, shape = pack_matches(mds, pin=True)
             sets.append((zc.cpu().pin_memory(), nc.cpu().pin_memory(), kp1, kp2, i12, off, shape))
-        hints = dict(max_pairs=N_FRAMES * (N_FRAMES - 1) // 2, max_matches_per_pair=PER_PAIR)
+        hints = dict(max_pairs=N_FRAMES * (N_FRAMES - 1) // 2, max_matches_per_pair=PER_PAIR, one_order=True)
         staging = [tuple(torch.empty_like(t, device=dev) for t in sets[0][:5]) for _ in range(depth)]
         up_bytes = sum(t.numel() * t.element_size() for t in sets[0][:5])
 
@@ -539,11 +543,19 @@ def main():
     ggs_set_ms = max(evs[0][0].elapsed_time(e1) for _, e1 in evs)
     ggs_set_tflops = depth * ggs_flops / (ggs_set_ms * 1e-3) / 1e12
     match_bytes = float(EB) * M * MATCH_BYTES * 7 * cfg.iter_num             # streamed once per iteration at one workgroup per sequence
+    # (the lane-per-item kernel keeps 12 of a lane item's 75 steps in registers: it streams 84 % of these bytes -- `fabric.streamed_fraction`)
     ceil_rng, ceil_src = (None, "skipped (--no-stream-probe)") if (args.no_stream_probe or rank != 0) else stream_ceiling()
     ggs_traffic, traffic_src = pmc_traffic("ggs_launch", EB) if (wgs or 24) == 1 else (None, "PMC summary is for one workgroup per sequence")
     k_eff = wgs or 24
+    import ctypes as _C
+    plan8 = (_C.c_int * 8)()
+    lane_kernel = False
+    if hasattr(eng.lib, "pd_debug_ggs_plan") and eng.lib.pd_debug_ggs_plan(eng._h, EB, N_FRAMES, _C.byref(cfg), plan8) == 0:
+        lane_kernel = bool(plan8[6])
+    kname = ("pd_ggs_lane_kernel<12> (a lane per work item, 12 steps of every item resident in registers, the rest through an LDS ring fed by LDS-DMA)"
+             if lane_kernel else f"pd_ggs_kernel<5, false, {plan8[4] or 12}> (a wave per work item)")
     roofline = {
-        "kernel": f"pd_ggs_kernel (one launch = one guided diffusion step = 700 iterations x {EB} sequences, {k_eff} workgroup(s) per sequence)",
+        "kernel": f"{kname}: one launch = one guided diffusion step = 700 iterations x {EB} sequences, {k_eff} workgroup(s) per sequence",
         "bound": "valu", "bound_detail": "fp32 vector ALU, 157.3 TFLOP/s (SURVEY 8d names the arithmetic roofline for the Sampson kernel; the kernel issues no "
                                          "MFMA).  What actually binds the one-workgroup-per-sequence launch is the match stream: see `fabric`",
         "achieved": ggs_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ggs_tflops / FP32_PEAK_TFLOPS,
@@ -554,7 +566,8 @@ def main():
         "co_resident": {"launches": depth, "wall_ms": ggs_set_ms, "achieved": ggs_set_tflops, "frac": ggs_set_tflops / FP32_PEAK_TFLOPS,
                         "note": f"the {depth} contexts' launches issued together on their streams, as in the pipe; reproducible from "
                                 "profiles/ with tools/coresident_from_trace.py (union of the kernel's intervals in a rocprofv3 kernel trace)"},
-        "fabric": {"algorithmic_bytes_per_launch": match_bytes, "achieved_GBps_one_launch": match_bytes / (ggs_ms * 1e-3) / 1e9,
+        "fabric": {"algorithmic_bytes_per_launch": match_bytes, "streamed_fraction": (1.0 - 12.0 / ((PER_PAIR // 2 + 1) // 2)) if lane_kernel else 1.0,
+                   "achieved_GBps_one_launch": match_bytes / (ggs_ms * 1e-3) / 1e9,
                    "achieved_GBps_co_resident": depth * match_bytes / (ggs_set_ms * 1e-3) / 1e9,
                    "hbm_peak_GBps": HBM_PEAK_GBS, "frac_of_hbm_peak_one_launch": match_bytes / (ggs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "measured_ceiling_GBps": None if ceil_rng is None else [ceil_rng[0], ceil_rng[1]], "measured_ceiling_source": ceil_src,

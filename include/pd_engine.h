@@ -170,8 +170,12 @@ int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, const double 
  * {190, 512} for hloc's exhaustive i < j pairs of 20 frames with <= 512 matches each; with max_matches_per_pair in
  * 1..512 sequences of more than 32 frames take the two-hop kernel.  A violated hint empties the slot and, like a frame
  * index outside [0, n_frames), raises the asynchronous error word (pd_check_async_error). */
+#define PD_MATCH_HINT_ONE_ORDER (1 << 30)   /* OR-ed into pd_match_hints.max_pairs: every frame pair occurs in ONE order only (hloc's exhaustive
+                                            * i < j pairs, match_extraction.py:64-70), i.e. no frame is in more than n_frames - 1 pairs.  Lets
+                                            * the engine plan the launch shape of host-uploaded tables (the lane-per-item kernel needs that bound)
+                                            * for device-built ones too; checked on the device like every hint */
 typedef struct pd_match_hints {
-    int32_t max_pairs;               /* 0 = unknown; else an upper bound on the frame pairs that own matches            */
+    int32_t max_pairs;               /* 0 = unknown; else an upper bound on the frame pairs that own matches (| PD_MATCH_HINT_ONE_ORDER) */
     int32_t max_matches_per_pair;    /* 0 = unknown; else an upper bound on the matches of one frame pair               */
 } pd_match_hints;
 int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n_seqs, const int64_t *seq_offsets, const double *kp1,

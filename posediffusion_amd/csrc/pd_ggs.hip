@@ -1211,49 +1211,8 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
                 // ---- P3b: per-frame sums over the rows of this chunk, fixed (ascending) order ----
                 if (PD_GGS_ABLATE & 4) {
                 } else if (fast34) {
-                    if (wave < n_row_waves) {            // (wave-uniform: every lane of these waves runs along, rows past N on frame 0's data)
-                        const bool row_ok = fb_n < N;
-                        // column fb_c of frame fb_n's `cap` rows (rows past the frame's pairs are zero): 24 loads issued back to back --
-                        // an LDS round trip per group of four is what this phase would otherwise consist of --, summed in row order
-                        const float *src = L.pinc + ((row_ok ? fb_n : 0) * rstride) * 16 + fb_c;
-                        float acc = 0.0f;
-                        for (int e0 = 0; e0 < cap; e0 += 24) {
-                            float t[24];
-#pragma unroll
-                            for (int u = 0; u < 24; ++u) t[u] = src[(e0 + u) * 16];      // (past `cap`: the next frame's rows or the tables behind the rows; never added)
-#pragma unroll
-                            for (int u = 0; u < 24; u += 4)
-                                if (e0 + u < cap) {                                       // block-uniform, cap % 4 == 0
-                                    acc += t[u];
-                                    acc += t[u + 1];
-                                    acc += t[u + 2];
-                                    acc += t[u + 3];
-                                }
-                        }
-                        const float fs = row_ok ? fb_sign * acc : 0.0f;   // lanes 0..8: dL/dR[b][a] at m = 3 a + b; 9..11: dL/dT; 12..15: the frame's dL/dA partials
-                        // dL/dq_x (lanes x = 0..3 of the row) = sum_m W[frame][x][m] fs[lane m]: the sums come over the row's DPP
-                        // broadcast, the Jacobian row from LDS (jac_all); the other lanes run along on a clamped row
-                        const float *Wr = L.W + ((row_ok ? fb_n : 0) * 4 + (fb_c & 3)) * 12;
-                        const float4 w0 = *(const float4 *)Wr, w1 = *(const float4 *)(Wr + 4);
-                        const float w8 = Wr[8];
-                        float gq = row_bcast<0>(fs) * w0.x;
-                        gq = __builtin_fmaf(row_bcast<1>(fs), w0.y, gq);
-                        gq = __builtin_fmaf(row_bcast<2>(fs), w0.z, gq);
-                        gq = __builtin_fmaf(row_bcast<3>(fs), w0.w, gq);
-                        gq = __builtin_fmaf(row_bcast<4>(fs), w1.x, gq);
-                        gq = __builtin_fmaf(row_bcast<5>(fs), w1.y, gq);
-                        gq = __builtin_fmaf(row_bcast<6>(fs), w1.z, gq);
-                        gq = __builtin_fmaf(row_bcast<7>(fs), w1.w, gq);
-                        gq = __builtin_fmaf(row_bcast<8>(fs), w8, gq);
-                        // dL/dA: only the sum over ALL frames is needed (the focal length is the mean over frames, :142): the four rows of
-                        // the wave add up on the cross-lane network, P4 adds the waves' partials in wave order
-                        const float ga_w = add_xor32(add_xor16(fs));
-                        if (row_ok) {
-                            if (fb_c < 4) L.gq[fb_n * 8 + fb_c] = S.update_R ? gq : 0.0f;
-                            else if (fb_c >= 9 && fb_c < 12) L.gq[fb_n * 8 + fb_c - 5] = S.update_T ? fs : 0.0f;
-                            else if (fb_c >= 12 && lane < 16) L.gA[wave * 4 + fb_c - 12] = ga_w;
-                        }
-                    } else if (wave == W_LOSS) {
+#include "pd_ggs_p3b.inc"
+                    if (wave >= n_row_waves && wave == W_LOSS) {
                         loss_totals();
                     }
                 } else {         // several passes over the frames, partial sums carried across chunks in LDS
@@ -1621,19 +1580,6 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
 }
 
 #include "pd_ggs_lane.inc"
-// (register-resident steps, streamed steps in flight) variants of the lane kernel; PD_LANE_VARIANT in the environment picks one (development)
-struct PdLaneVariant {
-    void (*fn)(PdGgsParams, int, int);
-    int rv, depth;
-};
-#define PD_LANE_VARIANTS 2
-static const PdLaneVariant pd_lane_variants[PD_LANE_VARIANTS] = {{pd_ggs_lane_kernel<PD_LANE_RV, PD_LANE_DEPTH>, PD_LANE_RV, PD_LANE_DEPTH},
-                                                                 {pd_ggs_lane_kernel<10, 6>, 10, 6}};
-static int pd_lane_variant() {
-    static const int v0 = pd_dev_knob("PD_LANE_VARIANT", 0);
-    return (v0 < 0 || v0 >= PD_LANE_VARIANTS) ? 0 : v0;
-}
-
 // --------------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------------
@@ -1964,8 +1910,7 @@ int pd_ggs_init() {
                               (const void *)pd_ggs_kernel<3, false, 12>, (const void *)pd_ggs_kernel<5, false, 12>, (const void *)pd_ggs_kernel<6, false, 12>};
     for (const void *f : variants) PD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PD_HIP_CHECK(hipFuncSetAttribute((const void *)pd_ggs2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    for (int v = 0; v < PD_LANE_VARIANTS; ++v)
-        PD_HIP_CHECK(hipFuncSetAttribute((const void *)pd_lane_variants[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PD_HIP_CHECK(hipFuncSetAttribute((const void *)pd_ggs_lane_kernel<PD_LANE_RV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return PD_OK;
 }
 
@@ -1995,35 +1940,35 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
     int device_cus = eng->num_cus > 0 ? eng->num_cus : 256;
     int k = cfg->wgs_per_seq > 0 ? cfg->wgs_per_seq : (max_items + PD_GGS_WAVES - 1) / PD_GGS_WAVES;
     k = std::max(1, std::min(k, device_cus / B));
-    // the lane-per-item kernel: on request, or -- when the engine picks the shape and the launch holds more sequences than half the CUs
-    // (nothing to gain from several workgroups per sequence) -- where every sequence's matches stay RESIDENT in its registers + LDS
-    // (<= ~40 matches per lane item): there it runs 1.5 - 2 x faster than the wave-per-item kernel (profiles/round3_lane_kernel.txt).
-    // With more matches both kernels are bound by the same match stream from the Infinity Cache (7.2 - 7.7 TB/s) and the
-    // wave-per-item kernel, which keeps more of it in flight, stays the default.
+    // the lane-per-item kernel: on request (PD_GGS_CFG_LANE_ITEMS: what the pipeline sets wherever it gives a sequence ONE workgroup), or when
+    // the engine picks the shape and the launch holds more sequences than half the CUs (nothing to gain from several workgroups per sequence).
+    // An explicit wgs_per_seq without the flag keeps the wave-per-item kernels, whose results are bitwise independent of the workgroup
+    // count (the lane kernel sums in another fixed order: rounding-level differences).  Round 4: its stream goes through an
+    // LDS ring fed by LDS-DMA that never stops (pd_ggs_lane.inc) and it is 10 - 14 % faster than the 12-wave wave-per-item kernel at
+    // the bench shape (18.6 against 21.6 ms per 256-sequence launch, profiles/round4_lane_ring.txt); fully resident sequences 1.5 - 2 x.
     memset(out, 0, sizeof(*out));
-    if (!(cfg->reserved & PD_GGS_CFG_NO_LANE_ITEMS) && ((cfg->reserved & PD_GGS_CFG_LANE_ITEMS) || (cfg->wgs_per_seq == 0 && device_cus / B <= 1))) {
-        bool ok = N <= PD_LANE_MAX_FRAMES;
-        int pairs = 0, steps = 0;
+    if (!(cfg->reserved & PD_GGS_CFG_NO_LANE_ITEMS) &&
+        ((cfg->reserved & PD_GGS_CFG_LANE_ITEMS) || (cfg->wgs_per_seq == 0 && device_cus / B <= 1))) {
+        bool ok = N <= PD_GGS_FAST_FRAMES;
+        int pairs = 0, steps = 0, deg = 0;
         for (int b = 0; b < B && ok; ++b) {
             const PdSeqDesc &d = eng->seqs[b].desc;
             ok = d.n_litems > 0 && d.n_pchunks == 1;
             pairs = std::max(pairs, d.n_pairs);
             steps = std::max(steps, d.l_max_steps);
+            deg = std::max(deg, eng->seqs[b].max_deg);
         }
         if (ok) {
-            const int rv = pd_lane_variants[pd_lane_variant()].rv;
-            const int pinc_rows = 2 * std::min(PD_LANE_MAX_ITEMS, std::max(pairs, 1));
-            // PD_LANE_LDS_SPARE_KB (development knob): LDS left free beside the workgroup, e.g. for a denoiser GEMM workgroup of another context
-            static const int spare_kb = pd_dev_knob("PD_LANE_LDS_SPARE_KB", 0);
-            const int room = std::max(0, (int)((160 * 1024 - spare_kb * 1024 - (int)lane_lds_bytes(pinc_rows, 0)) / (PD_LANE_WAVES * 2048)));
-            const int rl = std::max(0, std::min(room, steps - rv));
-            if ((cfg->reserved & PD_GGS_CFG_LANE_ITEMS) || steps <= rv + rl) {
+            // rows of the pair backward at the fixed per-frame stride of the fast serial phases (pd_ggs_p3b.inc)
+            const int pinc_rows = std::max(2 * std::min(PD_LANE_MAX_ITEMS, std::max(pairs, 1)), N * (((deg + 3) & ~3) + 1));
+            const size_t lds = lane_lds_bytes(pinc_rows);        // tables + the six waves' rings (PD_LANE_RING steps of 2 KiB each)
+            if (lds <= 160 * 1024) {
                 out->lane = 1;
-                out->lane_rl = rl;
+                out->lane_rl = std::max(0, std::min(PD_LANE_RING, steps - PD_LANE_RV));   // (reported: steps of a lane item that live in the ring)
                 out->k = 1;
                 out->waves = PD_LANE_WAVES;
                 out->pinc_rows = pinc_rows;
-                out->lds = (int)lane_lds_bytes(pinc_rows, rl);
+                out->lds = (int)lds;
                 out->max_items = PD_LANE_MAX_ITEMS;
                 return PD_OK;
             }
@@ -2192,7 +2137,7 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
         hipLaunchKernelGGL(pd_ggs_zero_kernel, dim3(256), dim3(256), 0, s, eng->d_xchg, n_zero);
     }
     if (plan.lane)
-        hipLaunchKernelGGL(pd_lane_variants[pd_lane_variant()].fn, dim3(B), dim3(PD_LANE_THREADS), lds, s, P, plan.lane_rl, pinc_rows);
+        hipLaunchKernelGGL(pd_ggs_lane_kernel<PD_LANE_RV>, dim3(B), dim3(PD_LANE_THREADS), lds, s, P, pinc_rows);
     else if (two_hop)
         hipLaunchKernelGGL(pd_ggs2_kernel, dim3(B * k), dim3(PD_GGS_THREADS), lds, s, P, B, n_slots);
     else {

@@ -41,6 +41,7 @@ struct IngestArgs {
     const long long *i12;
     int N, P_cap, I_cap, C_cap, per_pair_cap;
     int LS_cap;                  // capacity of the lane-major stream in steps per wave (0: no lane-per-item tables for this slice)
+    int deg_cap;                 // most pairs one frame may be in (PD_MATCH_HINT_ONE_ORDER: n_frames - 1; else no bound below 2 (n_frames - 1))
     float sc, cx, cy;
     unsigned int *err_flag;
 };
@@ -230,9 +231,13 @@ __global__ __launch_bounds__(ING_TABLE_THREADS) void ingest_tables_kernel(Ingest
                 }
                 row += hit0 + hit1;
             }
-            if (pass == 0) foff[c * (N + 1) + n] = row;        // degree
+            if (pass == 0) {
+                foff[c * (N + 1) + n] = row;                   // degree
+                if (row > A.deg_cap) atomicOr(&flags[0], 4);   // a frame in more pairs than the hint allows
+            }
         }
         __syncthreads();
+        if (pass == 0) bad = flags[0] != 0;                    // (block-uniform again)
         if (pass == 0) {
             if (tid <= A.C_cap) {                              // exclusive scan over the frames of chunk `tid`
                 int run = 0;
@@ -458,7 +463,9 @@ extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n
     }
     PD_HIP_CHECK(hipSetDevice(eng->device));
     hipStream_t s = (hipStream_t)stream;
-    const int hint_pairs = hints ? hints->max_pairs : 0, hint_per_pair = hints ? hints->max_matches_per_pair : 0;
+    const bool one_order = hints && hints->max_pairs > 0 && (hints->max_pairs & PD_MATCH_HINT_ONE_ORDER);
+    const int hint_pairs = hints ? (hints->max_pairs > 0 ? (hints->max_pairs & ~PD_MATCH_HINT_ONE_ORDER) : hints->max_pairs) : 0;
+    const int hint_per_pair = hints ? hints->max_matches_per_pair : 0;
     if (hint_pairs < 0 || hint_per_pair < 0) {
         pd_set_error("pd_ggs_set_matches_csr_async: negative hint");
         return PD_ERR_INVALID_ARG;
@@ -551,6 +558,7 @@ extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n
         A.I_cap = I_cap;
         A.C_cap = C_cap;
         A.LS_cap = sl.LS_cap;
+        A.deg_cap = (one_order ? 1 : 2) * (N - 1);
         int max_tiles = 0;
         for (int b = 0; b < nb; ++b) {
             const int slot = seq_first + b0 + b;
@@ -600,7 +608,9 @@ extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n
             h.desc.cx = A.cx;
             h.desc.cy = A.cy;
             h.max_item_len = single ? hint_per_pair : PD_ITEM_MAX_MATCHES;
-            h.max_deg = std::min(P_cap, 2 * (N - 1));          // an upper bound (the host never learns the pair list): every pair of both orders
+            // an upper bound (the host never learns the pair list): every pair in both orders, or one (PD_MATCH_HINT_ONE_ORDER; the tables
+            // kernel checks the degrees against it)
+            h.max_deg = std::min(P_cap, (one_order ? 1 : 2) * (N - 1));
             h.device_built = true;
         }
         const size_t lds_hist = sizeof(int) * (size_t)N * N;

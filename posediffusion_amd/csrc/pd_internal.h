@@ -24,7 +24,7 @@
 #define PD_LANE_WAVES 6
 #define PD_LANE_THREADS (PD_LANE_WAVES * PD_WAVE)
 #define PD_LANE_MAX_ITEMS PD_LANE_THREADS   // one lane item per thread
-#define PD_LANE_MAX_FRAMES 48               // 16 threads per frame in the per-frame sums
+#define PD_LANE_MAX_FRAMES 24               // 16 threads per frame in the per-frame sums (= PD_GGS_FAST_FRAMES: the fast serial phases)
 #define PD_LANE_ITEM_VALS 10                // 9 dL/dF sums + sum(s valid) per lane item
 #define PD_GGS_FAST_FRAMES 24               // one-hop kernel: up to this many frames the per-frame sums take 16 lanes per frame (6 waves) and two
                                             //   idle waves form the totals beside them (pd_ggs_kernel, "fast serial phases")

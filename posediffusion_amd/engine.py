@@ -167,13 +167,15 @@ class PoseEngine:
                                                    kp1.shape[0], n, h, w), "pd_ggs_set_matches")
 
     def set_matches_async(self, seq_first: int, kp1: torch.Tensor, kp2: torch.Tensor, i12: torch.Tensor, offsets,
-                          img_shape: Sequence[int], max_pairs: int = 0, max_matches_per_pair: int = 0):
+                          img_shape: Sequence[int], max_pairs: int = 0, max_matches_per_pair: int = 0, one_order: bool = False):
         """Asynchronous, device-resident upload of the matches of consecutive slots (pd_ggs_set_matches_csr_async).
 
         kp1 / kp2: float64 [total, 2], i12: int64 [total, 2] -- CUDA tensors on this device or PINNED host tensors (the
         kernels then read them over PCIe); ``offsets`` [n + 1]: CSR offsets, sequence b = rows offsets[b]:offsets[b+1].
         Runs on torch's current stream; returns at once.  The engine keeps the tensors alive until the upload has
-        executed.  ``max_pairs`` / ``max_matches_per_pair``: capacity hints (include/pd_engine.h pd_match_hints)."""
+        executed.  ``max_pairs`` / ``max_matches_per_pair``: capacity hints (include/pd_engine.h pd_match_hints); ``one_order``: every
+        frame pair occurs in one order only (hloc's exhaustive i < j pairs: PD_MATCH_HINT_ONE_ORDER) -- with it the engine plans the same
+        launch shape as for host-uploaded tables."""
         for name, t, dt in (("kp1", kp1, torch.float64), ("kp2", kp2, torch.float64), ("i12", i12, torch.int64)):
             if t.dtype != dt or t.dim() != 2 or t.shape[1] != 2 or not t.is_contiguous():
                 raise ValueError(f"{name} must be a contiguous {dt} tensor of shape [total, 2]")
@@ -184,7 +186,7 @@ class PoseEngine:
         if off.ndim != 1 or len(off) < 2 or off[0] < 0 or off[-1] > kp1.shape[0] or kp1.shape != kp2.shape or kp1.shape != i12.shape:
             raise ValueError("offsets must be [n_seqs + 1] within the rows of kp1 / kp2 / i12 (equal shapes)")
         n, _, h, w = (int(v) for v in img_shape)
-        hints = _lib.pd_match_hints(int(max_pairs), int(max_matches_per_pair))
+        hints = _lib.pd_match_hints(int(max_pairs) | (_lib.PD_MATCH_HINT_ONE_ORDER if (one_order and max_pairs > 0) else 0), int(max_matches_per_pair))
         cache = self.__dict__.setdefault("_match_ids", {})
         for b in range(len(off) - 1):
             cache.pop(int(seq_first) + b, None)                    # host.upload_matches' identity cache

@@ -16,7 +16,7 @@ import torch
 
 from conftest import rel_err
 from oracle import pd_oracle as O
-from posediffusion_amd import synth
+from posediffusion_amd import _lib, synth
 from posediffusion_amd.engine import make_ggs_cfg
 
 pytestmark = pytest.mark.gpu
@@ -405,7 +405,7 @@ def test_bench_default_shape_one_workgroup_per_sequence(seeded_diffuser, engine,
         mds.append(md)
         x0s.append(synth.perturb_pose(enc, seed=50 + b))
     x0 = torch.cat(x0s).to(dev)
-    cfg1 = make_ggs_cfg(iter_num=6, wgs_per_seq=1)
+    cfg1 = make_ggs_cfg(iter_num=6, wgs_per_seq=1, reserved=_lib.PD_GGS_CFG_NO_LANE_ITEMS)   # the wave-per-item kernels (bitwise across workgroup counts)
     out64, st64, _ = eng.ggs_optimize(x0, cfg=cfg1)
     eng.check_async()
     assert (st64.reshape(B, -1)[:, 1] == 12).all()                      # 6 iterations x 2 runs ("all" = T alone, then all) everywhere
@@ -413,7 +413,7 @@ def test_bench_default_shape_one_workgroup_per_sequence(seeded_diffuser, engine,
         md = mds[b]
         engine.set_matches(0, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
         for k in (1, 24):
-            o, _, _ = engine.ggs_optimize(x0[b:b + 1], cfg=make_ggs_cfg(iter_num=6, wgs_per_seq=k))
+            o, _, _ = engine.ggs_optimize(x0[b:b + 1], cfg=make_ggs_cfg(iter_num=6, wgs_per_seq=k, reserved=_lib.PD_GGS_CFG_NO_LANE_ITEMS))
             engine.check_async()
             assert torch.equal(o[0], out64[b]), (b, k)
     # a whole guided pass of the batch (2 guided steps): hipGraph replay equals eager launches bit for bit, (single sequences are not compared here: at 1 280 token rows the denoiser takes other GEMM

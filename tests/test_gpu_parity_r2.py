@@ -299,7 +299,7 @@ def test_async_match_ingestion_is_bitwise_the_host_upload(seeded_diffuser, case,
         N, (mds, x0) = 9, _ragged_batch(9, [800, 801, 802, 803, 804])
     elif case == "n20_full":
         N, (mds, x0) = 20, _ragged_batch(20, [810, 811], shuffle=False, per_pair=lambda b: 300)
-        hints = dict(max_pairs=190, max_matches_per_pair=512)
+        hints = dict(max_pairs=190, max_matches_per_pair=512, one_order=True)     # (i < j pairs: the same launch plan as the host-built tables)
     elif case == "n12_ordered_big_pair":
         N, (mds, x0) = 12, _ragged_batch(12, [820, 821, 822], ordered=True, big_pair=1300)
     else:
@@ -442,7 +442,7 @@ def test_one_workgroup_per_sequence_kernel_variants_agree_bitwise(seeded_diffuse
     x0 = torch.cat(xs).to(dev)
     res = {}
     for flags in (0, 4, 2, 6):
-        out, stats = eng.ggs_guide(x0, 3, make_ggs_cfg(synth.GGS_CFG, iter_num=5, wgs_per_seq=1, reserved=flags))
+        out, stats = eng.ggs_guide(x0, 3, make_ggs_cfg(synth.GGS_CFG, iter_num=5, wgs_per_seq=1, reserved=flags | 16))   # (16 = PD_GGS_CFG_NO_LANE_ITEMS: the wave-per-item kernels)
         eng.check_async()
         res[flags] = (out.clone(), stats.clone())
     for flags in (4, 2, 6):

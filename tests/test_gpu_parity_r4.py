@@ -193,26 +193,30 @@ def test_ggs_plan_keeps_the_exchange_region(seeded_diffuser):
     eng.close()
 
 
-def test_engine_picks_the_lane_kernel_only_where_every_match_is_resident(seeded_diffuser):
-    """pd_ggs_plan's own choice: more sequences than half the CUs and every lane item resident in registers +
-    LDS -> the lane-per-item kernel; the bench's 300 matches per pair (two lane items of 75 steps per pair) -> the wave-per-item kernel
-    with 12 waves; fewer sequences than half the CUs -> never the lane kernel."""
+def test_engine_picks_the_lane_kernel_where_a_sequence_gets_one_workgroup(seeded_diffuser):
+    """pd_ggs_plan's own choice: more sequences than half the CUs (one workgroup per sequence is all there is) ->
+    the lane-per-item kernel, whether the sequences are fully resident (40 matches per pair) or stream through its LDS ring (300: the
+    bench shape, where it is 10 - 14 % faster since round 4); fewer sequences -> several workgroups per sequence on the wave-per-item
+    kernels, and an EXPLICIT workgroup count without PD_GGS_CFG_LANE_ITEMS always stays on those (bitwise independent of the count)."""
     B, N = 130, 20
     eng = _engine(seeded_diffuser, B, N)
     enc = synth.make_cameras(N, seed=77)
-    cfg = make_ggs_cfg(synth.GGS_CFG)
     plan = (C.c_int * 8)()
     got = {}
     for per_pair in (40, 300):
         md = synth.make_matches(enc, 224, 224, per_pair=per_pair, seed=78)
         for b in range(B):
             eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
-        _lib.check(eng.lib.pd_debug_ggs_plan(eng._h, B, N, C.byref(cfg), plan), "pd_debug_ggs_plan")
-        got[(per_pair, B)] = list(plan)
-        _lib.check(eng.lib.pd_debug_ggs_plan(eng._h, 64, N, C.byref(cfg), plan), "pd_debug_ggs_plan")
-        got[(per_pair, 64)] = list(plan)
-    print("plans {k, slots, lds, two_hop, waves, stage_p, lane, lane_rl}:", got)
-    assert got[(40, B)][6] == 1 and got[(40, B)][0] == 1
-    assert got[(300, B)][6] == 0 and got[(300, B)][0] == 1 and got[(300, B)][4] == 12
-    assert got[(40, 64)][6] == 0 and got[(300, 64)][6] == 0
+        for tag, nb, cfg in (("auto", B, make_ggs_cfg(synth.GGS_CFG)), ("auto", 64, make_ggs_cfg(synth.GGS_CFG)),
+                             ("wgs1", B, make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=1)),
+                             ("wgs1_lane", 64, make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=1, reserved=_lib.PD_GGS_CFG_LANE_ITEMS))):
+            _lib.check(eng.lib.pd_debug_ggs_plan(eng._h, nb, N, C.byref(cfg), plan), "pd_debug_ggs_plan")
+            got[(per_pair, tag, nb)] = list(plan)
+    print("plans {k, slots, lds, two_hop, waves, stage_p, lane, ring steps}:", got)
+    for per_pair in (40, 300):
+        assert got[(per_pair, "auto", B)][6] == 1 and got[(per_pair, "auto", B)][0] == 1
+        assert got[(per_pair, "auto", 64)][6] == 0 and got[(per_pair, "auto", 64)][0] > 1
+        assert got[(per_pair, "wgs1", B)][6] == 0 and got[(per_pair, "wgs1", B)][0] == 1
+        assert got[(per_pair, "wgs1_lane", 64)][6] == 1
+    assert got[(300, "wgs1", B)][4] == 12                          # the staged 12-wave kernel
     eng.close()
