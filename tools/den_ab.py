@@ -1,5 +1,5 @@
 """Same-box A / B of the small-batch denoiser step between engine libraries: us per step alone (pd_time_kernel) at B = 1 and B = 8, N = 20,
-and one step against the fp64 oracle.   python tools/den_ab.py [libA.so libB.so ...]"""
+and a checksum of one step (parity is the tests' business).   python tools/den_ab.py [libA.so libB.so ...]"""
 import os
 import subprocess
 import sys
@@ -10,7 +10,6 @@ sys.path.insert(0, ROOT)
 
 def child():
     import torch
-    from oracle import pd_oracle as O
     from posediffusion_amd import synth
     from posediffusion_amd.engine import PoseEngine
     from posediffusion_amd.host import denoiser_state, draw_noise
@@ -18,16 +17,13 @@ def child():
     N = 20
     diff = synth.make_diffuser(seed=0)
     synth.randomize_norm_and_bias_(diff.model)
-    sd64 = {k: v.double() for k, v in O.cast_state_dict(diff.model.state_dict(), torch.float32).items()}
     diff = diff.to(dev)
     for B in (1, 8):
         eng = PoseEngine(denoiser_state(diff.model), {n: v for n, v in diff.named_buffers(recurse=False)}, device=dev, max_B=B, max_N=N)
         z = synth.make_z(B, N).to(dev)
         x = torch.randn(B, N, 9, generator=torch.Generator().manual_seed(3))
         out = eng.denoise(x.to(dev), z, 40).cpu().double()
-        with torch.no_grad():
-            ref = O.denoiser_forward(sd64, x.double(), torch.full((B,), 40, dtype=torch.long), z.cpu().double())
-        err = float((out - ref).abs().max() / ref.abs().max())
+        err = float(out.sum())
         noise = draw_noise((B, N, 9), 100, dev)
         eng.sample(z, noise, 0, None, use_graph=True, want_process=False)
         torch.cuda.synchronize()
@@ -38,7 +34,7 @@ def child():
             eng.sample(z, noise, 0, None, use_graph=True, want_process=False)
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - t0) * 1e3)
-        print(f"  B={B}: step alone {eng.time_kernel(0, B, N, reps=50) * 1e3:7.1f} us; 100-step pass (hipGraph) {min(ts):7.3f} ms; one step vs fp64 {err:.2e}", flush=True)
+        print(f"  B={B}: step alone {eng.time_kernel(0, B, N, reps=50) * 1e3:7.1f} us; 100-step pass (hipGraph) {min(ts):7.3f} ms; checksum of one step {err:.9f}", flush=True)
         eng.close()
 
 
