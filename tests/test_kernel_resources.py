@@ -33,16 +33,17 @@ def test_ggs_kernel_variants_keep_their_register_budget(tmp_path):
         twelve = "ELi12EE" in name
         if twelve:
             assert r["VGPRs"] <= 168 and r["Occupancy"] == 3, (name, r)
-            assert r["VGPRs Spill"] <= 16 and r["ScratchSize"] <= 64, (name, r)     # launch constants of the serial phases only
+            assert r["VGPRs Spill"] <= 4 and r["ScratchSize"] <= 16, (name, r)      # (round 4: one register, touched before the iteration loop only)
         else:
             assert r["VGPRs"] <= 256 and r["Occupancy"] >= 2, (name, r)
             assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
-    # the lane-per-item kernel: 6 waves of up to 256 registers (two per SIMD on half of the SIMDs), most of them holding matches for the
-    # whole launch; what is spilled are launch constants and up to three of the twelve resident steps (reloaded once per iteration)
+    # the lane-per-item kernel: 6 waves of up to 256 registers (two per SIMD on half of the SIMDs), twelve steps of every lane item resident in
+    # them for the whole launch and NOTHING spilled (round 4: its pass is bound by instruction issue; 16 resident steps spill 26 registers and
+    # cost 4 % of a launch, profiles/round4_lane_ring.txt)
     lane = {k: v for k, v in kernels.items() if "pd_ggs_lane_kernel" in k}
-    assert len(lane) == 2, sorted(kernels)
+    assert len(lane) == 1, sorted(kernels)
     for name, r in lane.items():
-        assert r["VGPRs"] <= 256 and r["Occupancy"] == 2 and r["VGPRs Spill"] <= 96 and r["ScratchSize"] <= 400, (name, r)
+        assert r["VGPRs"] <= 256 and r["Occupancy"] == 2 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
     two_hop = [v for k, v in kernels.items() if "pd_ggs2_kernel" in k]
     assert two_hop and two_hop[0]["VGPRs Spill"] == 0 and two_hop[0]["ScratchSize"] == 0
 
