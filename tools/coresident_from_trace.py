@@ -16,9 +16,9 @@ flops = float(sys.argv[2]) if len(sys.argv) > 2 else 256 * 57000 * 100.0 * 700  
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
 kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
 ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
-rows = db.execute(f"select d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id where s.kernel_name like '%pd_ggs_kernel%' order by d.start").fetchall()
+rows = db.execute(f"select d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id where (s.kernel_name like '%pd_ggs_kernel%' or s.kernel_name like '%pd_ggs_lane_kernel%') order by d.start").fetchall()
 if not rows:
-    raise SystemExit("no pd_ggs_kernel dispatches in the trace")
+    raise SystemExit("no pd_ggs_kernel / pd_ggs_lane_kernel dispatches in the trace")
 sets, cur = [], [rows[0]]
 cur_end = rows[0][1]
 for st, en in rows[1:]:
@@ -33,7 +33,7 @@ by_size = defaultdict(list)
 for s in sets:
     by_size[len(s)].append(s)
 durs = [(en - st) / 1e6 for st, en in rows]
-print(f"pd_ggs_kernel: {len(rows)} launches, average duration {sum(durs) / len(durs):.3f} ms (min {min(durs):.3f}, max {max(durs):.3f})")
+print(f"GGS kernel (pd_ggs_lane_kernel since round 4, else pd_ggs_kernel): {len(rows)} launches, average duration {sum(durs) / len(durs):.3f} ms (min {min(durs):.3f}, max {max(durs):.3f})")
 print(f"one launch alone: {flops / (sum(durs) / len(durs) * 1e-3) / 1e12:.2f} TFLOP/s = {flops / (sum(durs) / len(durs) * 1e-3) / 1e12 / 157.3 * 100:.1f} % of 157.3 (fp32 vector ALU), "
       f"{flops / 1e9:.2f} GFLOP per launch")
 for n in sorted(by_size):

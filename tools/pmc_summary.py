@@ -76,7 +76,8 @@ def main():
                              "coalesced read stream on gfx950 -> doubled in *_corrected; Infinity-Cache hits are counted "
                              "(fabric-side counter), so this is L2-miss traffic, an upper bound on HBM bytes",
         "kernels": kernels,
-        "ggs_launch": {"traffic_bytes_corrected": corrected("pd_ggs_kernel")},
+        "ggs_launch": {"traffic_bytes_corrected": corrected("pd_ggs_lane_kernel") or corrected("pd_ggs_kernel"),
+                       "kernel": "pd_ggs_lane_kernel" if corrected("pd_ggs_lane_kernel") else "pd_ggs_kernel"},
         "denoiser_step": {"traffic_bytes_corrected": den},
     }
     json.dump(out, sys.stdout, indent=1)

@@ -6,7 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from posediffusion_amd import synth
+from posediffusion_amd import _lib, synth
 from posediffusion_amd.engine import PoseEngine, make_ggs_cfg
 from posediffusion_amd.host import denoiser_state
 
@@ -22,7 +22,7 @@ for b in range(B):
     md = mds[b % len(mds)]
     eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
 x0 = torch.cat([synth.perturb_pose(cams[b % len(cams)], seed=7 + b) for b in range(B)]).to(dev)
-cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=k)
+cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=k, reserved=_lib.PD_GGS_CFG_LANE_ITEMS if k == 1 else 0)   # as the pipeline asks (SamplingPipeline.make_cfg)
 for _ in range(2):
     eng.ggs_guide(x0, 0, cfg)
 torch.cuda.synchronize()
