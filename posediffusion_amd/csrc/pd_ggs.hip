@@ -1765,7 +1765,8 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
     }
 
     // lane-per-item tables (pd_ggs_lane_kernel): every pair is cut into ceil(m / len) lane items of balanced size, len = the smallest
-    // length that leaves a sequence at most PD_LANE_MAX_ITEMS items; lane item q belongs to thread q, a wave's stream holds
+    // length that leaves a sequence at most PD_LANE_MAX_ITEMS items (+ one more cut for the pairs with the longest items while lanes are
+    // left, round 4); lane item q belongs to thread q, a wave's stream holds
     // max-over-its-lanes steps of two matches per lane (a lane past its item's end re-reads its last match, masked in the kernel)
     std::vector<int4> litems;
     std::vector<int2> lwave, lptab(n_pairs);
@@ -1785,17 +1786,43 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
             else lo = mid + 1;
         }
         l_item_len = lo;
+        // Cuts per pair at that length; the lanes this leaves over go, one more cut each, to the pairs whose items are longest (ties: the
+        // earlier pair).  Then the items are ORDERED by length (steps of the pair's longest item, descending; pair; cut), 64 per wave: a
+        // wave runs as many steps as its longest item, and waves w and w + 4 share a SIMD (tools/simd_probe.hip), so long and short waves
+        // pair up.  A pair's items stay adjacent and in cut order (the pair backward sums them in that order).
+        std::vector<int> l_m(n_pairs), l_nch(n_pairs), l_steps(n_pairs);
+        int l_total = 0;
         for (int p = 0; p < n_pairs; ++p) {
-            const int q = pair_ij[p].x * N + pair_ij[p].y, m = key_off[q + 1] - key_off[q];
-            const int nch = pd_lane_items_of(m, l_item_len);
-            lptab[p] = make_int2((int)litems.size(), nch);
+            const int q = pair_ij[p].x * N + pair_ij[p].y;
+            l_m[p] = key_off[q + 1] - key_off[q];
+            l_nch[p] = pd_lane_items_of(l_m[p], l_item_len);
+            l_total += l_nch[p];
+        }
+        const int spare = PD_LANE_MAX_ITEMS - l_total;
+        {
+            std::vector<int> more(n_pairs, 0);
+            for (int p = 0; p < n_pairs; ++p) {
+                if (l_nch[p] == 0 || l_m[p] <= l_nch[p]) continue;
+                more[p] = pd_lane_rank(l_m.data(), l_nch.data(), n_pairs, p, false) < spare ? 1 : 0;
+            }
+            for (int p = 0; p < n_pairs; ++p) l_nch[p] += more[p];
+        }
+        for (int p = 0; p < n_pairs; ++p) l_steps[p] = l_nch[p] ? (pd_lane_items_of(l_m[p], l_nch[p]) + 1) / 2 : 0;
+        litems.assign((size_t)l_total + (size_t)std::max(0, std::min(spare, n_pairs)), make_int4(0, 0, 0, 0));
+        int n_lit = 0;
+        for (int p = 0; p < n_pairs; ++p) {
+            const int q = pair_ij[p].x * N + pair_ij[p].y, m = l_m[p], nch = l_nch[p];
+            const int first = pd_lane_rank(l_steps.data(), l_nch.data(), n_pairs, p, true);
+            lptab[p] = make_int2(first, nch);
             int start = key_off[q];
             for (int c = 0; c < nch; ++c) {
                 const int len = m / nch + (c < m % nch ? 1 : 0);
-                litems.push_back(make_int4(pair_ij[p].x | (pair_ij[p].y << 8), len, p, start));
+                litems[(size_t)first + c] = make_int4(pair_ij[p].x | (pair_ij[p].y << 8), len, p, start);
                 start += len;
             }
+            n_lit += nch;
         }
+        litems.resize(n_lit);
         const int n_lw = ((int)litems.size() + 63) / 64;
         size_t base = 0;
         for (int w = 0; w < n_lw; ++w) {

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(ING_TABLE_THREADS) void ingest_tables_kernel(Ingest
     int *foff = ppos + A.P_cap;                     // [(C_cap + 1)][N + 1]
     int *scratch = foff + (A.C_cap + 1) * (N + 1);   // [16]: 0..8 the block scans, 8..15 the block maximum of (3b)
     int *flags = scratch + 16;
+    int *lnch = flags + 4, *lstp = lnch + NN;      // (3b) cuts per key, then steps of the key's longest lane item
     int *hist = (int *)(S.blob + L.hist);
     int *cnt = (int *)(S.blob + L.cnt);
     if (tid < 4) flags[tid] = 0;
@@ -283,15 +284,35 @@ __global__ __launch_bounds__(ING_TABLE_THREADS) void ingest_tables_kernel(Ingest
             else lo = mid + 1;
         }
         l_len = lo;
-        int lit_base = 0;
-        for (int k0 = 0; k0 < NN; k0 += ING_TABLE_THREADS) {
-            const int key = k0 + tid;
-            const int m = key < NN ? totals[key] : 0;
-            const int nch = pd_lane_items_of(m, l_len);
-            int t_lit;
-            const int first = block_scan_incl(nch, scratch, t_lit) - nch + lit_base;
-            __syncthreads();
+        // cuts per key at that length; the spare lanes go, one more cut each, to the pairs with the longest items; items ordered by the
+        // steps of their pair's longest item (descending; key; cut) -- pd_ggs_set_matches' rule, line by line (pd_lane_rank)
+        int part = 0, tot0;
+        for (int key = tid; key < NN; key += ING_TABLE_THREADS) {
+            const int nch = pd_lane_items_of(totals[key], l_len);
+            lnch[key] = nch;
+            part += nch;
+        }
+        block_scan_incl(part, scratch, tot0);
+        __syncthreads();
+        const int spare = PD_LANE_MAX_ITEMS - tot0;
+        for (int key = tid; key < NN; key += ING_TABLE_THREADS) {
+            const int m = totals[key], nch = lnch[key];
+            lstp[key] = (nch > 0 && m > nch && pd_lane_rank(totals, lnch, NN, key, false) < spare) ? 1 : 0;
+        }
+        __syncthreads();
+        part = 0;
+        for (int key = tid; key < NN; key += ING_TABLE_THREADS) {
+            const int nch = lnch[key] + lstp[key];
+            lnch[key] = nch;
+            lstp[key] = nch ? (pd_lane_items_of(totals[key], nch) + 1) / 2 : 0;
+            part += nch;
+        }
+        block_scan_incl(part, scratch, n_litems);
+        __syncthreads();
+        for (int key = tid; key < NN; key += ING_TABLE_THREADS) {
+            const int m = totals[key], nch = lnch[key];
             if (m > 0) {
+                const int first = pd_lane_rank(lstp, lnch, NN, key, true);
                 const int p = pidx[key], i = key / N, j = key - i * N;
                 lptab[p] = make_int2(first, nch);
                 int start = cnt[key];
@@ -301,9 +322,7 @@ __global__ __launch_bounds__(ING_TABLE_THREADS) void ingest_tables_kernel(Ingest
                     start += len;
                 }
             }
-            lit_base += t_lit;
         }
-        n_litems = lit_base;
         n_lwaves = (n_litems + 63) / 64;
         __syncthreads();                                       // litems written by this workgroup are read below
         if (tid < n_lwaves) {
@@ -445,7 +464,7 @@ __global__ __launch_bounds__(64) void ingest_interleave_kernel(IngestArgs A) {
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 static size_t tables_lds_bytes(int N, int P_cap, int C_cap) {
-    return sizeof(int) * ((size_t)2 * N * N + 2 * (size_t)P_cap + (size_t)(C_cap + 1) * (N + 1) + 16 + 4);
+    return sizeof(int) * ((size_t)4 * N * N + 2 * (size_t)P_cap + (size_t)(C_cap + 1) * (N + 1) + 16 + 4);
 }
 
 extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n_seqs, const int64_t *seq_offsets,

@@ -21,7 +21,9 @@
 #define PD_ITEM_VALS 12           // 9 dL/dF sums + sum(s valid) + n_valid + sum(min(s, max))
 // lane-per-item kernel (pd_ggs_lane_kernel, the throughput shape: one workgroup of 6 waves per sequence with up to 256 VGPRs each -- most
 // of them hold matches for the whole launch --, every LANE owns a work item)
-#define PD_LANE_WAVES 6
+#ifndef PD_LANE_WAVES
+#define PD_LANE_WAVES 8
+#endif
 #define PD_LANE_THREADS (PD_LANE_WAVES * PD_WAVE)
 #define PD_LANE_MAX_ITEMS PD_LANE_THREADS   // one lane item per thread
 #define PD_LANE_MAX_FRAMES 24               // 16 threads per frame in the per-frame sums (= PD_GGS_FAST_FRAMES: the fast serial phases)
@@ -132,6 +134,20 @@ struct PdGgsPlan {
 
 // lane items of one frame pair with m matches at lane-item length len: ceil(m / len) items of balanced size (host and device builders)
 __host__ __device__ inline int pd_lane_items_of(int m, int len) { return (m + len - 1) / len; }
+// Ordering of the frame pairs of a sequence by item length (host and device builders of the lane tables; n <= 576 keys, quadratic on purpose:
+// the same few lines on both sides).  val[q] = matches (by_steps false: compared through the item length ceil(val / nch)) or steps of
+// the pair's longest item (by_steps true); nch[q] = its cuts, 0 = no such pair.  Returns, for pair p, by_steps false: the NUMBER OF PAIRS
+// ordered before p (longer items first, ties: lower index); by_steps true: the number of ITEMS of the pairs ordered before p.
+__host__ __device__ inline int pd_lane_rank(const int *val, const int *nch, int n, int p, bool by_steps) {
+    const int vp = by_steps ? val[p] : pd_lane_items_of(val[p], nch[p]);
+    int r = 0;
+    for (int q = 0; q < n; ++q) {
+        if (nch[q] == 0 || q == p) continue;
+        const int vq = by_steps ? val[q] : pd_lane_items_of(val[q], nch[q]);
+        if (vq > vp || (vq == vp && q < p)) r += by_steps ? nch[q] : 1;
+    }
+    return r;
+}
 
 struct PdSeqHost {
     void *blob = nullptr;      // one hipMalloc holding every array of the PdSeqDesc

@@ -220,3 +220,37 @@ def test_engine_picks_the_lane_kernel_where_a_sequence_gets_one_workgroup(seeded
         assert got[(per_pair, "wgs1_lane", 64)][6] == 1
     assert got[(300, "wgs1", B)][4] == 12                          # the staged 12-wave kernel
     eng.close()
+
+
+def test_xcd_local_exchange_equals_the_spread_one(seeded_diffuser):
+    """Round 4: at more than one workgroup per sequence the block -> (sequence, workgroup) map keeps a sequence's workgroups on one XCD
+    and, once the launch-time handshake on XCC_ID has confirmed it, the exchange stores are plain stores through the shared L2
+    (pd_ggs.hip, `xl`).  PD_GGS_CFG_XCHG_SPREAD restores round 3's map + agent-scope stores.  The exchange only transports the items' sums:
+    the poses, iteration counts and statistics must agree bit for bit, for one sequence, for a count that is not a multiple of 8 (padded map)
+    and for k in {3, 24}, over enough iterations that a stale line would show."""
+    B, N = 11, 20
+    eng = _engine(seeded_diffuser, B, N)
+    x0s = []
+    for b in range(B):
+        enc = synth.make_cameras(N, seed=4100 + b)
+        md = synth.make_matches(enc, 224, 224, per_pair=60 + 20 * (b % 3), seed=4100 + b)
+        eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+        x0s.append(synth.perturb_pose(enc, seed=90 + b))
+    x0 = torch.cat(x0s).to(DEV)
+    plan = (C.c_int * 8)()
+    for nb in (1, 5, B):
+        for k in (3, 24):
+            if nb * k > 256:
+                continue
+            outs = []
+            for flags in (0, _lib.PD_GGS_CFG_XCHG_SPREAD):
+                cfg = make_ggs_cfg(synth.GGS_CFG, iter_num=40, wgs_per_seq=k, reserved=flags | _lib.PD_GGS_CFG_NO_LANE_ITEMS)
+                _lib.check(eng.lib.pd_debug_ggs_plan(eng._h, nb, N, C.byref(cfg), plan), "pd_debug_ggs_plan")
+                assert plan[0] == k, list(plan)
+                out, stats = eng.ggs_guide(x0[:nb], 3, cfg)
+                eng.check_async()
+                outs.append((out.clone(), stats.clone()))
+            assert torch.equal(outs[0][0], outs[1][0]), (nb, k)
+            assert torch.equal(outs[0][1], outs[1][1]), (nb, k)
+            assert torch.isfinite(outs[0][0]).all()
+    eng.close()

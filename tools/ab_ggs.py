@@ -23,7 +23,7 @@ def child(lib):
     from posediffusion_amd.engine import PoseEngine, make_ggs_cfg
     from posediffusion_amd.host import denoiser_state
     dev = torch.device("cuda:0")
-    N = 20
+    N = int(os.environ.get("PD_AB_N", "20"))
     diff = synth.make_diffuser(seed=0).to(dev)
     mds = []
     for s in range(4):
