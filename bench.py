@@ -127,6 +127,30 @@ def pmc_traffic(which, eb=None):
         "library hash as this run")
 
 
+def lane_stream_fraction(pair_sizes, lanes=512, resident_steps=12):
+    """Share of the algorithmic match bytes the lane-per-item GGS kernel pulls through the fabric per iteration (reporting only; the rule
+    is pd_ggs_set_matches' in csrc/pd_ggs.hip: the smallest item length that leaves <= `lanes` lane items, one more cut for the pairs with
+    the longest items while lanes are left, items ordered by length, 64 per wave, a wave's stream padded to its longest item; the first
+    `resident_steps` steps (two matches per lane each) of every wave live in registers for the whole launch)."""
+    ms = [m for m in pair_sizes if m > 0]
+    lo, hi = 1, max(ms)
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if sum(-(-m // mid) for m in ms) <= lanes:
+            hi = mid
+        else:
+            lo = mid + 1
+    nch = [-(-m // lo) for m in ms]
+    spare = lanes - sum(nch)
+    order = sorted(range(len(ms)), key=lambda p: (-(-(-ms[p] // nch[p])), p))
+    for p in [p for p in order if ms[p] > nch[p]][:max(spare, 0)]:
+        nch[p] += 1
+    steps = sorted(((-(-ms[p] // nch[p]) + 1) // 2 for p in range(len(ms)) for _ in range(nch[p])), reverse=True)
+    waves = [steps[w] for w in range(0, len(steps), 64)]                   # a wave runs (and streams) as many steps as its longest item
+    streamed = sum(max(t - resident_steps, 0) for t in waves) * 64 * 32     # bytes per iteration and sequence
+    return streamed / (16.0 * sum(ms)), len(steps), waves
+
+
 def stream_ceiling():
     """This box's ceiling for the GGS access pattern: tools/stream_probe (built by __graft_entry__.build()) lets every CU re-read a
     private 912 KB region -- the match stream of one workgroup per sequence.  -> (min, max) GB/s over its 912 KB rows, or None."""
@@ -549,7 +573,7 @@ def main():
     ggs_set_ms = max(evs[0][0].elapsed_time(e1) for _, e1 in evs)
     ggs_set_tflops = depth * ggs_flops / (ggs_set_ms * 1e-3) / 1e12
     match_bytes = float(EB) * M * MATCH_BYTES * 7 * cfg.iter_num             # streamed once per iteration at one workgroup per sequence
-    # (the lane-per-item kernel keeps 12 of a lane item's 75 steps in registers: it streams 84 % of these bytes -- `fabric.streamed_fraction`)
+    # (the lane-per-item kernel keeps 12 steps of every lane item in registers: it streams ~80 % of these bytes -- `fabric.streamed_fraction`)
     ceil_rng, ceil_src = (None, "skipped (--no-stream-probe)") if (args.no_stream_probe or rank != 0) else stream_ceiling()
     ggs_traffic, traffic_src = pmc_traffic("ggs_launch", EB) if (wgs or 24) == 1 else (None, "PMC summary is for one workgroup per sequence")
     k_eff = wgs or 24
@@ -558,9 +582,9 @@ def main():
     lane_kernel = False
     if hasattr(eng.lib, "pd_debug_ggs_plan") and eng.lib.pd_debug_ggs_plan(eng._h, EB, N_FRAMES, _C.byref(cfg), plan8) == 0:
         lane_kernel = bool(plan8[6])
-    kname = ("pd_ggs_lane_kernel<12> (a lane per work item, 12 steps of every item resident in registers, the rest through an LDS ring fed by LDS-DMA)"
+    kname = ("pd_ggs_lane_kernel<12> (a lane per work item: 8 waves, 12 steps of every item resident in registers, the rest through an LDS ring fed by LDS-DMA)"
              if lane_kernel else f"pd_ggs_kernel<5, false, {plan8[4] or 12}> (a wave per work item)")
-    streamed = (1.0 - 12.0 / ((PER_PAIR // 2 + 1) // 2)) if lane_kernel else 1.0
+    streamed, lane_items, lane_wave_steps = lane_stream_fraction([PER_PAIR] * (N_FRAMES * (N_FRAMES - 1) // 2)) if lane_kernel else (1.0, 0, [])
     roofline = {
         "kernel": f"{kname}: one launch = one guided diffusion step = 700 iterations x {EB} sequences, {k_eff} workgroup(s) per sequence",
         "bound": "valu", "bound_detail": "fp32 vector ALU, 157.3 TFLOP/s (SURVEY 8d names the arithmetic roofline for the Sampson kernel; the kernel issues no "
@@ -573,7 +597,7 @@ def main():
         "co_resident": {"launches": depth, "wall_ms": ggs_set_ms, "achieved": ggs_set_tflops, "frac": ggs_set_tflops / FP32_PEAK_TFLOPS,
                         "note": f"the {depth} contexts' launches issued together on their streams, as in the pipe; reproducible from "
                                 "profiles/ with tools/coresident_from_trace.py (union of the kernel's intervals in a rocprofv3 kernel trace)"},
-        "fabric": {"algorithmic_bytes_per_launch": match_bytes, "streamed_fraction": streamed,
+        "fabric": {"algorithmic_bytes_per_launch": match_bytes, "streamed_fraction": streamed, "lane_items_per_sequence": lane_items, "lane_wave_steps": lane_wave_steps,
                    "streamed_bytes_per_launch": match_bytes * streamed,
                    "achieved_GBps_one_launch": match_bytes / (ggs_ms * 1e-3) / 1e9,
                    "streamed_GBps_one_launch": match_bytes * streamed / (ggs_ms * 1e-3) / 1e9,

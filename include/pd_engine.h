@@ -103,13 +103,13 @@ typedef struct pd_ggs_cfg {
                                        * bitwise the same results -- comparison / testing */
 #define PD_GGS_CFG_WAVES8 4           /* pd_ggs_cfg.reserved: keep 8 wavefronts per workgroup where the staged one-workgroup-per-
                                        * sequence shape would run 12 (three per SIMD); bitwise the same results -- comparison */
-#define PD_GGS_CFG_LANE_ITEMS 8       /* pd_ggs_cfg.reserved: run the lane-per-item kernel (one workgroup of 6 wavefronts per sequence,
-                                       * every LANE owns <= l matches of one frame pair, the head of the match table resident in registers
-                                       * and LDS for the whole launch, the rest streamed) whatever the batch size, where its tables exist
-                                       * (<= 48 frames, <= 384 frame pairs).  Without the flag it is picked only when wgs_per_seq == 0, the
-                                       * launch holds more sequences than half the CUs and every sequence stays fully resident (about
-                                       * <= 40 matches per lane item).  Same valid sets and formulas as the wave-per-item kernels, another
-                                       * (fixed) summation order: results agree to rounding (~1e-6), not bit for bit */
+#define PD_GGS_CFG_LANE_ITEMS 8       /* pd_ggs_cfg.reserved: run the lane-per-item kernel (one workgroup of 8 wavefronts per sequence,
+                                       * every LANE owns <= l matches of one frame pair, 12 steps of every lane item resident in registers
+                                       * for the whole launch, the rest streamed through an LDS ring) whatever the batch size, where its tables
+                                       * exist (<= 24 frames, <= 512 frame pairs) and its LDS image fits.  Without the flag it is picked only
+                                       * when wgs_per_seq == 0 and the launch holds more sequences than half the CUs.  Same valid sets and
+                                       * formulas as the wave-per-item kernels, another (fixed) summation order: results agree to rounding
+                                       * (~1e-6), not bit for bit */
 #define PD_GGS_CFG_NO_LANE_ITEMS 16   /* pd_ggs_cfg.reserved: never pick the lane-per-item kernel (comparison / testing) */
 #define PD_GGS_CFG_XCHG_SPREAD 32     /* pd_ggs_cfg.reserved: with several workgroups per sequence, do NOT place a sequence's workgroups on one XCD
                                        * (where the engine would: at most 32 of them per XCD) -- the exchange then goes through write-through

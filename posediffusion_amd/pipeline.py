@@ -162,8 +162,8 @@ class SamplingPipeline:
 
     def make_cfg(self, ggs_cfg: dict, B: int, reserved: int = 0):
         """The GGS configuration of a pass of B sequences: workgroups per sequence from the pipeline shape; where that is ONE the
-        lane-per-item kernel is asked for (PD_GGS_CFG_LANE_ITEMS: 10 - 14 % faster than the wave-per-item kernel there; the engine
-        falls back to the latter where the lane tables do not exist -- more than 24 frames or 384 frame pairs)."""
+        lane-per-item kernel is asked for (PD_GGS_CFG_LANE_ITEMS: 20 - 30 % faster than the wave-per-item kernel there; the engine
+        falls back to the latter where the lane tables do not exist or do not fit -- more than 24 frames or 512 frame pairs)."""
         from . import _lib
         wgs = self.wgs_per_seq(B)
         if wgs == 1 and not (reserved & _lib.PD_GGS_CFG_NO_LANE_ITEMS):

@@ -333,3 +333,24 @@ def test_free_running_fixtures_are_self_consistent(golden, fname):
         assert shape == (20, 3, 224, 224) and cond_start == 10
         key = g["s0_i12"][:, 0] * 20 + g["s0_i12"][:, 1]
         assert len(key) == 57000 and len(np.unique(key)) == 190 and (np.bincount(key)[np.unique(key)] == 300).all()
+
+
+def test_reference_in_place_timing_fixture_is_self_consistent():
+    """tests/golden/ref_timing.json (python -m oracle.make_ref_timing, where /root/reference is mounted): the reference files executed in
+    place and the oracle port timed by bench.cpu_baseline on ONE host.  bench.py on the GPU box can only report the port
+    (`cpu_baseline.kind == "port"`); this fixture says how the port relates to the reference itself.  Checked here: both legs are there,
+    each leg's sequences/s is the extrapolation bench.py documents (100 denoiser steps + 10 x (400 all + 100 FL + 100 R + 100 T)
+    iterations) of its own per-step figures, and the port is within a factor of two of the reference on every figure."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_timing.json")) as f:
+        d = json.load(f)
+    assert set(d["legs"]) == {"reference", "port"} and d["host_cores"] >= 1
+    for kind, leg in d["legs"].items():
+        g = leg["ggs_ms_per_iteration"]
+        t_seq = 100 * leg["denoiser_ms_per_step"] + 10 * (400 * g["all"] + 100 * g["fl"] + 100 * g["r"] + 100 * g["t"])
+        assert abs(1e3 / t_seq - leg["sequences_per_s"]) <= 0.03 * leg["sequences_per_s"], (kind, t_seq, leg["sequences_per_s"])   # (ms rounded to 0.1)
+        assert ("reference files executed in place" in leg["sample"]) == (kind == "reference")
+        assert leg["threads"] <= d["host_cores"]
+    for k, v in d["port_over_reference"].items():
+        assert 0.5 <= v <= 2.0, (k, v)
