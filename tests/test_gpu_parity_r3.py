@@ -221,7 +221,9 @@ def test_fp16_plane_denoiser_mode_is_fp32_grade(seeded_diffuser, oracle_weights)
     d0 = [rel_err(finals[0][b], p64[b]) for b in range(8)]
     d2 = [rel_err(finals[2][b], p64[b]) for b in range(8)]
     print("free-running 100 steps vs fp64, per sequence: exact", [f"{v:.1e}" for v in d0], " fp16 planes", [f"{v:.1e}" for v in d2])
-    assert float(np.median(d2)) <= max(1.5 * float(np.median(d0)), 1e-5) and max(d2) <= max(3.0 * max(d0), 1e-4)
+    assert float(np.median(d2)) <= max(1.5 * float(np.median(d0)), 1e-5)
+    for b in range(8):                                                  # round 4 (VERDICT round 3, 1 d): sequence by sequence within 2 x the exact mode's
+        assert d2[b] <= max(2.0 * d0[b], 1e-5), (b, d0[b], d2[b])       # (measured: 0.4 .. 1.6 x)
     eng.close()
     # (c) the same network with rescaled encoder weights: the scales are recomputed from the bounds, nothing over- or underflows
     for wscale in (2.0 ** -10, 2.0 ** 6):
