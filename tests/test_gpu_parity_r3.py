@@ -32,13 +32,31 @@ def ragged_matches(enc, h, w, seed, lo=3, hi=400):
     return {"kp1": md["kp1"][keep], "kp2": md["kp2"][keep], "i12": md["i12"][keep], "img_shape": md["img_shape"]}
 
 
+def skewed_matches(enc, h, w, seed, big=6000):
+    """One frame pair with `big` matches, the others with 10 .. 60: the lane kernel's uniform item length is then set by the big pair and
+    most pairs are a single short item (waves of very different lengths, ordered by length)."""
+    rng = np.random.default_rng(seed)
+    md = synth.make_matches(enc, h, w, per_pair=big, seed=seed)
+    key = md["i12"][:, 0] * len(enc) + md["i12"][:, 1]
+    keep = np.zeros(len(key), dtype=bool)
+    for n, k in enumerate(np.unique(key)):
+        idx = np.nonzero(key == k)[0]
+        keep[idx[:(big if n == 3 else int(rng.integers(10, 61)))]] = True
+    return {"kp1": md["kp1"][keep], "kp2": md["kp2"][keep], "i12": md["i12"][keep], "img_shape": md["img_shape"]}
+
+
 CASES = {
     "n20_x300_bench_sequence": (20, lambda e, s: synth.make_matches(e, 224, 224, per_pair=300, seed=s)),          # 2 lane items per pair, streamed tail
     "n6_x40_all_resident": (6, lambda e, s: synth.make_matches(e, 224, 224, per_pair=40, seed=s)),
     "n12_ragged_3_to_400": (12, lambda e, s: ragged_matches(e, 224, 224, s)),                                      # masked steps, empty pairs
     "n20_x7_odd_tiny": (20, lambda e, s: synth.make_matches(e, 224, 224, per_pair=7, seed=s)),                     # half-filled last step everywhere
-    "n24_x64_276_pairs": (24, lambda e, s: synth.make_matches(e, 336, 336, per_pair=64, seed=s)),                  # one lane item per pair, idle lanes
+    "n24_x64_276_pairs": (24, lambda e, s: synth.make_matches(e, 336, 336, per_pair=64, seed=s)),                  # 24 frames x 23 incidences: the tables no
+                                                                                                                   #   longer fit beside the ring -> wave kernels
+    "n20_x96_uneven_cuts": (20, lambda e, s: synth.make_matches(e, 224, 224, per_pair=96, seed=s)),                # round 4: 380 items of 48 + 132 spare lanes ->
+                                                                                                                   #   132 pairs in 3 items of 32, 58 in 2 of 48
+    "n10_skewed_one_pair_6000": (10, lambda e, s: skewed_matches(e, 224, 224, s)),                                 # round 4: waves of very different lengths
 }
+LANE_FALLS_BACK = {"n24_x64_276_pairs"}      # pd_ggs_plan keeps the wave-per-item kernels there (LDS); the comparison is then trivially exact
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
@@ -53,6 +71,11 @@ def test_lane_kernel_vs_wave_kernels_and_oracle(engine, case):
     for b in range(B):
         engine.set_matches(b, mds[b]["kp1"], mds[b]["kp2"], mds[b]["i12"], mds[b]["img_shape"])
     x0 = torch.cat([synth.perturb_pose(encs[b], seed=70 + b) for b in range(B)]).to(DEV)
+    import ctypes as C
+    plan = (C.c_int * 8)()
+    lane_cfg = make_ggs_cfg(reserved=LANE)
+    _lib.check(engine.lib.pd_debug_ggs_plan(engine._h, B, N, C.byref(lane_cfg), plan), "pd_debug_ggs_plan")
+    assert plan[6] == (0 if case in LANE_FALLS_BACK else 1), (case, list(plan))      # which kernel family the "lane" leg really runs
     res = {}
     for tag, flags in (("wave", NOLANE), ("lane", LANE)):
         loss, grad = engine.ggs_loss_grad(x0, cfg=make_ggs_cfg(reserved=flags))
