@@ -33,7 +33,7 @@ def test_ggs_kernel_variants_keep_their_register_budget(tmp_path):
         twelve = "ELi12EE" in name
         if twelve:
             assert r["VGPRs"] <= 168 and r["Occupancy"] == 3, (name, r)
-            assert r["VGPRs Spill"] <= 4 and r["ScratchSize"] <= 16, (name, r)      # (round 4: one register, touched before the iteration loop only)
+            assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)       # (round 4: built with -fno-slp-vectorize, nothing spills)
         else:
             assert r["VGPRs"] <= 256 and r["Occupancy"] >= 2, (name, r)
             assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
