@@ -222,15 +222,9 @@ int pd_ggs_loss_grad(pd_engine *eng, const float *x, int B, int N, int update_R,
  *        (LayerNorm output <= sqrt(d); a Linear fed by it <= sqrt(d) ||w|| + |b|): no overflow, no underflow, and results as
  *        close to the fp64 product as the exact-fp32 instruction's (tests/test_gpu_parity_r3.py).  Same batches as 1. */
 #define PD_OPT_DENOISER_SPLIT 2
-/*   PD_OPT_DENOISER_PERSISTENT  0 (default): the multi-launch path (43 dependent launches per evaluation, exact-fp32 matrix instruction).
- *        1: a denoiser evaluation of <= 32 token rows (and <= 16 sequences) is ONE persistent launch of 64 workgroups whose 43 phases
- *        are separated by grid barriers (csrc/pd_den_small.inc); its encoder GEMMs use the fp16-plane arithmetic of
- *        PD_OPT_DENOISER_SPLIT = 2.  Correct (tests/test_gpu_parity_r3.py) but MEASURED SLOWER on MI355X -- 495 us against 205 us per
- *        evaluation at B = 1, N = 20: a bare grid barrier costs 1.3 - 2.0 us, but every workgroup has to pull the whole activation
- *        matrix through the L2-bypassing coherent path each phase (~4 us per GEMM phase, profiles/round3_small_persistent.txt), which a
- *        launch boundary gets for free.  Kept as a measured alternative.  The workgroups spin at the barriers: every one of them must
- *        be able to become resident (fewer than ~4 such launches concurrently on the device). */
-#define PD_OPT_DENOISER_PERSISTENT 3
+/*   (option 3, PD_OPT_DENOISER_PERSISTENT of round 3 -- a denoiser evaluation of <= 32 token rows as ONE persistent launch -- is no longer
+ *    built: correct but 2.4 x slower than the 43-launch path, profiles/round3_small_persistent.txt; source parked under tools/parked/.
+ *    Value 0 is accepted, 1 returns PD_ERR_UNSUPPORTED.) */
 int pd_engine_set_option(pd_engine *eng, int option, int value);
 
 /* GaussianDiffusion.sample / p_sample_loop (gaussian_diffuser.py:284-306).
@@ -344,13 +338,11 @@ int pd_time_kernel(pd_engine *eng, int what, int B, int N, const pd_ggs_cfg *cfg
 
 /* Synchronises the device and reports (PD_ERR_STATE) what the kernels flagged asynchronously since the last check: a
  * bounded spin of the GGS cross-workgroup exchange that gave up (bit 0), an out-of-range frame index (bit 1) or violated
- * pd_match_hints (bit 2) met by pd_ggs_set_matches_csr_async, a grid barrier of the opt-in persistent small-batch denoiser launch that
- * gave up (bit 3).  Clears the word.  PD_OK otherwise. */
+ * pd_match_hints (bit 2) met by pd_ggs_set_matches_csr_async.  Clears the word.  PD_OK otherwise. */
 int pd_check_async_error(pd_engine *eng);
 
 /* Debug aid: switch the GGS kernel's in-kernel phase cycle counters on/off and (out6 != NULL)
  * read them: {P1 pair F, P2 matches, exchange, P3 backward, P4 update, iterations} of workgroup 0. */
-int pd_debug_small_clocks(pd_engine *eng, unsigned *out56);   /* 100 MHz clock at the start and after each grid barrier of the last persistent small-batch denoiser launch */
 int pd_debug_ggs_prof(pd_engine *eng, int enable, long long *out6);   /* enable = 1 + wave index to record; out6 holds 16 values */
 /* The launch shape pd_ggs_guide / pd_sample would use for (B, N, cfg) with the matches uploaded now:
  * out8 = {workgroups per sequence, item slots per workgroup, LDS bytes, two-hop kernel, waves per workgroup, LDS-DMA staging pieces,

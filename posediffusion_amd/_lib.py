@@ -54,7 +54,6 @@ class pd_vit_weights(C.Structure):
 PD_GGS_CFG_FORCE_ONE_HOP = 1
 PD_GGS_CFG_NO_LDS_STAGING = 2
 PD_GGS_CFG_WAVES8 = 4
-PD_OPT_DENOISER_PERSISTENT = 3
 PD_WEIGHTS_PRED_X0 = 1
 PD_GGS_CFG_LANE_ITEMS = 8       # lane-per-item kernel (the throughput shape) whatever the batch size
 PD_GGS_CFG_NO_LANE_ITEMS = 16   # never the lane-per-item kernel
@@ -104,7 +103,6 @@ SIGNATURES = {
     "pd_pose_to_camera": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "pd_time_kernel": (_i, [_vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _i, C.POINTER(C.c_float), _vp]),
     "pd_check_async_error": (_i, [_vp]),
-    "pd_debug_small_clocks": (_i, [_vp, C.POINTER(C.c_uint)]),
     "pd_debug_ggs_prof": (_i, [_vp, _i, C.POINTER(C.c_longlong)]),
     "pd_debug_ggs_plan": (_i, [_vp, _i, _i, C.POINTER(pd_ggs_cfg), C.POINTER(C.c_int)]),
     "pd_debug_mfma_f16_subnormal": (_i, [C.POINTER(C.c_float), _vp]),

@@ -671,8 +671,6 @@ __global__ __launch_bounds__(256) void pd_tail_kernel(HeadArgs g) {
     }
 }
 
-#include "pd_den_small.inc"
-
 // --------------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------------
@@ -810,7 +808,7 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(dev_alloc(d, &d->ff, rows * DFF));
     PD_TRY(dev_alloc(d, &d->hid, rows * HID));
     if (rows >= PD_STREAM_MIN_ROWS) PD_TRY(dev_alloc(d, &d->hn, rows * DM));
-    // _first's input rows (materialised by pd_embed_rows_kernel on the streamed path, by the first phase of pd_den_small_kernel) and the
+    // _first's input rows (materialised by pd_embed_rows_kernel on the streamed path, formerly also by the parked persistent kernel) and the
     // row-major _first / _last.0 the two paths pack from
     PD_TRY(dev_alloc(d, &d->emb, rows * KFIRST_PAD));
     PD_TRY(dev_alloc(d, &d->first_wf, (size_t)DM * KFIRST_PAD));
@@ -933,54 +931,6 @@ static int pd_denoiser_build_split_h(pd_engine *eng) {
     d->split_h_ready = true;
     return PD_OK;
 }
-// the persistent small-batch kernel's operands (pd_den_small.inc): the encoder weights as fp16 planes in its tile order (same scales as
-// the streamed fp16-plane kernels), `_first` / `_last.0` in fp32 tile order, the activation rows of `_first`, the barrier words
-int pd_denoiser_build_small(pd_engine *eng) {
-    PdDenoiserDev *d = eng->den;
-    if (d->small_ready) return PD_OK;
-    PD_TRY(pd_denoiser_build_scales(eng));
-    auto pack_h = [&](unsigned **dst, const float *Wf, int Nout, int K, int ew) -> int {
-        float *p = nullptr;
-        PD_TRY(dev_alloc(d, &p, (size_t)Nout * K));
-        *dst = (unsigned *)p;
-        const size_t total = (size_t)(Nout / 16) * 4 * (K / 128) * 64;
-        hipLaunchKernelGGL(pd_small_pack_h_kernel, dim3(512), dim3(256), 0, 0, Wf, K, ldexpf(1.0f, ew), total, (uint4 *)p);
-        PD_HIP_CHECK(hipGetLastError());
-        return PD_OK;
-    };
-    auto pack_f = [&](float **dst, const float *Wf, int Nout, int K) -> int {
-        PD_TRY(dev_alloc(d, dst, (size_t)Nout * K));
-        const size_t total = (size_t)(Nout / 16) * 4 * (K / 64) * 64;
-        hipLaunchKernelGGL(pd_small_pack_f_kernel, dim3(512), dim3(256), 0, 0, Wf, K, total, (float4 *)*dst);
-        PD_HIP_CHECK(hipGetLastError());
-        return PD_OK;
-    };
-    for (int l = 0; l < d->num_layers; ++l) {
-        PdLayerDev &L = d->layers[l];
-        PD_TRY(pack_h(&L.qkv_wk, L.qkv_wf, 3 * DM, DM, L.e_wqkv));
-        PD_TRY(pack_h(&L.out_wk, L.out_wf, DM, DM, L.e_wo));
-        PD_TRY(pack_h(&L.ff1_wk, L.ff1_wf, DFF, DM, L.e_w1));
-        PD_TRY(pack_h(&L.ff2_wk, L.ff2_wf, DM, DFF, L.e_w2));
-    }
-    PD_TRY(pack_f(&d->first_wk, d->first_wf, DM, KFIRST_PAD));
-    PD_TRY(pack_f(&d->last0_wk, d->last0_wf, HID, DM));
-    float *bar = nullptr;
-    PD_TRY(dev_alloc(d, &bar, 64));
-    PD_HIP_CHECK(hipMemset(bar, 0, 64 * sizeof(float)));
-    d->small_bar = (unsigned *)bar;
-    PD_HIP_CHECK(hipDeviceSynchronize());
-    d->small_ready = true;
-    return PD_OK;
-}
-
-// debug: the 100 MHz clock at the start and after every grid barrier of the last pd_den_small_kernel launch
-extern "C" int pd_debug_small_clocks(pd_engine *eng, unsigned *out56) {
-    if (!eng || !eng->den || !eng->den->small_bar || !out56) return PD_ERR_INVALID_ARG;
-    PD_HIP_CHECK(hipDeviceSynchronize());
-    PD_HIP_CHECK(hipMemcpy(out56, eng->den->small_bar + 8, 56 * sizeof(unsigned), hipMemcpyDeviceToHost));
-    return PD_OK;
-}
-
 bool pd_denoiser_has_streamed_path(const pd_engine *eng) { return eng->den && eng->den->hn; }
 
 int pd_denoiser_build_split(pd_engine *eng, int mode) {
@@ -1055,41 +1005,6 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     memset(&g, 0, sizeof(g));
     g.M = M;
     const bool streamed = M >= PD_STREAM_MIN_ROWS && d->hn;
-    if (M <= PD_SMALL_ROWS && 4 * B <= PD_SMALL_WGS && d->small_ready && eng->den_persistent) {
-        // the whole evaluation as ONE persistent launch (pd_den_small.inc)
-        PdSmallArgs a;
-        memset(&a, 0, sizeof(a));
-        a.x = x; a.z = z; a.temb = d->t_table + (size_t)t * 128;
-        a.M = M; a.N = N; a.num_layers = d->num_layers;
-        {
-            static const int dbg = pd_dev_knob("PD_SMALL_DBG", 0);
-            a.dbg = dbg;
-        }
-        a.emb = d->emb; a.h = d->h; a.qkv = d->qkv; a.ctx = d->ctx; a.ff = d->ff; a.hid = d->hid;
-        a.first_w = (const float4 *)d->first_wk; a.first_b = d->first_b;
-        a.last0_w = (const float4 *)d->last0_wk; a.last0_b = d->last0_b;
-        a.bar = d->small_bar;
-        a.err = eng->d_err;
-        HeadArgs &ha = a.head;
-        ha.hid = d->hid; ha.lnw = d->last_ln_w; ha.lnb = d->last_ln_b;
-        ha.w3 = d->last3_w; ha.b3 = d->last3_b; ha.x = x; ha.noise = noise;
-        ha.eps_out = eps_out; ha.mean_out = mean_out; ha.x0_out = x0_out; ha.xnext_out = x_next_out;
-        ha.c_recip = eng->c_recip[t]; ha.c_recipm1 = eng->c_recipm1[t]; ha.coef1 = eng->coef1[t]; ha.coef2 = eng->coef2[t];
-        ha.sigma = expf(0.5f * eng->logvar[t]);
-        ha.M = M;
-        ha.pred_x0 = eng->pred_x0;
-        for (int l = 0; l < d->num_layers; ++l) {
-            const PdLayerDev &S = d->layers[l];
-            PdSmallLayer &L = a.L[l];
-            L.qkv_w = (const uint4 *)S.qkv_wk; L.out_w = (const uint4 *)S.out_wk; L.ff1_w = (const uint4 *)S.ff1_wk; L.ff2_w = (const uint4 *)S.ff2_wk;
-            L.qkv_b = S.qkv_b; L.out_b = S.out_b; L.ff1_b = S.ff1_b; L.ff2_b = S.ff2_b;
-            L.qkv_cs = S.qkv_cs; L.out_cs = S.out_cs; L.ff1_cs = S.ff1_cs; L.ff2_cs = S.ff2_cs;
-            L.ctx_scale = S.ctx_scale; L.ff_scale = S.ff_scale;
-        }
-        hipLaunchKernelGGL(pd_den_small_kernel, dim3(PD_SMALL_WGS), dim3(256), 0, s, a);
-        PD_HIP_CHECK(hipGetLastError());
-        return PD_OK;
-    }
     if (streamed) {
         hipLaunchKernelGGL(pd_embed_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, z, d->t_table + (size_t)t * 128, N, M, d->emb);
         pd_gemm_dma<0>(d->emb, KFIRST_PAD, d->first_wf, KFIRST_PAD, d->first_b, d->h, M, DM, s);

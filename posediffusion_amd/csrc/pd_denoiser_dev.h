@@ -39,7 +39,6 @@ struct PdLayerDev {          // [0] = 32-wide-tile packing, [1] = 16-wide-tile p
     unsigned *qkv_wh, *out_wh, *ff1_wh, *ff2_wh;
     float qkv_cs, out_cs, ff1_cs, ff2_cs, ctx_scale, ff_scale;
     int e_wqkv, e_wo, e_w1, e_w2;                  // the weights' scale exponents (pd_denoiser_build_scales)
-    unsigned *qkv_wk, *out_wk, *ff1_wk, *ff2_wk;   // the same fp16 planes in the persistent small-batch kernel's tile order (pd_den_small.inc)
 };
 
 struct PdDenoiserDev {
@@ -55,9 +54,6 @@ struct PdDenoiserDev {
     bool split_ready = false;          // the fast mode's split weights exist
     bool split_h_ready = false;        // the fp16-plane mode's weights exist
     bool scales_ready = false;         // the fp16-plane scales exist (pd_denoiser_build_scales)
-    bool small_ready = false;          // the persistent small-batch kernel's weights and barrier words exist
-    float *first_wk = nullptr, *last0_wk = nullptr;   // `_first` / `_last.0` in that kernel's fp32 tile order
-    unsigned *small_bar = nullptr;     // its grid-barrier words {arrivals, arrivals at launch}
     std::vector<void *> allocs;
 };
 

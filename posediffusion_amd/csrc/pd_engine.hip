@@ -350,7 +350,7 @@ extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *nois
         key.cond_start = has_ggs ? cond_start_step : 0;
         key.has_ggs = has_ggs;
         key.phase = phase;
-        key.den_split = eng->den_split | (eng->den_persistent << 8);      // both options change the captured launches
+        key.den_split = eng->den_split;      // the option changes the captured launches
         if (has_ggs) {
             key.cfg = *ggs;
             // the GGS nodes bake the match-derived launch shape in: a re-upload with another item count must not
@@ -436,18 +436,11 @@ extern "C" int pd_engine_set_option(pd_engine *eng, int option, int value) {
         }
         eng->den_split = value;
         break;
-    case PD_OPT_DENOISER_PERSISTENT:
-        if (value != 0 && value != 1) {
-            pd_set_error("pd_engine_set_option: PD_OPT_DENOISER_PERSISTENT takes 0 or 1 (got %d)", value);
-            return PD_ERR_INVALID_ARG;
-        }
-        if (value) {
-            PD_HIP_CHECK(hipSetDevice(eng->device));
-            int rc = pd_denoiser_build_small(eng);
-            if (rc) return rc;
-        }
-        eng->den_persistent = value;
-        break;
+    case 3:      // (PD_OPT_DENOISER_PERSISTENT of round 3: the persistent small-batch kernel was measured 2.4 x slower and parked, tools/parked/)
+        if (value == 0) break;
+        pd_set_error("pd_engine_set_option: option 3 (the persistent small-batch denoiser launch of round 3) is no longer built: it measured "
+                     "2.4 x slower than the multi-launch path (profiles/round3_small_persistent.txt; source parked under tools/parked/)");
+        return PD_ERR_UNSUPPORTED;
     default:
         pd_set_error("pd_engine_set_option: unknown option %d", option);
         return PD_ERR_INVALID_ARG;
@@ -503,11 +496,10 @@ extern "C" int pd_check_async_error(pd_engine *eng) {
     PD_HIP_CHECK(hipDeviceSynchronize());
     PD_HIP_CHECK(hipMemcpy(&v, eng->d_err, sizeof(v), hipMemcpyDeviceToHost));
     if (v) {
-        pd_set_error("asynchronous error (flag=%u):%s%s%s%s", v,
+        pd_set_error("asynchronous error (flag=%u):%s%s%s", v,
                      (v & 1u) ? " a cross-workgroup exchange spin timed out (co-resident workgroups lost?);" : "",
                      (v & 2u) ? " pd_ggs_set_matches_csr_async met a frame index outside [0, n_frames);" : "",
-                     (v & 4u) ? " pd_ggs_set_matches_csr_async: pd_match_hints violated (more pairs / matches per pair than declared): the slot was emptied;" : "",
-                     (v & 8u) ? " a grid barrier of the persistent small-batch denoiser launch timed out (PD_OPT_DENOISER_PERSISTENT: its workgroups could not all become resident);" : "");
+                     (v & 4u) ? " pd_ggs_set_matches_csr_async: pd_match_hints violated (more pairs / matches per pair than declared): the slot was emptied;" : "");
         (void)hipMemset(eng->d_err, 0, sizeof(v));
         return PD_ERR_STATE;
     }

@@ -178,7 +178,6 @@ struct pd_engine {
     size_t xchg_granules = 0;            // per (sequence, slot)
     unsigned int *d_err = nullptr;       // [0] async error word; [2..] debug phase counters
     int ggs_prof_on = 0;
-    int den_persistent = 0;          // PD_OPT_DENOISER_PERSISTENT: <= 32 token rows run as one persistent launch (pd_den_small.inc); measured slower, off by default
     int den_split = 0;               // PD_OPT_DENOISER_SPLIT: encoder GEMMs of the large-batch path: 0 exact fp32, 1 bf16 planes, 2 fp16 planes (default there)
     int gemm_wide_min_tiles = 200;   // launch_gemm: 32-wide tiles when there are at least this many of them
     float *d_stats_scratch = nullptr;
@@ -213,8 +212,7 @@ struct pd_engine {
 int pd_denoiser_create(pd_engine *eng, const pd_weights *w);
 void pd_denoiser_destroy(pd_engine *eng);
 bool pd_denoiser_has_streamed_path(const pd_engine *eng);   // created with max_B x max_N >= PD_STREAM_MIN_ROWS token rows
-int pd_denoiser_build_split(pd_engine *eng, int mode);
-int pd_denoiser_build_small(pd_engine *eng);               // the persistent small-batch kernel's weights and barrier words   // 1: bf16 planes (fast mode), 2: fp16 planes with static scales
+int pd_denoiser_build_split(pd_engine *eng, int mode);    // 1: bf16 planes (fast mode), 2: fp16 planes with static scales
 // eps_out / mean_out / x_next_out may each be null. noise null => 0.
 int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, int B, int N, float *eps_out,
                        float *mean_out, float *x0_out, const float *noise, float *x_next_out, hipStream_t s);

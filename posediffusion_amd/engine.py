@@ -268,12 +268,6 @@ class PoseEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pd_engine_set_option(self._h, _lib.PD_OPT_DENOISER_SPLIT, int(mode)), "pd_engine_set_option")
 
-    def set_persistent_denoiser(self, on: bool):
-        """<= 32 token rows: one persistent launch per denoiser evaluation instead of the default multi-launch exact-fp32 path
-        (include/pd_engine.h PD_OPT_DENOISER_PERSISTENT; measured slower on MI355X, kept as an alternative)."""
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.pd_engine_set_option(self._h, _lib.PD_OPT_DENOISER_PERSISTENT, int(bool(on))), "pd_engine_set_option")
-
     def pose_to_camera(self, enc: torch.Tensor):
         enc = self._f32(enc).reshape(-1, 9)
         n = enc.shape[0]

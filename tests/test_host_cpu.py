@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     import re
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pd_engine.h")).read()
     for name in ("PD_GGS_CFG_FORCE_ONE_HOP", "PD_GGS_CFG_NO_LDS_STAGING", "PD_GGS_CFG_WAVES8", "PD_GGS_CFG_LANE_ITEMS",
-                 "PD_GGS_CFG_NO_LANE_ITEMS", "PD_OPT_DENOISER_SPLIT", "PD_OPT_DENOISER_PERSISTENT", "PD_WEIGHTS_PRED_X0"):
+                 "PD_GGS_CFG_NO_LANE_ITEMS", "PD_OPT_DENOISER_SPLIT", "PD_WEIGHTS_PRED_X0"):
         m = re.search(r"#define\s+" + name + r"\s+(\d+)", hdr)
         assert m and int(m.group(1)) == getattr(_lib, name), name
 
