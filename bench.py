@@ -720,6 +720,8 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "sequences/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
                                    "kind": "port", "sample": "skipped (measured on rank 0 at N=1 only)"}
         sys.stdout.flush()
+        import ctypes as _Cf
+        _Cf.CDLL(None).fflush(None)           # RCCL's banner sits in libc's stdout buffer: out with it while descriptor 1 is still stderr
         os.dup2(result_fd, 1)
         print(json.dumps(out), flush=True)
     if world > 1 or dry:
