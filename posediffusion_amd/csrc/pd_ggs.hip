@@ -1988,7 +1988,7 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
         if (ok) {
             // rows of the pair backward at the fixed per-frame stride of the fast serial phases (pd_ggs_p3b.inc)
             const int pinc_rows = std::max(2 * std::min(PD_LANE_MAX_ITEMS, std::max(pairs, 1)), N * (((deg + 3) & ~3) + 1));
-            const size_t lds = lane_lds_bytes(pinc_rows);        // tables + the six waves' rings (PD_LANE_RING steps of 2 KiB each)
+            const size_t lds = lane_lds_bytes(pinc_rows);        // tables + the waves' rings (PD_LANE_RING steps of 2 KiB each)
             if (lds <= 160 * 1024) {
                 out->lane = 1;
                 out->lane_rl = std::max(0, std::min(PD_LANE_RING, steps - PD_LANE_RV));   // (reported: steps of a lane item that live in the ring)

@@ -19,7 +19,7 @@
 #define PD_GGS_MAX_STAGES 5
 #define PD_ITEM_MAX_MATCHES 512   // one work item = <= 512 matches of one frame pair (8 per lane)
 #define PD_ITEM_VALS 12           // 9 dL/dF sums + sum(s valid) + n_valid + sum(min(s, max))
-// lane-per-item kernel (pd_ggs_lane_kernel, the throughput shape: one workgroup of 6 waves per sequence with up to 256 VGPRs each -- most
+// lane-per-item kernel (pd_ggs_lane_kernel, the throughput shape: one workgroup of 8 waves per sequence with up to 256 VGPRs each -- most
 // of them hold matches for the whole launch --, every LANE owns a work item)
 #ifndef PD_LANE_WAVES
 #define PD_LANE_WAVES 8
