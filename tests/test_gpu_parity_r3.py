@@ -104,12 +104,18 @@ def test_lane_kernel_vs_wave_kernels_and_oracle(engine, case):
         assert steps == int(l[3][b, 1]) and rel_err(l[2][b:b + 1], ref5) < step_tol
 
 
-def test_lane_kernel_device_built_tables_are_the_host_built_ones(engine):
+@pytest.mark.parametrize("shape", ["n20_ragged_100_to_300", "n20_x96_uneven_cuts", "n10_skewed_one_pair_6000", "n12_ragged_3_to_400"])
+def test_lane_kernel_device_built_tables_are_the_host_built_ones(engine, shape):
     """pd_ggs_set_matches_csr_async builds the lane-per-item tables on the device (ingest_tables_kernel step 3b +
-    ingest_lane_stream_kernel): bitwise the results of the host-built tables, ragged counts included."""
-    N, B = 20, 4
+    ingest_lane_stream_kernel): bitwise the results of the host-built tables -- ragged counts, the extra cuts of the spare lanes and
+    the ordering of the items by length (round 4: pd_lane_rank on both sides) included."""
+    N = int(shape.split("_")[0][1:])
+    B = 4
     encs = [synth.make_cameras(N, seed=600 + b) for b in range(B)]
-    mds = [ragged_matches(encs[b], 224, 224, 950 + b, lo=100, hi=300) for b in range(B)]
+    if shape == "n20_ragged_100_to_300":
+        mds = [ragged_matches(encs[b], 224, 224, 950 + b, lo=100, hi=300) for b in range(B)]
+    else:
+        mds = [CASES[shape][1](encs[b], 950 + b) for b in range(B)]
     x0 = torch.cat([synth.perturb_pose(encs[b], seed=80 + b) for b in range(B)]).to(DEV)
     cfg = make_ggs_cfg(synth.GGS_CFG, iter_num=10, reserved=LANE)
     for b in range(B):
@@ -120,7 +126,8 @@ def test_lane_kernel_device_built_tables_are_the_host_built_ones(engine):
     kp1 = torch.from_numpy(np.concatenate([m["kp1"] for m in mds])).to(DEV)
     kp2 = torch.from_numpy(np.concatenate([m["kp2"] for m in mds])).to(DEV)
     i12 = torch.from_numpy(np.concatenate([m["i12"] for m in mds])).to(DEV)
-    engine.set_matches_async(0, kp1, kp2, i12, off, mds[0]["img_shape"], max_pairs=190, max_matches_per_pair=300, one_order=True)
+    per_pair = max(int(np.unique(m["i12"][:, 0] * N + m["i12"][:, 1], return_counts=True)[1].max()) for m in mds)
+    engine.set_matches_async(0, kp1, kp2, i12, off, mds[0]["img_shape"], max_pairs=N * (N - 1) // 2, max_matches_per_pair=per_pair, one_order=True)
     g_dev, st_dev = engine.ggs_guide(x0, 3, cfg)
     engine.check_async()
     assert torch.equal(g_host, g_dev) and torch.equal(st_host, st_dev)
