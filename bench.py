@@ -452,17 +452,31 @@ def main():
     cold = None
     if EB >= STEP_SEQS:
         zc, nc = z[:STEP_SEQS].contiguous(), noise[:, :STEP_SEQS].contiguous()
-        lat = []
-        for rep in range(3):    # the first call captures this shape's graph
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            with torch.cuda.stream(pipe.u_stream):
-                engines[0].sample(zc, nc, COND_START, cfg, use_graph=use_graph, want_process=False)
-            torch.cuda.synchronize()
-            lat.append((time.perf_counter() - t1) * 1e3)
-        cold = {"sequences": STEP_SEQS, "latency_ms": min(lat[1:]), "sequences_per_s": STEP_SEQS / (min(lat[1:]) * 1e-3),
-                "note": "one batch of 64 sequences, nothing else in flight (64 of the 256 CUs carry a GGS workgroup): the latency of a single "
-                        "configs[3] batch; `value` is the steady-state rate with " + str(EB * depth) + " sequences in flight"}
+        # the launch shape a caller with ONE batch in flight gets (SamplingPipeline.wgs_per_seq with one context: CUs // sequences = 4
+        # workgroups per sequence on the wave-per-item kernels, 8.3 ms per GGS launch against 13.0 ms for one lane-kernel workgroup per
+        # sequence on a quarter of the chip); the streaming shape's figure is reported beside it
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        cfg_cold = type(cfg).from_buffer_copy(cfg)
+        cfg_cold.wgs_per_seq = max(1, cus // STEP_SEQS) if not args.ggs_wgs else args.ggs_wgs
+        cfg_cold.reserved = 0
+        lat_by = {}
+        for tag, c in (("alone", cfg_cold), ("streaming_shape", cfg)):
+            lat = []
+            for rep in range(3):    # the first call captures this shape's graph
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                with torch.cuda.stream(pipe.u_stream):
+                    engines[0].sample(zc, nc, COND_START, c, use_graph=use_graph, want_process=False)
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t1) * 1e3)
+            lat_by[tag] = min(lat[1:])
+        cold = {"sequences": STEP_SEQS, "latency_ms": lat_by["alone"], "sequences_per_s": STEP_SEQS / (lat_by["alone"] * 1e-3),
+                "ggs_workgroups_per_sequence": int(cfg_cold.wgs_per_seq),
+                "latency_ms_with_the_streaming_launch_shape": lat_by["streaming_shape"],
+                "note": "one batch of 64 sequences, nothing else in flight: the latency of a single configs[3] batch with the launch shape a caller "
+                        f"with one batch in flight gets ({int(cfg_cold.wgs_per_seq)} GGS workgroups per sequence fill the chip); with the streaming shape "
+                        "(one workgroup per sequence: 64 of the 256 CUs busy) beside it; `value` is the steady-state rate with "
+                        + str(EB * depth) + " sequences in flight"}
 
     # ---- exact mode (reported next to `value`): the same pipe with the encoder GEMMs on the exact-fp32 matrix instruction
     # (PD_OPT_DENOISER_SPLIT = 0) instead of the default fp16-plane kernels -- what rounds 1 and 2 reported as `value`
