@@ -254,3 +254,24 @@ def test_xcd_local_exchange_equals_the_spread_one(seeded_diffuser):
             assert torch.equal(outs[0][1], outs[1][1]), (nb, k)
             assert torch.isfinite(outs[0][0]).all()
     eng.close()
+
+
+def test_free_running_ggs_on_full_size_on_the_lane_kernel(engine, golden):
+    """SURVEY 8c's free-running criterion at the benchmark's real size (fixture guided_free_full: BASELINE configs[2] exactly -- N = 20,
+    57 000 matches, 100 steps, the last 10 guided x 700 = 7 000 iterations -- through the UNMODIFIED reference in fp32 and the fp64
+    oracle) for the kernel the throughput shape runs since round 4: pd_ggs_lane_kernel (8 waves, uneven cuts ordered by length, LDS
+    ring).  tests/test_gpu_parity_r2.py holds the wave-per-item kernels to the same bounds on the same fixture.  Per seed: pose deviation
+    from fp64 <= 2 x the reference-fp32's own (5.8e-4); final mean Sampson gap to fp64 <= max(1 %, 2 x the reference's own 27 %);
+    hipGraph replay == eager, all 7 000 iterations run (_free_running_case asserts both)."""
+    from test_gpu_parity_r2 import _free_running_case
+    g = golden["guided_free_full"]
+    cfg = dict(synth.GGS_CFG, wgs_per_seq=1, reserved=_lib.PD_GGS_CFG_LANE_ITEMS)
+    plan = (C.c_int * 8)()
+    dev, ref_dev, gap, ref_gap = _free_running_case(engine, g, 0, cfg)
+    c = make_ggs_cfg(cfg)
+    _lib.check(engine.lib.pd_debug_ggs_plan(engine._h, 1, 20, C.byref(c), plan), "pd_debug_ggs_plan")
+    assert plan[6] == 1, list(plan)                                       # it WAS the lane kernel
+    print(f"free-running GGS-on, configs[2] full size, lane-per-item kernel: engine vs fp64 {dev:.3e} (reference fp32 {ref_dev:.3e}); "
+          f"final mean Sampson gap to fp64: engine {gap:.3%}, reference fp32 {ref_gap:.3%}")
+    assert dev <= 2.0 * ref_dev, (dev, ref_dev)
+    assert gap <= max(0.01, 2.0 * ref_gap), (gap, ref_gap)
