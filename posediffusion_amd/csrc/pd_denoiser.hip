@@ -23,6 +23,9 @@
 #include "pd_denoiser_dev.h"
 #include "pd_gemm_stream.h"
 #include "pd_gemm_split.h"
+#ifndef PD_STRIP_K64
+#define PD_STRIP_K64 true      // the strip GEMMs of the fp16-plane mode: A chunks of 64 k per barrier (pd_gemm_split.h)
+#endif
 
 #include <algorithm>
 #include <math.h>
@@ -1027,17 +1030,17 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
             // bitwise the same results (tools/split3_probe.hip).  PD_DEN_STRIP = bit mask {QKV, out, FF1, FF2} (development A / B)
             static const int strip = pd_dev_knob("PD_DEN_STRIP", 15);
             hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 2>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 512.0f);
-            if (strip & 1) pd_gemm_strip<0, 2, true>((const unsigned *)d->hn, DM, L.qkv_wh, DM, L.qkv_b, d->qkv, M, 3 * DM, s, L.qkv_cs);
+            if (strip & 1) pd_gemm_strip<0, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->hn, DM, L.qkv_wh, DM, L.qkv_b, d->qkv, M, 3 * DM, s, L.qkv_cs);
             else pd_gemm_split<0, 1, 2, true>((const unsigned *)d->hn, DM, L.qkv_wh, DM, L.qkv_b, d->qkv, M, 3 * DM, s, L.qkv_cs);
             static const int attn_mma = pd_dev_knob("PD_DEN_ATTN_MMA", 1);     // development A / B
             if (N <= 32 && attn_mma) hipLaunchKernelGGL(pd_attn_mma_kernel<2>, dim3(B * NH), dim3(256), attn_mma_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
             else hipLaunchKernelGGL(pd_attn_seq_kernel<2>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
-            if (strip & 2) pd_gemm_strip<2, 2, true>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
+            if (strip & 2) pd_gemm_strip<2, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
             else pd_gemm_split<2, 1, 1, true>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
             hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 2>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 512.0f);
-            if (strip & 4) pd_gemm_strip<4, 2, true>((const unsigned *)d->hn, DM, L.ff1_wh, DM, L.ff1_b, d->ff, M, DFF, s, L.ff1_cs, L.ff_scale);
+            if (strip & 4) pd_gemm_strip<4, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->hn, DM, L.ff1_wh, DM, L.ff1_b, d->ff, M, DFF, s, L.ff1_cs, L.ff_scale);
             else pd_gemm_split<4, 1, 2, true>((const unsigned *)d->hn, DM, L.ff1_wh, DM, L.ff1_b, d->ff, M, DFF, s, L.ff1_cs, L.ff_scale);
-            if (strip & 8) pd_gemm_strip<2, 2, true>((const unsigned *)d->ff, DFF, L.ff2_wh, DFF, L.ff2_b, d->h, M, DM, s, L.ff2_cs);
+            if (strip & 8) pd_gemm_strip<2, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->ff, DFF, L.ff2_wh, DFF, L.ff2_b, d->h, M, DM, s, L.ff2_cs);
             else pd_gemm_split<2, 1, 1, true>((const unsigned *)d->ff, DFF, L.ff2_wh, DFF, L.ff2_b, d->h, M, DM, s, L.ff2_cs);
             continue;
         }

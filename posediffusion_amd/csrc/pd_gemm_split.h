@@ -243,7 +243,10 @@ __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
 // accumulated in the same order as in vit_gemm_split_kernel: bitwise the same C.
 // BARE (probe only): 1 no weight-fragment loads in the loop, 2 no DMA in the loop, 3 neither, 4 neither and no barrier / wait,
 // 5 everything but the MFMAs, 6 everything but the fragment reads + un-zip (the first chunk's are reused)
-template <int EPI, int RT, bool F16, int CT = 1, int BARE = 0>
+// K64 (round 4): A chunks of 64 k per barrier (two 32-k blocks of the same LDS layout), the weight fragments of a block requested half a chunk
+// ahead into the registers the previous block just freed: half the barriers, every load has >= half a chunk of matrix work to hide behind,
+// the same accumulation order (bitwise the same C).  K must be a multiple of 64.
+template <int EPI, int RT, bool F16, int CT = 1, int BARE = 0, bool K64 = false>
 __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
     constexpr int KC = 32, TM = 32 * RT, TN = 128 * CT, GROUP = 2048 / TM, CHA = TM * KC;     // words of A per chunk
     static_assert((RT == 2 || RT == 4) && (CT == 1 || CT == 2), "pieces of 8 rows, RT per wave and chunk");
@@ -287,6 +290,87 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
         if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     };
+    f32x16 acc[RT][CT];
+    if constexpr (K64) {
+        static_assert(CT == 1 && BARE == 0, "the 64-k form exists for one column tile per wave");
+        typedef unsigned wv4 __attribute__((ext_vector_type(4)));          // a weight fragment as a native vector (an inline-asm register operand)
+#pragma unroll
+        for (int mi = 0; mi < RT; ++mi)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][0][i] = 0.0f;
+        auto mmaw = [](const uint4 &a, const wv4 &b, const f32x16 &c) {
+            if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+        };
+        // weights of 32-k block b (b = 2 * chunk + half): 4 fragments {k step 0 | 1} x {hi | lo}, 1 KiB apart -- hand-issued like the DMA, so that
+        // every vector-memory operation of the loop is counted by the s_waitcnt below and by nothing else (the compiler's own waits assume
+        // it sees every load in flight)
+#define PD_STRIP_WLOAD(w0, w1, w2, w3, b)                                                                                            \
+    do {                                                                                                                             \
+        const uint4 *wp_ = wq + (size_t)(b) * 256;                                                                                   \
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"                           \
+                     "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"                    \
+                     : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(wp_) : "memory");                                            \
+    } while (0)
+#define PD_STRIP_WAIT(n, w0, w1, w2, w3) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : : "memory")
+        auto stage64 = [&](int c, int buf) {            // both 32-k blocks of chunk c: 2 RT pieces per wave
+            const unsigned da = __builtin_amdgcn_readfirstlane(lds_a + buf * 2 * CHA * 4);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float *ab = (const float *)(g.A + (2 * c + h) * KC);
+#pragma unroll
+                for (int j = 0; j < RT; ++j) pd_dma_piece(ab, oa[j], da + h * CHA * 4 + j * 1024);
+            }
+        };
+        // one 32-k block: fragment reads + un-zip + 6 RT MFMAs; w0 / w1 = k step 0 {hi | lo}, w2 / w3 = k step 1
+        auto block = [&](const unsigned *a, const wv4 &w0, const wv4 &w1, const wv4 &w2, const wv4 &w3) {
+            uint4 ah[RT], al[RT];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+#pragma unroll
+                for (int mi = 0; mi < RT; ++mi) {
+                    const uint4 p = *(const uint4 *)(a + mi * 32 * KC + 4 * ((4 * st + 2 * hi) ^ ((l31 >> 1) & 7)));
+                    const uint4 q = *(const uint4 *)(a + mi * 32 * KC + 4 * ((4 * st + 2 * hi + 1) ^ ((l31 >> 1) & 7)));
+                    ah[mi] = make_uint4(__builtin_amdgcn_perm(p.y, p.x, 0x05040100u), __builtin_amdgcn_perm(p.w, p.z, 0x05040100u),
+                                        __builtin_amdgcn_perm(q.y, q.x, 0x05040100u), __builtin_amdgcn_perm(q.w, q.z, 0x05040100u));
+                    al[mi] = make_uint4(__builtin_amdgcn_perm(p.y, p.x, 0x07060302u), __builtin_amdgcn_perm(p.w, p.z, 0x07060302u),
+                                        __builtin_amdgcn_perm(q.y, q.x, 0x07060302u), __builtin_amdgcn_perm(q.w, q.z, 0x07060302u));
+                }
+                const wv4 &wh = st ? w2 : w0, &wl = st ? w3 : w1;
+#pragma unroll
+                for (int mi = 0; mi < RT; ++mi) acc[mi][0] = mmaw(al[mi], wh, acc[mi][0]);
+#pragma unroll
+                for (int mi = 0; mi < RT; ++mi) acc[mi][0] = mmaw(ah[mi], wl, acc[mi][0]);
+#pragma unroll
+                for (int mi = 0; mi < RT; ++mi) acc[mi][0] = mmaw(ah[mi], wh, acc[mi][0]);
+            }
+        };
+        wv4 a0, a1, a2, a3, b0, b1, b2, b3;               // weight fragments of the chunk's first / second 32-k block
+        const int nk64 = g.K / 64;
+        stage64(0, 0);
+        PD_STRIP_WLOAD(a0, a1, a2, a3, 0);
+        PD_STRIP_WLOAD(b0, b1, b2, b3, 1);
+        PD_STRIP_WAIT(0, a0, a1, a2, a3);
+        PD_STRIP_WAIT(0, b0, b1, b2, b3);
+        __syncthreads();
+        for (int c = 0; c < nk64; ++c) {
+            const int cn = min(c + 1, nk64 - 1);                 // the chunk after the last is the last again (never used)
+            const unsigned *a = strip_lds + (c & 1) * 2 * CHA + l31 * KC;
+            stage64(cn, (c + 1) & 1);                            // in flight, oldest first: the second block's weights [4, from the previous turn], this DMA [2 RT]
+            block(a, a0, a1, a2, a3);
+            PD_STRIP_WLOAD(a0, a1, a2, a3, 2 * cn);              //   ... + the next chunk's first block [4]
+            // the second block's weights must have landed; the DMA and the loads just issued may still be in flight (in-order returns)
+            if constexpr (RT == 2) PD_STRIP_WAIT(8, b0, b1, b2, b3);
+            else PD_STRIP_WAIT(12, b0, b1, b2, b3);
+            block(a + CHA, b0, b1, b2, b3);
+            PD_STRIP_WLOAD(b0, b1, b2, b3, 2 * cn + 1);          //   ... + the next chunk's second block [4]
+            PD_STRIP_WAIT(4, a0, a1, a2, a3);                    // the next chunk's rows and first block have landed; the second block may still fly
+            __syncthreads();
+        }
+        PD_STRIP_WAIT(0, b0, b1, b2, b3);
+#undef PD_STRIP_WLOAD
+#undef PD_STRIP_WAIT
+    } else {
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -296,7 +380,6 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    f32x16 acc[RT][CT];
 #pragma unroll
     for (int mi = 0; mi < RT; ++mi)
 #pragma unroll
@@ -361,6 +444,7 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
             __syncthreads();
         }
     }
+    }
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int col = n0 + (CT * wave + c) * 32 + l31;
@@ -390,12 +474,13 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
         }
     }
 }
-template <int EPI, int RT, bool F16, int CT = 1>
+template <int EPI, int RT, bool F16, int CT = 1, bool K64 = false>
 static inline void pd_gemm_strip(const unsigned *A, int lda, const unsigned *W, int K, const float *bias, void *C, int M, int Nout, hipStream_t s,
                                  float c_scale = 1.0f, float out_scale = 1.0f) {
     VitSplitArgs g{A, W, bias, C, M, Nout, K, lda, c_scale, out_scale};
     constexpr int TM = 32 * RT;
-    hipLaunchKernelGGL((pd_gemm_strip_kernel<EPI, RT, F16, CT>), dim3(((M + TM - 1) / TM) * (Nout / (128 * CT))), dim3(256), (size_t)2 * TM * 32 * sizeof(unsigned), s, g);
+    hipLaunchKernelGGL((pd_gemm_strip_kernel<EPI, RT, F16, CT, 0, K64>), dim3(((M + TM - 1) / TM) * (Nout / (128 * CT))), dim3(256),
+                       (size_t)(K64 ? 4 : 2) * TM * 32 * sizeof(unsigned), s, g);
 }
 
 static constexpr size_t pd_split_lds(int WM) { return (size_t)2 * 64 * WM * PD_STREAM_LR * sizeof(float); }
