@@ -5,8 +5,12 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 The reference's ``MultiScaleImageFeatureExtractor`` (models/image_feature_extractor.py:28-87) wraps a DINO ViT-S/16 it
 fetches with ``torch.hub.load("facebookresearch/dino:main", "dino_vits16")`` (:40-42).  That model's code
 (facebookresearch/dino, vision_transformer.py) is a third-party dependency that is NOT under /root/reference and cannot
-be fetched here, so ``DinoViT`` below RESTATES its published algorithm (parity against the DINO source is unpinned;
-weights are random-init, the trained checkpoint is not available offline).  The multi-scale wrapper itself -- ImageNet
+be fetched here, so ``DinoViT`` below RESTATES its published algorithm (parity against the DINO SOURCE is unpinned;
+weights are random-init, the trained checkpoint is not available offline).  What CAN be pinned offline is pinned
+(round 4): ``to_hf_vit`` loads the same weights into HuggingFace ``transformers.ViTModel`` -- an independent
+implementation of the same published architecture, the class the Hub's ``facebook/dino-vits16`` conversion of this very
+checkpoint instantiates -- and tests/test_oracle_golden.py compares the two in fp64 (2e-15 at 224 x 224; at other input
+sizes with the position grid resampled by DINO's rule, which HF resamples by another one).  The multi-scale wrapper itself -- ImageNet
 normalisation, bilinear rescaling by 1, 1/2, 1/3, averaging of the CLS features (:57-87) -- is the reference's own code:
 ``multiscale_features`` restates it and ``ref_stubs.load_reference_extractor`` runs the reference file in place around
 this ViT to pin that restatement.
@@ -142,3 +146,39 @@ def multiscale_features(net: nn.Module, image_rgb: torch.Tensor, scale_factors=(
         f = net(inp)
         feats = f if feats is None else feats + f
     return feats / len(scale_factors)                                                   # :82-83
+
+
+def to_hf_vit(net: "DinoViT", img_size: int = 224):
+    """The same weights in HuggingFace ``transformers.ViTModel`` (ViT-S/16 configuration, LayerNorm eps 1e-6 as in DINO's
+    ``partial(nn.LayerNorm, eps=1e-6)``, no pooler): DINO's fused ``attn.qkv`` rows split into q / k / v projections, every
+    other tensor renamed.  ``img_size`` other than 224: the position table is resampled by ``DinoViT.interpolate_pos_encoding``
+    first (HF's own resampling passes the target SIZE to ``F.interpolate``; DINO passes a scale factor of (size + 0.1) / 14,
+    which samples the bicubic kernel at slightly different points -- the reference inherits DINO's).  Test infrastructure."""
+    from transformers import ViTConfig, ViTModel
+    sd = net.state_dict()
+    dim, depth = sd["cls_token"].shape[-1], len(net.blocks)
+    heads = net.blocks[0].attn.num_heads
+    cfg = ViTConfig(hidden_size=dim, num_hidden_layers=depth, num_attention_heads=heads, intermediate_size=sd["blocks.0.mlp.fc1.weight"].shape[0],
+                    hidden_act="gelu", layer_norm_eps=1e-6, image_size=img_size, patch_size=net.patch_embed.patch_size, num_channels=3,
+                    qkv_bias=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    hf = ViTModel(cfg, add_pooling_layer=False).to(sd["cls_token"].dtype).eval()
+    pos = sd["pos_embed"]
+    if img_size != 224:
+        g = img_size // net.patch_embed.patch_size
+        with torch.no_grad():
+            pos = net.interpolate_pos_encoding(torch.zeros(1, g * g + 1, dim, dtype=pos.dtype), img_size, img_size)
+    out = {"embeddings.cls_token": sd["cls_token"], "embeddings.position_embeddings": pos,
+           "embeddings.patch_embeddings.projection.weight": sd["patch_embed.proj.weight"],
+           "embeddings.patch_embeddings.projection.bias": sd["patch_embed.proj.bias"],
+           "layernorm.weight": sd["norm.weight"], "layernorm.bias": sd["norm.bias"]}
+    for i in range(depth):
+        w, b = sd[f"blocks.{i}.attn.qkv.weight"], sd[f"blocks.{i}.attn.qkv.bias"]
+        for j, n in enumerate("qkv"):
+            out[f"layers.{i}.attention.{n}_proj.weight"] = w[dim * j:dim * (j + 1)]
+            out[f"layers.{i}.attention.{n}_proj.bias"] = b[dim * j:dim * (j + 1)]
+        for hf_name, dino_name in (("attention.o_proj", "attn.proj"), ("layernorm_before", "norm1"), ("layernorm_after", "norm2"),
+                                   ("mlp.fc1", "mlp.fc1"), ("mlp.fc2", "mlp.fc2")):
+            for t in ("weight", "bias"):
+                out[f"layers.{i}.{hf_name}.{t}"] = sd[f"blocks.{i}.{dino_name}.{t}"]
+    hf.load_state_dict(out, strict=True)
+    return hf

@@ -310,6 +310,31 @@ def test_vit_oracle_loads_dino_state_dict_names():
     assert sum(v.numel() for v in VO.make_vit(0).state_dict().values()) == 21665664      # ViT-S/16
 
 
+@pytest.mark.parametrize("size", [224, 112, 74])
+def test_vit_oracle_against_an_independent_implementation(size):
+    """Row N1's backbone: DINO's source (facebookresearch/dino vision_transformer.py) is neither under /root/reference nor
+    fetchable, so the restatement oracle/vit_oracle.DinoViT is pinned against the one independent implementation of the same
+    published model that IS installed here: HuggingFace transformers.ViTModel, the class the Hub's facebook/dino-vits16
+    conversion of the checkpoint instantiates.  Same weights (fused qkv split into q / k / v), fp64, CLS token after the
+    final LayerNorm: patch embedding, position table, 12 pre-norm blocks, 6-head attention, exact-erf GELU, eps 1e-6.
+    112 and 74 are the 1/2 and 1/3 scales of the multi-scale wrapper (image_feature_extractor.py:71-87): there the position
+    grid is resampled by DINO's published rule (scale factor (size + 0.1) / 14), restated in DinoViT and handed to HF as its
+    table -- that one rule and the trained weights are what stays unpinned offline."""
+    transformers = pytest.importorskip("transformers")
+    from oracle import vit_oracle as VO
+    if not hasattr(transformers, "ViTModel"):
+        pytest.skip("transformers without ViTModel")
+    net = VO.make_vit(seed=3, dtype=torch.float64)
+    hf = VO.to_hf_vit(net, img_size=size)
+    x = torch.randn(2, 3, size, size, dtype=torch.float64, generator=torch.Generator().manual_seed(size))
+    with torch.no_grad():
+        ours = net(x)
+        theirs = hf(pixel_values=x).last_hidden_state[:, 0]
+    assert tuple(ours.shape) == (2, 384)
+    rel = ((ours - theirs).abs().max() / theirs.abs().max()).item()
+    assert rel < 1e-12, rel
+
+
 @pytest.mark.parametrize("fname", ["guided_free", "guided_free_full"])
 def test_free_running_fixtures_are_self_consistent(golden, fname):
     """The free-running GGS-on fixtures (reference fp32 run + fp64 oracle run, oracle/make_golden.py make_guided_free):
