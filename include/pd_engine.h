@@ -265,6 +265,21 @@ int pd_sample_phase(pd_engine *eng, const float *z, const float *noise, int B, i
 int pd_pose_to_camera(pd_engine *eng, const float *enc, int n_cameras, float *R_out, float *T_out,
                       float *focal_out, void *stream);
 
+/* ---- rows D2 / D3 as stand-alone operators (stateless, all pointers DEVICE fp32) --------------------
+ * The engine fuses both embeddings into the denoiser (a [T,128] table built at creation; the harmonic columns formed while
+ * _first's rows are staged).  These two entry points run the same device code for a caller that uses the reference's
+ * util/embedding.py modules piecewise (dropin/util/embedding.py binds them). */
+
+/* TimeStepEmbedding.forward (util/embedding.py:28-37, dim = 256): out[n,128] = linear.2(SiLU(linear.0([cos(t f) | sin(t f)]))),
+ * f_i = exp(-ln(10000) i / 128); w0 [128,256], b0 [128], w2 [128,128], b2 [128] = the module's linear.0 / linear.2 tensors,
+ * timesteps[n] already converted to float (the reference's `timesteps[:, None].float()`). */
+int pd_time_embedding(const float *w0, const float *b0, const float *w2, const float *b2, const float *timesteps, int n,
+                      float *out, void *stream);
+
+/* PoseEmbedding.forward (util/embedding.py:52-54) = pytorch3d HarmonicEmbedding(n_harmonic_functions = 10, append_input = True):
+ * x[rows,dim] -> out[rows, 21 dim] = [sin(x_d 2^k) | sin(x_d 2^k + pi/2) | x], d-major, k = 0..9 (189 columns for dim = 9). */
+int pd_pose_embedding(const float *x, long long rows, int dim, float *out, void *stream);
+
 /* ---- evaluation metrics (stateless, all pointers DEVICE fp32) ------- */
 
 /* camera_to_rel_deg (util/metric.py:14-47): R_*[B*N,9] row-major 3x3, T_*[B*N,3] in the PyTorch3D convention

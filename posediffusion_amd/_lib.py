@@ -89,6 +89,8 @@ SIGNATURES = {
     "pd_ggs_optimize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp]),
     "pd_ggs_loss_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp]),
     "pd_engine_set_option": (_i, [_vp, _i, _i]),
+    "pd_time_embedding": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "pd_pose_embedding": (_i, [_vp, C.c_longlong, _i, _vp, _vp]),
     "pd_metrics_rel_pose_errors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "pd_metrics_summary": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pd_metrics_are": (_i, [_vp, _vp, _i, _vp, _vp]),

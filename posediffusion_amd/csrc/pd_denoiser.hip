@@ -114,15 +114,13 @@ __global__ void pd_first_rowmajor_kernel(const float *__restrict__ W, float *__r
     Wf[idx] = k < KFIRST ? W[(size_t)n * KFIRST + k] : 0.0f;
 }
 
-// time-step embedding table (util/embedding.py:28-37): one block per step t
-__global__ void pd_time_table_kernel(const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w2,
-                                     const float *__restrict__ b2, float *__restrict__ table) {
-    __shared__ float emb[256];
-    __shared__ float hid[128];
-    const int t = blockIdx.x, i = threadIdx.x;   // 128 threads
+// time-step embedding (util/embedding.py:28-37) of one timestep value t: 128 threads, thread i owns output i
+__device__ __forceinline__ float pd_time_embed_one(float t, const float *__restrict__ w0, const float *__restrict__ b0,
+                                                   const float *__restrict__ w2, const float *__restrict__ b2, float *emb, float *hid) {
+    const int i = threadIdx.x;
     // freqs = exp(-ln(10000) * arange(128, fp32) / 128)  (embedding.py:24-26), args = t * freqs
     const float freq = expf((-9.210340371976184f * (float)i) / 128.0f);
-    const float arg = (float)t * freq;
+    const float arg = t * freq;
     emb[i] = cosf(arg);
     emb[128 + i] = sinf(arg);
     __syncthreads();
@@ -132,7 +130,41 @@ __global__ void pd_time_table_kernel(const float *__restrict__ w0, const float *
     __syncthreads();
     float o = b2[i];
     for (int k = 0; k < 128; ++k) o = fmaf(hid[k], w2[i * 128 + k], o);
-    table[t * 128 + i] = o;
+    return o;
+}
+// the engine's table: one block per step t = 0 .. T-1
+__global__ void pd_time_table_kernel(const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w2,
+                                     const float *__restrict__ b2, float *__restrict__ table) {
+    __shared__ float emb[256];
+    __shared__ float hid[128];
+    table[blockIdx.x * 128 + threadIdx.x] = pd_time_embed_one((float)blockIdx.x, w0, b0, w2, b2, emb, hid);
+}
+// TimeStepEmbedding.forward for arbitrary timesteps (pd_time_embedding): the same arithmetic, one block per entry of tvals
+__global__ void pd_time_embed_kernel(const float *__restrict__ tvals, const float *__restrict__ w0, const float *__restrict__ b0,
+                                     const float *__restrict__ w2, const float *__restrict__ b2, float *__restrict__ out) {
+    __shared__ float emb[256];
+    __shared__ float hid[128];
+    out[(size_t)blockIdx.x * 128 + threadIdx.x] = pd_time_embed_one(tvals[blockIdx.x], w0, b0, w2, b2, emb, hid);
+}
+// PoseEmbedding.forward = pytorch3d HarmonicEmbedding(n = 10, append_input = True) of rows [rows, dim] (pd_pose_embedding):
+// out [rows, 21 dim] = [sin(x_d 2^k) (d-major, k = 0..9) | sin(x_d 2^k + pi / 2) | x] -- the expressions of pd_embed_rows_kernel and
+// of the AMODE 2 staging, in the reference's own column order
+__global__ void pd_harmonic_rows_kernel(const float *__restrict__ x, long long rows, int dim, float *__restrict__ out) {
+    const int per = 21 * dim;
+    const long long total = rows * per;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long row = idx / per;
+        const int c = (int)(idx - row * per);
+        float v;
+        if (c >= 20 * dim) {
+            v = x[row * dim + (c - 20 * dim)];
+        } else {
+            const int s = c / (10 * dim), rem = c - s * 10 * dim, d = rem / 10, kk = rem - d * 10;
+            const float a = x[row * dim + d] * (float)(1 << kk);
+            v = sinf(s ? a + 1.5707963267948966f : a);
+        }
+        out[idx] = v;
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1096,6 +1128,31 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     ha.M = M;
     ha.pred_x0 = eng->pred_x0;
     hipLaunchKernelGGL(pd_tail_kernel, dim3((M + 3) / 4), dim3(256), 0, s, ha);
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}
+
+// ---- rows D2 / D3 as stand-alone operators (the reference's util/embedding.py modules called piecewise) -------------------------------
+extern "C" int pd_time_embedding(const float *w0, const float *b0, const float *w2, const float *b2, const float *timesteps, int n,
+                                 float *out, void *stream) {
+    if (!w0 || !b0 || !w2 || !b2 || !timesteps || !out || n < 0) {
+        pd_set_error("pd_time_embedding: invalid arguments (n=%d)", n);
+        return PD_ERR_INVALID_ARG;
+    }
+    if (n == 0) return PD_OK;
+    hipLaunchKernelGGL(pd_time_embed_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, timesteps, w0, b0, w2, b2, out);
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}
+extern "C" int pd_pose_embedding(const float *x, long long rows, int dim, float *out, void *stream) {
+    if (!x || !out || rows < 0 || dim < 1 || dim > 4096) {
+        pd_set_error("pd_pose_embedding: invalid arguments (rows=%lld dim=%d)", rows, dim);
+        return PD_ERR_INVALID_ARG;
+    }
+    if (rows == 0) return PD_OK;
+    const long long total = rows * 21 * dim;
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(pd_harmonic_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, rows, dim, out);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }

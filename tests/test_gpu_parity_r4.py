@@ -275,3 +275,34 @@ def test_free_running_ggs_on_full_size_on_the_lane_kernel(engine, golden):
           f"final mean Sampson gap to fp64: engine {gap:.3%}, reference fp32 {ref_gap:.3%}")
     assert dev <= 2.0 * ref_dev, (dev, ref_dev)
     assert gap <= max(0.01, 2.0 * ref_gap), (gap, ref_gap)
+
+
+def test_embedding_modules_called_piecewise(seeded_diffuser, oracle_weights):
+    """Rows D2 / D3 outside the fused denoiser: the drop-in `util.embedding.TimeStepEmbedding` / `PoseEmbedding` modules called the way
+    a user of the reference's modules may call them (util/embedding.py:28-37, :52-54) run pd_time_embedding / pd_pose_embedding --
+    the device code the engine's time table and `_first` staging use.  Time embedding against the fp64 oracle; the harmonic embedding
+    against the oracle in fp32 (the reference itself forms `x 2^k + pi/2` in fp32, so fp64 is not the reference there) at pose-sized and
+    at large arguments, 9-d poses in [B, N, 9] and another width."""
+    dev = torch.device(DEV)
+    model = seeded_diffuser.to(dev).model
+    sd64 = {k: v.double() for k, v in oracle_weights.items()}
+    for t in (torch.tensor([0, 1, 7, 42, 99], device=dev), torch.arange(100, device=dev), torch.tensor([3], device=dev, dtype=torch.int32)):
+        out = model.time_embed(t)
+        ref = O.timestep_embedding(t.cpu().long(), sd64)
+        assert out.shape == (t.shape[0], 128) and out.dtype == torch.float32
+        assert rel_err(out, ref) < 2e-6, rel_err(out, ref)
+    assert model.time_embed(torch.zeros(0, dtype=torch.long, device=dev)).shape == (0, 128)
+    g = torch.Generator().manual_seed(11)
+    for shape, scale in (((2, 5, 9), 1.0), ((3, 20, 9), 30.0), ((7, 4), 1.0), ((1, 9), 1e-3)):
+        x = (scale * torch.randn(*shape, generator=g)).float()
+        out = model.pose_embed(x.to(dev))
+        ref = O.harmonic_embedding(x)
+        assert out.shape == ref.shape == (*shape[:-1], 21 * shape[-1])
+        assert (out.cpu() - ref).abs().max().item() < 2e-6, (shape, scale, (out.cpu() - ref).abs().max().item())
+        assert torch.equal(out[..., -shape[-1]:].cpu(), x)                       # append_input: the input itself, bit for bit
+    assert model.pose_embed.out_dim == 189 and model.time_embed.out_dim == 128
+    with pytest.raises(RuntimeError, match="only on an AMD GPU"):
+        model.pose_embed(torch.zeros(1, 9))
+    lib = _lib.load()
+    assert lib.pd_pose_embedding(None, 1, 9, None, None) == -1 and "pd_pose_embedding" in _lib.last_error()      # PD_ERR_INVALID_ARG
+    assert lib.pd_time_embedding(None, None, None, None, None, 1, None, None) == -1

@@ -98,6 +98,17 @@ def test_dropin_registry_and_error_conventions():
     from posediffusion_amd.compat import instantiate, AttrDict
     cfg = {"_target_": "models.GaussianDiffusion", "beta_schedule": "custom"}
     assert isinstance(instantiate(AttrDict(cfg), _recursive_=False), models.GaussianDiffusion)
+    # the reference's embedding modules called piecewise run on the HIP path only (util/embedding.py; no CPU fallback)
+    from util.embedding import PoseEmbedding, TimeStepEmbedding
+    te, pe = TimeStepEmbedding(), PoseEmbedding(target_dim=9)
+    assert te.out_dim == 128 and pe.out_dim == 189
+    assert set(te.state_dict()) == {"linear.0.weight", "linear.0.bias", "linear.2.weight", "linear.2.bias"} and not pe.state_dict()
+    with pytest.raises(RuntimeError, match="only on an AMD GPU"):
+        te(torch.zeros(2, dtype=torch.long))
+    with pytest.raises(RuntimeError, match="only on an AMD GPU"):
+        pe(torch.zeros(1, 2, 9))
+    with pytest.raises(ValueError):
+        PoseEmbedding(target_dim=9, n_harmonic_functions=6)
 
 
 def test_cond_fn_recognition():
