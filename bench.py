@@ -305,6 +305,10 @@ def main():
     ap.add_argument("--ggs-wgs", type=int, default=0, help="override GGS workgroups per sequence (0 = from the pipeline shape)")
     ap.add_argument("--pipeline-depth", type=int, default=3,
                     help="engine contexts / HIP streams per GPU (engine passes in flight); 1 = serial")
+    ap.add_argument("--unguided-streams", type=int, default=0,
+                    help="0 = every context's stream runs whole passes; u > 0 = the two-stage pipe of SamplingPipeline: u streams run the unguided "
+                         "halves, --ggs-slots streams the guided halves (their GGS launches then never meet another slot's)")
+    ap.add_argument("--ggs-slots", type=int, default=0, help="streams that run guided halves (0 = one per context)")
     ap.add_argument("--trace", action="store_true", help="print the pipeline timeline (per-pass phase times) to stderr")
     ap.add_argument("--no-per-config", action="store_true", help="skip the per-BASELINE-config measurements")
     ap.add_argument("--no-fast-mode", "--no-exact-mode", dest="no_fast_mode", action="store_true",
@@ -360,7 +364,8 @@ def main():
     tables = {k: v for k, v in diff.named_buffers(recurse=False)}
     eng = get_engine(diff.model, diff, EB, N_FRAMES)
     engines = [eng] + [PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=EB, max_N=N_FRAMES) for _ in range(depth - 1)]
-    pipe = SamplingPipeline(engines, depth, dev, unguided_streams=0, trace=args.trace)
+    slots = depth if args.ggs_slots <= 0 else min(args.ggs_slots, depth)
+    pipe = SamplingPipeline(engines, slots, dev, unguided_streams=max(0, args.unguided_streams), trace=args.trace)
     # one resident engine batch per context (different sequences: seeds offset per context and rank)
     want_fresh = not args.no_fresh_inputs
     inputs = [make_batch_inputs(engines[j], diff, EB, dev, seed0=100_000 * rank + j * EB, keep_host=want_fresh) for j in range(depth)]
@@ -703,7 +708,7 @@ def main():
             "sequences_per_step": step_total, "sequences_per_gpu_per_step": B_step, "steps_per_engine_pass": group, "sequences_per_engine_pass": EB,
             "engine_passes_in_timed_region": len(pend), "sequences_in_flight_per_gpu": EB * depth, "frames": N_FRAMES,
             "matches_per_sequence": M, "diffusion_steps": 100, "ggs_iterations_per_sequence_run": float(iters.min().item()),
-            "hip_graph": use_graph, "pipeline_depth": depth, "ggs_workgroups_per_sequence": k_eff,
+            "hip_graph": use_graph, "pipeline_depth": depth, "guided_slots": slots, "unguided_streams": max(0, args.unguided_streams), "ggs_workgroups_per_sequence": k_eff,
             "engine_pass_latency_ms_unpipelined": pass_latency_ms,
             "parallelism": f"dp{world} (independent sequences, one final all_gather)", "outputs_finite": finite,
         },

@@ -1135,21 +1135,21 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
 // ---- rows D2 / D3 as stand-alone operators (the reference's util/embedding.py modules called piecewise) -------------------------------
 extern "C" int pd_time_embedding(const float *w0, const float *b0, const float *w2, const float *b2, const float *timesteps, int n,
                                  float *out, void *stream) {
+    if (n == 0) return PD_OK;                       // an empty batch: nothing to read or write (the pointers may be NULL)
     if (!w0 || !b0 || !w2 || !b2 || !timesteps || !out || n < 0) {
         pd_set_error("pd_time_embedding: invalid arguments (n=%d)", n);
         return PD_ERR_INVALID_ARG;
     }
-    if (n == 0) return PD_OK;
     hipLaunchKernelGGL(pd_time_embed_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, timesteps, w0, b0, w2, b2, out);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }
 extern "C" int pd_pose_embedding(const float *x, long long rows, int dim, float *out, void *stream) {
+    if (rows == 0 && dim >= 1) return PD_OK;        // an empty batch (the pointers may be NULL)
     if (!x || !out || rows < 0 || dim < 1 || dim > 4096) {
         pd_set_error("pd_pose_embedding: invalid arguments (rows=%lld dim=%d)", rows, dim);
         return PD_ERR_INVALID_ARG;
     }
-    if (rows == 0) return PD_OK;
     const long long total = rows * 21 * dim;
     const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     hipLaunchKernelGGL(pd_harmonic_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, rows, dim, out);

@@ -290,7 +290,7 @@ def test_embedding_modules_called_piecewise(seeded_diffuser, oracle_weights):
         out = model.time_embed(t)
         ref = O.timestep_embedding(t.cpu().long(), sd64)
         assert out.shape == (t.shape[0], 128) and out.dtype == torch.float32
-        assert rel_err(out, ref) < 2e-6, rel_err(out, ref)
+        assert rel_err(out, ref) < 5e-6, rel_err(out, ref)          # an fp32 fmaf chain of 256 + 128 terms (6e-7 expected)
     assert model.time_embed(torch.zeros(0, dtype=torch.long, device=dev)).shape == (0, 128)
     g = torch.Generator().manual_seed(11)
     for shape, scale in (((2, 5, 9), 1.0), ((3, 20, 9), 30.0), ((7, 4), 1.0), ((1, 9), 1e-3)):
@@ -300,6 +300,7 @@ def test_embedding_modules_called_piecewise(seeded_diffuser, oracle_weights):
         assert out.shape == ref.shape == (*shape[:-1], 21 * shape[-1])
         assert (out.cpu() - ref).abs().max().item() < 2e-6, (shape, scale, (out.cpu() - ref).abs().max().item())
         assert torch.equal(out[..., -shape[-1]:].cpu(), x)                       # append_input: the input itself, bit for bit
+    assert model.pose_embed(torch.zeros(0, 9, device=dev)).shape == (0, 189)
     assert model.pose_embed.out_dim == 189 and model.time_embed.out_dim == 128
     with pytest.raises(RuntimeError, match="only on an AMD GPU"):
         model.pose_embed(torch.zeros(1, 9))

@@ -16,9 +16,38 @@ flops = float(sys.argv[2]) if len(sys.argv) > 2 else 256 * 57000 * 100.0 * 700  
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
 kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
 ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
-rows = db.execute(f"select d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id where (s.kernel_name like '%pd_ggs_kernel%' or s.kernel_name like '%pd_ggs_lane_kernel%') order by d.start").fetchall()
-if not rows:
+def dispatches(pattern):
+    q = "select d.start, d.end{g} from {kd} d join {ks} s on d.kernel_id=s.id where s.kernel_name like '%{p}%' order by d.start"
+    try:
+        return db.execute(q.format(g=", d.grid_size_x", kd=kd, ks=ks, p=pattern)).fetchall()
+    except sqlite3.OperationalError:          # a rocpd schema without the grid columns: one shape assumed
+        return [(a, b, 0) for a, b in db.execute(q.format(g="", kd=kd, ks=ks, p=pattern)).fetchall()]
+
+
+# The bench's engine passes run the lane-per-item kernel since round 4 (one workgroup per sequence: 256 workgroups per launch); its
+# cold-single-batch leg launches other shapes (64 sequences: the lane kernel on 64 workgroups, the wave-per-item kernel on 4 x 64) with a
+# quarter of the FLOPs per launch.  Only the launches of the most time-consuming (kernel, grid) shape are analysed; the rest is listed.
+cand = dispatches("pd_ggs_lane_kernel")
+which = "pd_ggs_lane_kernel"
+others = [("pd_ggs_kernel", r) for r in dispatches("pd_ggs_kernel")]
+if not cand:
+    cand, others, which = [r for _, r in others], [], "pd_ggs_kernel"
+if not cand:
     raise SystemExit("no pd_ggs_kernel / pd_ggs_lane_kernel dispatches in the trace")
+by_grid = defaultdict(list)
+for r in cand:
+    by_grid[r[2]].append(r)
+main_grid = max(by_grid, key=lambda g: sum(en - st for st, en, _ in by_grid[g]))
+rows = [(st, en) for st, en, _ in by_grid[main_grid]]
+others += [(which, r) for g, rs in by_grid.items() if g != main_grid for r in rs]
+if main_grid:
+    which += f" with a grid of {main_grid} threads"
+if others:
+    shapes = defaultdict(list)
+    for name, (st, en, g) in others:
+        shapes[(name, g)].append((en - st) / 1e6)
+    for (name, g), od in sorted(shapes.items()):
+        print(f"(not counted below: {len(od)} {name} launches with a grid of {g} threads -- another shape: the cold single batch -- average {sum(od) / len(od):.3f} ms)")
 sets, cur = [], [rows[0]]
 cur_end = rows[0][1]
 for st, en in rows[1:]:
@@ -33,7 +62,7 @@ by_size = defaultdict(list)
 for s in sets:
     by_size[len(s)].append(s)
 durs = [(en - st) / 1e6 for st, en in rows]
-print(f"GGS kernel (pd_ggs_lane_kernel since round 4, else pd_ggs_kernel): {len(rows)} launches, average duration {sum(durs) / len(durs):.3f} ms (min {min(durs):.3f}, max {max(durs):.3f})")
+print(f"GGS kernel {which}: {len(rows)} launches, average duration {sum(durs) / len(durs):.3f} ms (min {min(durs):.3f}, max {max(durs):.3f})")
 print(f"one launch alone: {flops / (sum(durs) / len(durs) * 1e-3) / 1e12:.2f} TFLOP/s = {flops / (sum(durs) / len(durs) * 1e-3) / 1e12 / 157.3 * 100:.1f} % of 157.3 (fp32 vector ALU), "
       f"{flops / 1e9:.2f} GFLOP per launch")
 for n in sorted(by_size):
