@@ -1,2 +1,12 @@
-"""demo.py:25 imports `model_io` and `vis_utils` and never uses them."""
-from . import model_io, vis_utils  # noqa: F401
+"""pytorch3d.implicitron.tools as pose_diffusion/demo.py:25 needs it: `from pytorch3d.implicitron.tools import model_io, vis_utils`
+imports the two names and never uses them on the sampling path.  They are plain namespaces here (visualisation and checkpoint io of
+Implicitron are out of scope); the one function a reader of demo.py might reach for says why it is absent."""
+import types
+
+
+def _no_visdom(*args, **kwargs):
+    raise ConnectionError("visdom is not installed (posediffusion_amd stand-in): no visualisation server")
+
+
+model_io = types.SimpleNamespace(__name__="pytorch3d.implicitron.tools.model_io", __pd_shim__=True)
+vis_utils = types.SimpleNamespace(__name__="pytorch3d.implicitron.tools.vis_utils", __pd_shim__=True, get_visdom_connection=_no_visdom)
