@@ -226,22 +226,37 @@ def cpu_baseline(budget_s: float):
     flags = {"all": (True, True, True), "fl": (False, False, True), "r": (True, False, False), "t": (False, True, False)}
     t_stage, n_stage = {}, {}
     per_stage_budget = 0.8 * budget_s / 4
-    for name, (uR, uT, uF) in flags.items():
-        n_it = 2
+
+    def make_run(name, uR, uT, uF):
         if use_ref:
             pmr = {"kp1_homo": pm["kp1_homo"], "kp2_homo": pm["kp2_homo"], "i1": pm["i1"], "i2": pm["i2"], "h": IMG, "w": IMG,
                    "pair_idx": pm["pair_idx"]}
-            run = lambda n: ref.GGS_optimize(x0.clone(), 0, pmr, update_R=uR, update_T=uT, update_FL=uF,          # noqa: E731
-                                             **dict(synth.GGS_CFG, iter_num=(n // 2 if name == "all" else n)))
-        else:
-            run = lambda n: O.ggs_optimize(x0.clone(), pm, update_R=uR, update_T=uT, update_FL=uF,                # noqa: E731
-                                           iter_num=(n // 2 if name == "all" else n))
+            return lambda n: ref.GGS_optimize(x0.clone(), 0, pmr, update_R=uR, update_T=uT, update_FL=uF,
+                                              **dict(synth.GGS_CFG, iter_num=(n // 2 if name == "all" else n)))
+        return lambda n: O.ggs_optimize(x0.clone(), pm, update_R=uR, update_T=uT, update_FL=uF, iter_num=(n // 2 if name == "all" else n))
+
+    # the GGS iterations are 98 % of a sequence on the CPU and their operators (gathers and products over 57 000 matches) like another
+    # thread count than the denoiser's 20-row GEMMs: probed separately on the `all` stage, the fastest kept for the four stages
+    probe = make_run("all", True, True, True)
+    best_g = (float("inf"), threads)
+    with contextlib.redirect_stdout(io.StringIO()):
+        for n in sorted({min(max_threads, c) for c in (4, 8, 16, 32, 64, max_threads)}):
+            torch.set_num_threads(n)
+            probe(2)
+            t0 = time.time()
+            probe(4)
+            best_g = min(best_g, ((time.time() - t0) / 4, n))
+    den_threads, threads = threads, best_g[1]
+    torch.set_num_threads(threads)
+    for name, (uR, uT, uF) in flags.items():
+        n_it = 2
+        run = make_run(name, uR, uT, uF)
         with contextlib.redirect_stdout(io.StringIO()):
             run(2)                                                                     # warm-up
             t0 = time.time()
             run(n_it)
             dt = time.time() - t0
-            n_it = int(max(2, min(60, per_stage_budget / max(dt / n_it, 1e-4)))) // 2 * 2
+            n_it = int(max(2, min(400, per_stage_budget / max(dt / n_it, 1e-4)))) // 2 * 2      # fills the budget (~ 0.2 budget_s per stage)
             t0 = time.time()
             run(n_it)
             dt = time.time() - t0
@@ -253,8 +268,9 @@ def cpu_baseline(budget_s: float):
             "helpers, oracle/ref_stubs.py)" if use_ref else "oracle/pd_oracle.py (torch-CPU restatement of the reference path)")
     return {"value": 1.0 / t_seq, "unit": "sequences/s", "cores": threads, "host_cores": host_cores,
             "kind": "reference" if use_ref else "port",
-            "sample": f"{what}, torch {torch.__version__} CPU, {threads} threads (fastest of 4/8/16/32/all on the denoiser; the host "
-                      f"has {host_cores} cores): {n_den} denoiser steps (B=1, N=20): {t_den * 1e3:.1f} ms/step; GGS iterations at "
+            "sample": f"{what}, torch {torch.__version__} CPU, {threads} threads for the GGS iterations and {den_threads} for the denoiser "
+                      f"(each the fastest of 4/8/16/32/64/all on its own operator; the host has {host_cores} cores; `cores` = the GGS figure, "
+                      f"98 % of the time): {n_den} denoiser steps (B=1, N=20): {t_den * 1e3:.1f} ms/step; GGS iterations at "
                       f"M=57000: " + ", ".join(f"{k} x{n_stage[k]}: {t_stage[k] * 1e3:.1f} ms/it" for k in stage_iters) +
                       "; extrapolated to 100 steps + 10 x (400 all + 100 FL + 100 R + 100 T) iterations per sequence"}
 
