@@ -252,3 +252,52 @@ def test_advice_round2_host_side_guards(seeded_diffuser):
     cond = partial(geometry_guided_sampling, matches_dict=[md, empty], GGS_cfg=dict(synth.GGS_CFG))
     with pytest.raises(ValueError, match="have no matches"):
         seeded_diffuser.sample([2, 6, 9], torch.zeros(2, 6, 384), cond_fn=cond, cond_start_step=10)
+
+
+def test_trace_tools_separate_the_ggs_launch_shapes(tmp_path):
+    """tools/rocpd_stats.py and tools/coresident_from_trace.py produce the committed rocprofv3 evidence (profiles/round*_kernel_stats.txt,
+    *_coresident.txt).  One bench run launches the GGS kernels in several shapes (256-workgroup engine passes; the cold-single-batch leg
+    on 64 and 4 x 64 workgroups): the tools must analyse the engine passes alone and list the rest -- checked on a synthetic rocpd database
+    (three contexts' 256-workgroup launches, two of them overlapping; cold-batch launches of both kernel families)."""
+    import sqlite3
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "bench_results.db")
+    db = sqlite3.connect(path)
+    db.execute("create table rocpd_kernel_dispatch_x (start int, end int, kernel_id int, grid_size_x int, workgroup_size_x int)")
+    db.execute("create table rocpd_info_kernel_symbol_x (id int, kernel_name text)")
+    db.execute("insert into rocpd_info_kernel_symbol_x values (1, '_Z18pd_ggs_lane_kernelILi12EEv11PdGgsParamsi.kd'), "
+               "(2, '_Z13pd_ggs_kernelILi5ELb0ELi8EEv11PdGgsParamsiiii.kd'), (3, '_Z17pd_ln_rows_kernelILi512ELi2EEvPKfPfiff.kd')")
+    ms = 1_000_000
+    t = 0
+    for _ in range(4):                                             # engine passes, alone: 17 ms each
+        db.execute("insert into rocpd_kernel_dispatch_x values (?, ?, 1, ?, 512)", (t, t + 17 * ms, 256 * 512))
+        t += 20 * ms
+    for k in range(3):                                             # three contexts' launches issued together: they queue, 51 ms for the set
+        db.execute("insert into rocpd_kernel_dispatch_x values (?, ?, 1, ?, 512)", (t + k, t + 17 * (k + 1) * ms, 256 * 512))
+    t += 60 * ms
+    for _ in range(3):                                             # the cold single batch: another shape of the same kernel ...
+        db.execute("insert into rocpd_kernel_dispatch_x values (?, ?, 1, ?, 512)", (t, t + 13 * ms, 64 * 512))
+        t += 20 * ms
+    for _ in range(3):                                             # ... and the wave-per-item kernel on 4 x 64 workgroups
+        db.execute("insert into rocpd_kernel_dispatch_x values (?, ?, 2, ?, 512)", (t, t + 8 * ms, 256 * 512))
+        t += 20 * ms
+    db.execute("insert into rocpd_kernel_dispatch_x values (?, ?, 3, ?, 256)", (t, t + 6000, 1280 * 256))
+    db.commit()
+    db.close()
+    flops = 256 * 57000 * 100.0 * 700
+    co = subprocess.run([sys.executable, os.path.join(root, "tools", "coresident_from_trace.py"), path, str(flops)],
+                        capture_output=True, text=True, check=True).stdout
+    assert "7 launches, average duration" in co and "grid of 131072 threads" in co                  # 4 alone + the set of 3, nothing else
+    assert "3 pd_ggs_kernel launches" in co and "3 pd_ggs_lane_kernel launches with a grid of 32768 threads" in co
+    assert "sets of 1 overlapping launch(es): 4 sets, wall 17.000 ms" in co
+    assert "sets of 3 overlapping launch(es): 1 sets, wall 51.000 ms" in co
+    frac = 3 * flops / 51e-3 / 1e12 / 157.3 * 100
+    assert f"{frac:.1f} % of the fp32 vector ALU peak" in co
+    st = subprocess.run([sys.executable, os.path.join(root, "tools", "rocpd_stats.py"), path, "8"], capture_output=True, text=True, check=True).stdout
+    lines = [ln for ln in st.splitlines() if ln.startswith("# ")]
+    assert any("pd_ggs_lane_kernel" in ln and " 256 workgroups:     7 launches" in ln for ln in lines), st
+    assert any("pd_ggs_lane_kernel" in ln and "  64 workgroups:     3 launches, average   13.000 ms" in ln for ln in lines), st
+    assert any("pd_ggs_kernel" in ln and " 256 workgroups:     3 launches, average    8.000 ms" in ln for ln in lines), st
+    assert st.splitlines()[1].startswith("_Z18pd_ggs_lane_kernel")                                   # the table itself: by total time
