@@ -317,6 +317,9 @@ def main():
     ap.add_argument("--seqs-per-step", type=int, default=STEP_SEQS, help="sequences per step: in total (strong) / per GPU (weak)")
     ap.add_argument("--engine-batch", type=int, default=256,
                     help="most sequences per engine pass (a rank groups the shards of consecutive steps up to this; 256 = one GGS workgroup per CU)")
+    ap.add_argument("--min-passes", type=int, default=2,
+                    help="fewest engine passes a rank's run is cut into (shard.steps_per_pass; 2 = a second context overlaps the first; "
+                         "1 lets a short run -- an 8-GPU rank's 160 sequences -- go as ONE pass)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ggs-wgs", type=int, default=0, help="override GGS workgroups per sequence (0 = from the pipeline shape)")
     ap.add_argument("--pipeline-depth", type=int, default=3,
@@ -366,10 +369,10 @@ def main():
     strong = args.scaling == "strong"
     step_total = args.seqs_per_step * (1 if strong else world)                  # sequences of one step over all ranks
     if strong:
-        g0, g1, group, _ = shard.strong_schedule(K, step_total, world, rank, args.engine_batch)
+        g0, g1, group, _ = shard.strong_schedule(K, step_total, world, rank, args.engine_batch, args.min_passes)
     else:
         g0, g1 = rank * args.seqs_per_step, (rank + 1) * args.seqs_per_step
-        group = shard.steps_per_pass(K, args.seqs_per_step, args.engine_batch)
+        group = shard.steps_per_pass(K, args.seqs_per_step, args.engine_batch, args.min_passes)
     B_step = g1 - g0                                                            # this rank's sequences of one step
     if B_step <= 0:
         raise SystemExit(f"rank {rank} has no sequences: {step_total} per step over {world} ranks")

@@ -75,18 +75,18 @@ def barrier(force_collective: bool = False):
         dist.barrier()
 
 
-def steps_per_pass(n_steps: int, b_step: int, engine_batch: int) -> int:
+def steps_per_pass(n_steps: int, b_step: int, engine_batch: int, min_passes: int = 2) -> int:
     """How many consecutive steps' shards (b_step sequences each) a rank runs as ONE engine pass: as many as fit
     `engine_batch` sequences, but no more than leaves the run's passes balanced -- ceil(S / engine_batch) passes (at least
-    two when there are two steps: a second context overlaps its denoiser steps with the first one's GGS launches) of
-    equal length, instead of full passes plus a short straggler that runs alone at the end."""
+    `min_passes` = two when there are two steps: a second context overlaps its denoiser steps with the first one's GGS
+    launches) of equal length, instead of full passes plus a short straggler that runs alone at the end."""
     if b_step <= 0 or n_steps <= 0:
         return 1
-    n_pass = max(-(-n_steps * b_step // engine_batch), min(2, n_steps))
+    n_pass = max(-(-n_steps * b_step // engine_batch), min(max(1, min_passes), n_steps))
     return max(1, min(-(-n_steps // n_pass), max(1, engine_batch // b_step)))
 
 
-def strong_schedule(n_steps: int, step_seqs: int, world: int, rank: int, engine_batch: int):
+def strong_schedule(n_steps: int, step_seqs: int, world: int, rank: int, engine_batch: int, min_passes: int = 2):
     """Strong scaling of `n_steps` steps of `step_seqs` independent sequences each over `world` ranks (bench.py):
     every step is block-partitioned, rank r owning rows [g0, g1) of each; a rank runs the shards of `group` consecutive
     steps as ONE engine pass of at most `engine_batch` sequences (`steps_per_pass`).  -> (g0, g1, group, passes) where
@@ -98,7 +98,7 @@ def strong_schedule(n_steps: int, step_seqs: int, world: int, rank: int, engine_
     if b_step > engine_batch:
         raise ValueError(f"rank {rank} holds {b_step} sequences of every step, more than one engine pass takes ({engine_batch}): "
                          "raise the engine batch or use more ranks")
-    group = steps_per_pass(n_steps, b_step, engine_batch)
+    group = steps_per_pass(n_steps, b_step, engine_batch, min_passes)
     passes = [min(group, n_steps - s0) * b_step for s0 in range(0, n_steps, group)]
     return g0, g1, group, passes
 

@@ -232,6 +232,15 @@ def test_strong_scaling_schedule_covers_every_sequence_once():
     assert shard.strong_schedule(20, 64, 4, 0, 256)[3] == [160, 160]
     assert shard.strong_schedule(20, 64, 8, 0, 256)[3] == [80, 80]
     assert shard.strong_schedule(24, 64, 1, 0, 256)[3] == [256] * 6
+    # bench.py --min-passes (tools/rank_shape_sweep.sh): an 8-GPU rank's 160 sequences as one pass, or as three / four shorter ones
+    assert shard.strong_schedule(20, 64, 8, 3, 256, min_passes=1)[3] == [160]
+    assert shard.strong_schedule(20, 64, 8, 3, 256, min_passes=3)[3] == [56, 56, 48]
+    assert shard.strong_schedule(20, 64, 8, 3, 256, min_passes=4)[3] == [40] * 4
+    assert shard.strong_schedule(20, 64, 1, 0, 256, min_passes=1)[3] == [256] * 5          # a full-size run is cut by the engine batch either way
+    for mp in (1, 2, 3, 4):
+        for world in (1, 2, 4, 8):
+            g0, g1, group, passes = shard.strong_schedule(20, 64, world, world - 1, 256, min_passes=mp)
+            assert sum(passes) == 20 * (g1 - g0) and max(passes) <= 256 and len(passes) >= min(mp, 20)
 
 
 def test_advice_round2_host_side_guards(seeded_diffuser):
