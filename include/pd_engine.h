@@ -277,7 +277,8 @@ int pd_time_embedding(const float *w0, const float *b0, const float *w2, const f
                       float *out, void *stream);
 
 /* PoseEmbedding.forward (util/embedding.py:52-54) = pytorch3d HarmonicEmbedding(n_harmonic_functions = 10, append_input = True):
- * x[rows,dim] -> out[rows, 21 dim] = [sin(x_d 2^k) | sin(x_d 2^k + pi/2) | x], d-major, k = 0..9 (189 columns for dim = 9). */
+ * x[rows,dim] -> out[rows, 21 dim] = [sin(x_d 2^k) | sin(x_d 2^k + pi/2) | x], d-major, k = 0..9 (189 columns for dim = 9);
+ * 1 <= dim <= 4096, rows >= 0 (an empty batch is a no-op). */
 int pd_pose_embedding(const float *x, long long rows, int dim, float *out, void *stream);
 
 /* ---- evaluation metrics (stateless, all pointers DEVICE fp32) ------- */
