@@ -226,6 +226,10 @@ int pd_ggs_loss_grad(pd_engine *eng, const float *x, int B, int N, int update_R,
  *    built: correct but 2.4 x slower than the 43-launch path, profiles/round3_small_persistent.txt; source parked under tools/parked/.
  *    Value 0 is accepted, 1 returns PD_ERR_UNSUPPORTED.) */
 int pd_engine_set_option(pd_engine *eng, int option, int value);
+/* Reads an option back.  PD_OPT_DENOISER_SPLIT: the mode in force (an engine created from weights that hold inf / NaN stays on 0 although
+ * it is large enough for 2 -- the only downgrade pd_engine_create performs by itself; PD_OPT_WEIGHTS_NON_FINITE (read-only) then reads 1). */
+#define PD_OPT_WEIGHTS_NON_FINITE 4
+int pd_engine_get_option(pd_engine *eng, int option, int *value_out);
 
 /* GaussianDiffusion.sample / p_sample_loop (gaussian_diffuser.py:284-306).
  *   z      [B,N,z_dim]                      DEVICE

@@ -59,6 +59,7 @@ PD_GGS_CFG_LANE_ITEMS = 8       # lane-per-item kernel (the throughput shape) wh
 PD_GGS_CFG_NO_LANE_ITEMS = 16   # never the lane-per-item kernel
 PD_GGS_CFG_XCHG_SPREAD = 32     # k > 1: no XCD-local placement of a sequence's workgroups (comparison)
 PD_OPT_DENOISER_SPLIT = 2
+PD_OPT_WEIGHTS_NON_FINITE = 4   # pd_engine_get_option only
 PD_MATCH_HINT_ONE_ORDER = 1 << 30   # pd_match_hints.max_pairs flag: every frame pair in one order only (hloc's i < j pairs)
 
 
@@ -89,6 +90,7 @@ SIGNATURES = {
     "pd_ggs_optimize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp]),
     "pd_ggs_loss_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp]),
     "pd_engine_set_option": (_i, [_vp, _i, _i]),
+    "pd_engine_get_option": (_i, [_vp, _i, C.POINTER(_i)]),
     "pd_time_embedding": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "pd_pose_embedding": (_i, [_vp, C.c_longlong, _i, _vp, _vp]),
     "pd_metrics_rel_pose_errors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),

@@ -1,12 +1,5 @@
 """pytorch3d.implicitron.tools as pose_diffusion/demo.py:25 needs it: `from pytorch3d.implicitron.tools import model_io, vis_utils`
-imports the two names and never uses them on the sampling path.  They are plain namespaces here (visualisation and checkpoint io of
-Implicitron are out of scope); the one function a reader of demo.py might reach for says why it is absent."""
-import types
-
-
-def _no_visdom(*args, **kwargs):
-    raise ConnectionError("visdom is not installed (posediffusion_amd stand-in): no visualisation server")
-
-
-model_io = types.SimpleNamespace(__name__="pytorch3d.implicitron.tools.model_io", __pd_shim__=True)
-vis_utils = types.SimpleNamespace(__name__="pytorch3d.implicitron.tools.vis_utils", __pd_shim__=True, get_visdom_connection=_no_visdom)
+imports the two names and never uses them on the sampling path; util/train_util.py:20 imports `vis_utils.get_visdom_connection` by its
+dotted module path.  Both are real (one-line) submodules, so either import form resolves; visualisation and checkpoint io of
+Implicitron are out of scope."""
+from . import model_io, vis_utils  # noqa: F401

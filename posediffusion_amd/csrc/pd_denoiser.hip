@@ -933,6 +933,7 @@ static int pd_denoiser_build_scales(pd_engine *eng) {
         L.ctx_scale = ldexpf(1.0f, e_ctx);
         L.ff_scale = ldexpf(1.0f, e_ff);
         if (!finite) {
+            d->non_finite = true;
             pd_set_error("denoiser: encoder layer %d holds non-finite weights or biases: no static operand bound exists, the fp16-plane "
                          "mode (PD_OPT_DENOISER_SPLIT = 2) is not available for these weights", l);
             return PD_ERR_INVALID_ARG;
@@ -967,6 +968,7 @@ static int pd_denoiser_build_split_h(pd_engine *eng) {
     return PD_OK;
 }
 bool pd_denoiser_has_streamed_path(const pd_engine *eng) { return eng->den && eng->den->hn; }
+bool pd_denoiser_weights_non_finite(const pd_engine *eng) { return eng->den && eng->den->non_finite; }
 
 int pd_denoiser_build_split(pd_engine *eng, int mode) {
     PdDenoiserDev *d = eng->den;

@@ -54,6 +54,7 @@ struct PdDenoiserDev {
     bool split_ready = false;          // the fast mode's split weights exist
     bool split_h_ready = false;        // the fp16-plane mode's weights exist
     bool scales_ready = false;         // the fp16-plane scales exist (pd_denoiser_build_scales)
+    bool non_finite = false;           // pd_denoiser_build_scales met inf / NaN in an encoder weight or bias: the ONLY failure pd_engine_create downgrades on
     std::vector<void *> allocs;
 };
 

@@ -130,8 +130,10 @@ extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_en
         if (pd_denoiser_has_streamed_path(eng)) {
             rc = pd_denoiser_build_split(eng, 2);
             if (rc == PD_OK) eng->den_split = 2;
-            else if (rc == PD_ERR_INVALID_ARG) rc = PD_OK;
-            else break;
+            else if (rc == PD_ERR_INVALID_ARG && pd_denoiser_weights_non_finite(eng)) {
+                rc = PD_OK;                       // the one intended downgrade; any other failure of the build is an error of the creation
+                g_err[0] = 0;                     // ... and not the "last error" of a call that succeeded (pd_engine_get_option reports the mode)
+            } else break;
         }
         if ((rc = pd_ggs_init())) break;
         if ((rc = pd_ggs_ingest_init())) break;
@@ -446,6 +448,21 @@ extern "C" int pd_engine_set_option(pd_engine *eng, int option, int value) {
         return PD_ERR_INVALID_ARG;
     }
     return PD_OK;      // (captured graphs are keyed on the option: nothing to drop)
+}
+
+extern "C" int pd_engine_get_option(pd_engine *eng, int option, int *value_out) {
+    if (!eng || !value_out) {
+        pd_set_error("pd_engine_get_option: NULL argument");
+        return PD_ERR_INVALID_ARG;
+    }
+    switch (option) {
+    case PD_OPT_DENOISER_SPLIT: *value_out = eng->den_split; break;
+    case PD_OPT_WEIGHTS_NON_FINITE: *value_out = pd_denoiser_weights_non_finite(eng) ? 1 : 0; break;
+    default:
+        pd_set_error("pd_engine_get_option: unknown option %d", option);
+        return PD_ERR_INVALID_ARG;
+    }
+    return PD_OK;
 }
 
 // ---- measurement helper -------------------------------------------------------------------------

@@ -212,6 +212,7 @@ struct pd_engine {
 int pd_denoiser_create(pd_engine *eng, const pd_weights *w);
 void pd_denoiser_destroy(pd_engine *eng);
 bool pd_denoiser_has_streamed_path(const pd_engine *eng);   // created with max_B x max_N >= PD_STREAM_MIN_ROWS token rows
+bool pd_denoiser_weights_non_finite(const pd_engine *eng);  // the fp16-plane scales were refused because an encoder weight / bias is inf or NaN
 int pd_denoiser_build_split(pd_engine *eng, int mode);    // 1: bf16 planes (fast mode), 2: fp16 planes with static scales
 // eps_out / mean_out / x_next_out may each be null. noise null => 0.
 int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, int B, int N, float *eps_out,

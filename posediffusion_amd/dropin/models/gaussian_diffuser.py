@@ -136,8 +136,7 @@ class GaussianDiffusion(nn.Module):
         if stats is not None and os.environ.get("PD_GGS_VERBOSE", "1") not in ("", "0"):
             st = stats.cpu()
             for k in range(st.shape[0]):
-                for s in range(5):
-                    print(f"t={cond_start_step - 1 - k:02d} | sampson={float(st[k, 0, s, 0]):05f}")
+                host.print_ggs_stats(st[k], cond_start_step - 1 - k, int(dict(cfg).get("iter_num", 100)))   # incl. the drop line, :104-108
         return pose, process
 
     @torch.no_grad()

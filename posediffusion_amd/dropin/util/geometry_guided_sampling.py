@@ -14,7 +14,7 @@ from posediffusion_amd.engine import make_ggs_cfg
 
 @torch.no_grad()
 def geometry_guided_sampling(model_mean: torch.Tensor, t: int, matches_dict, GGS_cfg, engine=None):
-    from posediffusion_amd.host import current_engine, upload_matches
+    from posediffusion_amd.host import current_engine, print_ggs_stats, upload_matches
     if model_mean.shape[0] != 1 and not isinstance(matches_dict, (list, tuple)):
         raise ValueError("GGS is defined per sequence: pass one matches_dict per batch element (list) for B > 1")
     if engine is None:
@@ -23,7 +23,5 @@ def geometry_guided_sampling(model_mean: torch.Tensor, t: int, matches_dict, GGS
     out, stats = engine.ggs_guide(model_mean, t, make_ggs_cfg(GGS_cfg))
     engine.check_async()      # a bounded cross-workgroup spin that gave up must raise, not return garbage (and is cleared)
     if os.environ.get("PD_GGS_VERBOSE", "1") not in ("", "0"):     # the reference prints unconditionally (:124); PD_GGS_VERBOSE=0 mutes
-        for b in range(stats.shape[0]):
-            for s in stats[b].tolist():
-                print(f"t={t:02d} | sampson={s[0]:05f}")                         # geometry_guided_sampling.py:124
+        print_ggs_stats(stats, int(t), int(dict(GGS_cfg).get("iter_num", 100)))   # geometry_guided_sampling.py:104-108, :124
     return out

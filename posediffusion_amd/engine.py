@@ -268,6 +268,12 @@ class PoseEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pd_engine_set_option(self._h, _lib.PD_OPT_DENOISER_SPLIT, int(mode)), "pd_engine_set_option")
 
+    def get_option(self, option: int) -> int:
+        """pd_engine_get_option: e.g. ``_lib.PD_OPT_DENOISER_SPLIT`` -> the encoder GEMM mode in force (0 after the non-finite-weights downgrade)."""
+        v = C.c_int(0)
+        _lib.check(self.lib.pd_engine_get_option(self._h, int(option), C.byref(v)), "pd_engine_get_option")
+        return int(v.value)
+
     def pose_to_camera(self, enc: torch.Tensor):
         enc = self._f32(enc).reshape(-1, 9)
         n = enc.shape[0]

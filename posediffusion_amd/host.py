@@ -83,13 +83,34 @@ def draw_noise(shape, timesteps: int, device, guided_from: int = 0, has_cond: bo
     """[T+1, *shape] noise in the reference's draw order: randn(shape) (gaussian_diffuser.py:289), then
     one randn_like per step t = T-1..0 that is unguided and has t > 0 (:276-278); other slots stay 0."""
     out = torch.zeros((timesteps + 1, *shape), device=device, dtype=torch.float32)
-    out[0] = torch.randn(shape, device=device, generator=generator)
+    # randn straight into the slot (`out=` a contiguous slice): the same generator calls in the same order with the same shapes as
+    # the reference, hence the same values, without a temporary + copy kernel per step (tests/test_host_cpu.py pins the equality)
+    torch.randn(shape, out=out[0], generator=generator)
     for step in range(timesteps):
         t = timesteps - 1 - step
         guided = has_cond and t < guided_from
         if not guided and t > 0:
-            out[step + 1] = torch.randn(shape, device=device, generator=generator)
+            torch.randn(shape, out=out[step + 1], generator=generator)
     return out
+
+
+def ggs_stage_iters(iter_num: int):
+    """Iterations each of the five GGS_optimize calls of one guided step is given (geometry_guided_sampling.py:48-63, :86-87)."""
+    return (2 * iter_num, iter_num, iter_num, iter_num, 2 * iter_num)
+
+
+def print_ggs_stats(stats, t: int, iter_num: int, out=None):
+    """The lines the reference prints for one guided step (geometry_guided_sampling.py:104-108, :124), from the engine's per-stage
+    statistics ``stats`` [B, 5, 4] = {sampson_to_print, iterations stepped, last n_valid, last loss}: a stage that stepped fewer
+    iterations than it was given left through the `min_matches` break and printed the drop line first.  One line per GGS_optimize
+    call as in the reference, which is defined for B = 1; for a batch the lines are those of sequence 0."""
+    import sys
+    out = out or sys.stdout
+    st = stats.detach().cpu() if hasattr(stats, "detach") else stats
+    for s, given in enumerate(ggs_stage_iters(int(iter_num))):
+        if int(st[0, s, 1]) < given:
+            print("Drop this pair because of insufficient valid matches", file=out)      # :107
+        print(f"t={t:02d} | sampson={float(st[0, s, 0]):05f}", file=out)                  # :124
 
 
 _ENGINES = {}   # device index -> most recently built engine (used by the free functions of dropin/util)
