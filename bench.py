@@ -90,8 +90,10 @@ def make_batch_inputs(eng, diff, B, dev, seed0, n_frames=N_FRAMES, img=IMG, per_
         md = synth.make_epipolar_matches(mean[b], img, img, per_pair, seed=2000 + seed0 + b)
         if upload:
             eng.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
-        if keep_host:
+        if keep_host is True or (keep_host and b in keep_host):      # True: every slot; a collection: those slots (None elsewhere)
             mds.append(md)
+        elif keep_host:
+            mds.append(None)
     return z, noise, mds
 
 
@@ -387,7 +389,9 @@ def main():
     pipe = SamplingPipeline(engines, slots, dev, unguided_streams=max(0, args.unguided_streams), trace=args.trace)
     # one resident engine batch per context (different sequences: seeds offset per context and rank)
     want_fresh = not args.no_fresh_inputs
-    inputs = [make_batch_inputs(engines[j], diff, EB, dev, seed0=100_000 * rank + j * EB, keep_host=want_fresh) for j in range(depth)]
+    check_slots = sorted({0, min(EB - 1, ((EB - 1) // 3) | 1), EB - 1})                       # headline_slots_equal_alone: these slots of context 0 are re-run alone
+    inputs = [make_batch_inputs(engines[j], diff, EB, dev, seed0=100_000 * rank + j * EB, keep_host=True if want_fresh else (check_slots if j == 0 else False))
+              for j in range(depth)]
     wgs = args.ggs_wgs if args.ggs_wgs > 0 else pipe.wgs_per_seq(EB)
     flags = int(os.environ.get("PD_GGS_RESERVED", "0"))                                                          # A/B switch, pd_engine.h
     if wgs == 1 and not (flags & _lib.PD_GGS_CFG_NO_LANE_ITEMS):
@@ -586,6 +590,25 @@ def main():
             for b, md in enumerate(inputs[j][2]):
                 engines[j].set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
 
+    # ---- the headline kernel pinned at the headline launch: a guided step of the full engine batch -- the launch
+    # shape of the timed region: EB workgroups, the lane-per-item kernel -- against the same sequences run ALONE (one workgroup on an idle
+    # chip) on a second, single-slot engine: bit for bit, all 700 iterations.  (tests/test_gpu_parity_r5.py does this against the oracle too.)
+    slots_equal = None
+    if rank == 0:
+        solo = PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=1, max_N=N_FRAMES)
+        big, big_st = eng.ggs_guide(full_pose, 0, cfg)
+        eng.check_async()
+        slots_equal = True
+        for b in check_slots:
+            md = inputs[0][2][b]
+            solo.set_matches(0, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+            one, one_st = solo.ggs_guide(full_pose[b:b + 1], 0, cfg)
+            solo.check_async()
+            slots_equal = slots_equal and bool(torch.equal(one[0], big[b])) and bool(torch.equal(one_st[0], big_st[b])) \
+                and float(one_st[0, :, 1].sum().item()) == 7.0 * cfg.iter_num
+        solo.close()
+        assert slots_equal, f"slots {check_slots} of the {EB}-sequence GGS launch differ from the same sequences run alone"
+
     # ---- roofline of the dominant kernel + the denoiser step, timed with hipEvents on the launch stream
     eng.time_kernel(1, EB, N_FRAMES, cfg, reps=2)             # warm: the timed launches below start on a busy chip (clocks up), as in the pipe
     ggs_each = [eng.time_kernel(1, EB, N_FRAMES, cfg, reps=1) for _ in range(6)]   # each launch on its own: the spread is reported
@@ -730,6 +753,7 @@ def main():
             "hip_graph": use_graph, "pipeline_depth": depth, "guided_slots": slots, "unguided_streams": max(0, args.unguided_streams), "ggs_workgroups_per_sequence": k_eff,
             "engine_pass_latency_ms_unpipelined": pass_latency_ms,
             "parallelism": f"dp{world} (independent sequences, one final all_gather)", "outputs_finite": finite,
+            "headline_slots_equal_alone": slots_equal, "headline_slots_checked": check_slots,
         },
         "roofline": roofline,
         "roofline_denoiser": roofline_den,

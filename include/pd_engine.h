@@ -225,6 +225,11 @@ int pd_ggs_loss_grad(pd_engine *eng, const float *x, int B, int N, int update_R,
 /*   (option 3, PD_OPT_DENOISER_PERSISTENT of round 3 -- a denoiser evaluation of <= 32 token rows as ONE persistent launch -- is no longer
  *    built: correct but 2.4 x slower than the 43-launch path, profiles/round3_small_persistent.txt; source parked under tools/parked/.
  *    Value 0 is accepted, 1 returns PD_ERR_UNSUPPORTED.) */
+/*   PD_OPT_DENOISER_FUSED_ATTN  (fp16-plane mode, sequences of <= 32 frames) 1 (default): the in_proj Linear and the attention of a head run as
+ *        ONE kernel per group of whole sequences, Q / K / V held in LDS and never written to memory (csrc/pd_qkv_attn.h; models/denoiser.py:88-97);
+ *        0: the two launches it replaces (QKV GEMM -> fp32 QKV in memory -> attention).  Same arithmetic in the same order: bitwise the
+ *        same results -- comparison / testing. */
+#define PD_OPT_DENOISER_FUSED_ATTN 5
 int pd_engine_set_option(pd_engine *eng, int option, int value);
 /* Reads an option back.  PD_OPT_DENOISER_SPLIT: the mode in force (an engine created from weights that hold inf / NaN stays on 0 although
  * it is large enough for 2 -- the only downgrade pd_engine_create performs by itself; PD_OPT_WEIGHTS_NON_FINITE (read-only) then reads 1). */

@@ -256,7 +256,7 @@ def make_preprocess():
     print("preprocess.npz", os.path.getsize(os.path.join(OUT, "preprocess.npz")))
 
 
-def make_guided_free(seeds=(0, 1, 2), N=8, cond_start=3, per_pair=60, name="guided_free"):
+def make_guided_free(seeds=(0, 1, 2), N=8, cond_start=3, per_pair=60, name="guided_free", store_matches=True):
     """tests/golden/guided_free.npz -- SURVEY.md section 8c's FREE-RUNNING GGS-on criterion, scaled down from BASELINE
     configs[2]: N = 8 frames, 28 pairs x 60 matches, 100 DDPM steps, the last `cond_start` = 3 of them guided with the
     FULL default schedule (5 optimisations = 700 iterations per guided step, cfgs/default.yaml:6-13).  Per seed:
@@ -270,7 +270,11 @@ def make_guided_free(seeds=(0, 1, 2), N=8, cond_start=3, per_pair=60, name="guid
     `make_guided_free(seeds=(0,), N=20, cond_start=10, per_pair=300, name="guided_free_full")` writes
     tests/golden/guided_free_full.npz: ONE seed of BASELINE configs[2] at its real size -- 20 frames, 190 pairs x 300 =
     57 000 matches, 224^2, 100 steps, the last 10 guided x 700 iterations = 7 000 iterations.
-    (about 20 CPU-minutes: the reference and the fp64 oracle each run 7 000 iterations over 57 000 matches on one thread)."""
+    (about 20 CPU-minutes: the reference and the fp64 oracle each run 7 000 iterations over 57 000 matches on one thread).
+
+    `store_matches=False` (round 5: `guided_free_full_s12`, seeds 1 and 2 of the same full-size case) leaves the 57 000 matches out of
+    the file: they are a pure function of the stored `mean_at_first_guided` and the seed (`synth.make_epipolar_matches(mean, 224, 224,
+    per_pair, seed=2000 + s)`, numpy's `default_rng`), so the fixture stores their sha256 instead and `regenerate_matches` rebuilds them."""
     torch.set_num_threads(1)
     ref = RS.load_reference()
     diff = RS.build_reference_diffuser(seed=0)
@@ -319,12 +323,35 @@ def make_guided_free(seeds=(0, 1, 2), N=8, cond_start=3, per_pair=60, name="guid
         dev = float(((pose32.double() - pose64).abs().max() / pose64.abs().max()))
         print(f"seed {s}: reference ran {n_it} GGS_optimize calls to completion; |pose| max {float(pose64.abs().max()):.2f}; ref32 vs fp64 {dev:.3e}; "
               f"final mean Sampson ref32 {sam['32'][0]:.6f} ({sam['32'][1]} valid), fp64 {sam['64'][0]:.6f} ({sam['64'][1]} valid)")
-        out.update({f"s{s}_z": z.numpy(), f"s{s}_noise": noise, f"s{s}_kp1": md["kp1"], f"s{s}_kp2": md["kp2"], f"s{s}_i12": md["i12"],
+        if store_matches:
+            out.update({f"s{s}_kp1": md["kp1"], f"s{s}_kp2": md["kp2"], f"s{s}_i12": md["i12"]})
+        else:
+            out[f"s{s}_matches_sha256"] = np.frombuffer(matches_digest(md), dtype=np.uint8)
+        out.update({f"s{s}_z": z.numpy(), f"s{s}_noise": noise,
                     f"s{s}_pose32": pose32.numpy(), f"s{s}_pose64": pose64.detach().numpy(), f"s{s}_mean_at_first_guided": mean.numpy(),
                     f"s{s}_sampson32": np.array(sam["32"]), f"s{s}_sampson64": np.array(sam["64"]), f"s{s}_ref_optimize_calls": n_it})
     out["img_shape"] = np.array([N, 3, 224, 224])
+    out["per_pair"] = per_pair
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name + ".npz", os.path.getsize(os.path.join(OUT, name + ".npz")))
+
+
+def matches_digest(md):
+    import hashlib
+    h = hashlib.sha256()
+    for k in ("kp1", "kp2", "i12"):
+        h.update(np.ascontiguousarray(md[k]).tobytes())
+    return h.digest()
+
+
+def regenerate_matches(g, s):
+    """The matches of seed `s` of a `store_matches=False` fixture `g` (a dict of its arrays), rebuilt from the stored model mean and
+    checked against the stored sha256 (a numpy whose default_rng drew differently would fail here, not silently change the case)."""
+    n = int(g["img_shape"][0])
+    md = synth.make_epipolar_matches(g[f"s{s}_mean_at_first_guided"][0].astype(np.float64), 224, 224, int(g["per_pair"]), seed=2000 + s)
+    assert matches_digest(md) == bytes(g[f"s{s}_matches_sha256"]), "regenerated matches differ from the ones the fixture was made with"
+    assert int(md["img_shape"][0]) == n
+    return md
 
 
 def make_pred_x0():
@@ -384,6 +411,8 @@ if __name__ == "__main__":
         make_guided_free()      # only the free-running GGS-on fixture
     elif len(sys.argv) > 1 and sys.argv[1] == "guided_free_full":
         make_guided_free(seeds=(0,), N=20, cond_start=10, per_pair=300, name="guided_free_full")   # configs[2] at real size
+    elif len(sys.argv) > 1 and sys.argv[1] == "guided_free_full_s12":
+        make_guided_free(seeds=(1, 2), N=20, cond_start=10, per_pair=300, name="guided_free_full_s12", store_matches=False)
     elif len(sys.argv) > 1 and sys.argv[1] == "metrics":
         make_metrics()          # only the N3 fixture (the others stay byte-identical)
     elif len(sys.argv) > 1 and sys.argv[1] == "preprocess":

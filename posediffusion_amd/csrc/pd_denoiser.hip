@@ -23,6 +23,7 @@
 #include "pd_denoiser_dev.h"
 #include "pd_gemm_stream.h"
 #include "pd_gemm_split.h"
+#include "pd_qkv_attn.h"
 #ifndef PD_STRIP_K64
 #define PD_STRIP_K64 true      // the strip GEMMs of the fp16-plane mode: A chunks of 64 k per barrier (pd_gemm_split.h)
 #endif
@@ -54,7 +55,7 @@ __global__ void pd_repack_kernel(const float *__restrict__ W, int Nout, int K, i
             n = nt * 16 + (l & 15);
             k = kc * 16 + 4 * (l >> 4) + e;
         }
-        if (first_perm) k = pd_first_col(k);
+        if (first_perm) k = pd_first_col(first_perm, k);      // a piece of _first (PD_FIRST_D / PD_FIRST_Z): its column of the reference weight
         float v = (n < Nout && k < K) ? W[(size_t)n * K + k] : 0.0f;
         if (colscale && k < K) v *= colscale[k];
         Wp[idx] = v;
@@ -71,22 +72,18 @@ __global__ void pd_fold_bias_kernel(const float *__restrict__ W, const float *__
     out[n] = b[n] + a;
 }
 
-// _first's input rows for the streamed path (>= PD_STREAM_MIN_ROWS token rows): [z | t_emb | harmonic(x) | x | pivot | 0 0] in the
-// engine's column order (pd_first_col), one wave per row, written once per step and read by pd_gemm_stream like any activation
-// (denoiser.py:56-68; the same expressions as the AMODE 2 staging of pd_gemm_kernel).
-__global__ __launch_bounds__(256) void pd_embed_rows_kernel(const float *__restrict__ x, const float *__restrict__ z,
-                                                            const float *__restrict__ temb, int n_frames, int M, float *__restrict__ out) {
+// _first's STEP rows for the streamed path (>= PD_STREAM_MIN_ROWS token rows): [harmonic(x) (180) | x (9) | pivot | 0 0] = KFIRST_D
+// columns (piece PD_FIRST_D of pd_denoiser_dev.h), one wave per row, written once per step and read by pd_gemm_dma like any activation
+// (denoiser.py:60-68; the same expressions as the AMODE 2 staging of pd_gemm_kernel).  z and t_emb never enter the loop: their products
+// are hoisted (pd_denoiser_prepare, pd_first_ttab_kernel).
+__global__ __launch_bounds__(256) void pd_embed_rows_kernel(const float *__restrict__ x, int n_frames, int M, float *__restrict__ out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
-    float4 *dst = (float4 *)(out + (size_t)row * KFIRST_PAD);
-    const float4 *zr = (const float4 *)(z + (size_t)row * ZD), *te = (const float4 *)temb;
-    dst[lane] = zr[lane];                                       // z: 96 float4
-    if (lane < 32) dst[64 + lane] = zr[64 + lane];
-    else dst[64 + lane] = te[lane - 32];                        // t_emb: 32 float4 at [96, 128)
+    float4 *dst = (float4 *)(out + (size_t)row * KFIRST_D);
     float xv[9];
 #pragma unroll
     for (int d = 0; d < 9; ++d) xv[d] = x[(size_t)row * 9 + d];
-    if (lane < 45) {                                            // harmonic: 180 values = 45 float4 at [128, 173)
+    if (lane < 45) {                                            // harmonic: 180 values = 45 float4 at [0, 45)
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -97,21 +94,32 @@ __global__ __launch_bounds__(256) void pd_embed_rows_kernel(const float *__restr
             const float a = xd * (float)(1 << kk);
             o[e] = sinf(s ? a + 1.5707963267948966f : a);
         }
-        dst[128 + lane] = make_float4(o[0], o[1], o[2], o[3]);
+        dst[lane] = make_float4(o[0], o[1], o[2], o[3]);
     } else if (lane == 45) {
-        dst[173] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+        dst[45] = make_float4(xv[0], xv[1], xv[2], xv[3]);
     } else if (lane == 46) {
-        dst[174] = make_float4(xv[4], xv[5], xv[6], xv[7]);
+        dst[46] = make_float4(xv[4], xv[5], xv[6], xv[7]);
     } else if (lane == 47) {
-        dst[175] = make_float4(xv[8], (row % n_frames == 0) ? 1.0f : 0.0f, 0.0f, 0.0f);   // pivot one-hot on frame 0, padding
+        dst[47] = make_float4(xv[8], (row % n_frames == 0) ? 1.0f : 0.0f, 0.0f, 0.0f);   // pivot one-hot on frame 0, padding
     }
 }
-// W_first [512, 702] -> row-major [512, 704] in the engine's column order
-__global__ void pd_first_rowmajor_kernel(const float *__restrict__ W, float *__restrict__ Wf) {
+// a piece of W_first [512, 702] -> row-major [512, Kdst] in the engine's column order of that piece (pd_first_col)
+__global__ void pd_first_rowmajor_kernel(const float *__restrict__ W, float *__restrict__ Wf, int piece, int Kdst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= DM * KFIRST_PAD) return;
-    const int n = idx / KFIRST_PAD, k = pd_first_col(idx - n * KFIRST_PAD);
+    if (idx >= DM * Kdst) return;
+    const int n = idx / Kdst, k = pd_first_col(piece, idx - n * Kdst);
     Wf[idx] = k < KFIRST ? W[(size_t)n * KFIRST + k] : 0.0f;
+}
+// the time piece of _first: ttab[t][n] = sum_k W_first[n][189 + k] t_emb(t)[k], an fmaf chain over the 128 columns (one block per t)
+__global__ __launch_bounds__(DM) void pd_first_ttab_kernel(const float *__restrict__ W, const float *__restrict__ t_table, float *__restrict__ ttab) {
+    __shared__ float te[128];
+    const int t = blockIdx.x, n = threadIdx.x;
+    if (n < 128) te[n] = t_table[(size_t)t * 128 + n];
+    __syncthreads();
+    const float *w = W + (size_t)n * KFIRST + pd_first_col(PD_FIRST_T, 0);
+    float a = 0.0f;
+    for (int k = 0; k < 128; ++k) a = fmaf(te[k], w[k], a);
+    ttab[(size_t)t * DM + n] = a;
 }
 
 // time-step embedding (util/embedding.py:28-37) of one timestep value t: 128 threads, thread i owns output i
@@ -171,16 +179,18 @@ __global__ void pd_harmonic_rows_kernel(const float *__restrict__ x, long long r
 // fused 32x32-tile GEMM:  C[m, n] = epi( sum_k A'[m, k] * W[n, k] + bias[n] )
 //   AMODE 0: A' = A                      (plain rows of a [M, K] activation)
 //   AMODE 1: A' = LayerNorm(A) (K = 512) (norm_first encoder layer, eps 1e-5)
-//   AMODE 2: A' = [harmonic(x) | t_emb | z | pivot | 0 0]  (K = 704, denoiser.py:56-68)
-//   EPI   0: + bias     1: relu(+ bias)     2: + bias + residual (in place on C)
+//   AMODE 2: A' = [harmonic(x) | x | pivot | 0 0]  (K = 192: the step piece of _first, denoiser.py:60-68; pd_denoiser_dev.h)
+//   EPI   0: + bias     1: relu(+ bias)     2: + bias + residual (in place on C)     3: + bias + R (another [M, Nout] array: _first's
+//         hoisted z piece; the bias is the step's row of the time table)
 // --------------------------------------------------------------------------------------------
 struct GemmArgs {
     const float *A;        // [M, K] (AMODE 0/1)
     const float *Wp;       // packed weights
     const float *bias;     // [Nout]
     float *C;              // [M, Nout]
+    const float *R;        // [M, Nout] (EPI 3)
     // AMODE 2
-    const float *x, *z, *temb;   // x [M,9], z [M,384], temb [128] (row of the table for this t)
+    const float *x;        // x [M,9]
     int n_frames;
     int M, Nout;
     int MT;                // number of 32-row M tiles (XCD-aware block mapping)
@@ -227,30 +237,12 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
         const int mr = live ? m : g.M - 1;   // clamp: padded rows load a valid row and are zeroed
         float *dst = As + r * LDA;
         if constexpr (AMODE == 2) {
-            // engine column order (pd_first_col): z | t_emb | harmonic | x | pivot | pad
-            const float4 *zr = (const float4 *)(g.z + (size_t)mr * ZD);
-            const float4 *te = (const float4 *)g.temb;
-            float4 zv[ZD / 32], tv[4];
-#pragma unroll
-            for (int i = 0; i < ZD / 32; ++i) zv[i] = zr[sub + 8 * i];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tv[i] = te[sub + 8 * i];
+            // the step piece of _first in the engine's column order (pd_first_col, PD_FIRST_D): harmonic | x | pivot | pad
+            static_assert(AMODE != 2 || K == KFIRST_D, "the embedding staging is built for the 192-column step piece");
             float xv[9];
 #pragma unroll
             for (int d = 0; d < 9; ++d) xv[d] = g.x[(size_t)mr * 9 + d];
             const float keep = live ? 1.0f : 0.0f;
-#pragma unroll
-            for (int i = 0; i < ZD / 32; ++i) {
-                float4 v = zv[i];
-                v.x *= keep; v.y *= keep; v.z *= keep; v.w *= keep;
-                *(float4 *)(dst + 4 * (sub + 8 * i)) = v;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4 v = tv[i];
-                v.x *= keep; v.y *= keep; v.z *= keep; v.w *= keep;
-                *(float4 *)(dst + 384 + 4 * (sub + 8 * i)) = v;
-            }
             // harmonic embedding: idx = s*90 + d*10 + k -> sin(x_d * 2^k + s * pi/2)  (pytorch3d 0.7.x)
             for (int idx = sub; idx < 180; idx += 8) {
                 const int s = idx / 90, rem = idx - s * 90, d = rem / 10, kk = rem - d * 10;
@@ -258,14 +250,14 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int q = 1; q < 9; ++q) xd = (d == q) ? xv[q] : xd;
                 const float e = xd * (float)(1 << kk);
-                dst[512 + idx] = keep * sinf(s ? e + 1.5707963267948966f : e);
+                dst[idx] = keep * sinf(s ? e + 1.5707963267948966f : e);
             }
             if (sub == 0) {
 #pragma unroll
-                for (int d = 0; d < 9; ++d) dst[692 + d] = keep * xv[d];
-                dst[701] = (live && (m % g.n_frames == 0)) ? 1.0f : 0.0f;   // pivot one-hot on frame 0
-                dst[702] = 0.0f;
-                dst[703] = 0.0f;
+                for (int d = 0; d < 9; ++d) dst[180 + d] = keep * xv[d];
+                dst[189] = (live && (m % g.n_frames == 0)) ? 1.0f : 0.0f;   // pivot one-hot on frame 0
+                dst[190] = 0.0f;
+                dst[191] = 0.0f;
             }
         } else if constexpr (AMODE == 1) {
             // LayerNorm without affine: gamma is folded into the packed weights, beta into the bias
@@ -298,7 +290,8 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
             const float4 *src = (const float4 *)(g.A + (size_t)mr * K);
             const float keep = live ? 1.0f : 0.0f;
             constexpr int NV = K / 32;
-            constexpr int VB = 16;        // loads in flight per pass
+            constexpr int VB = NV < 16 ? NV : 16;        // loads in flight per pass
+            static_assert(NV % VB == 0, "passes of VB float4 per thread");
 #pragma unroll
             for (int i0 = 0; i0 < NV; i0 += VB) {
                 float4 v[VB];
@@ -385,6 +378,7 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
             float *cp = g.C + (size_t)row * g.Nout + col;
             if constexpr (EPI == 1) v = pd_relu(v);
             if constexpr (EPI == 2) v += *cp;
+            if constexpr (EPI == 3) v += g.R[(size_t)row * g.Nout + col];
             *cp = v;
         }
     }
@@ -802,7 +796,8 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     }
     for (int v = 0; v < 2; ++v) {   // v = 0: 32-wide tiles, v = 1: 16-wide tiles
         const int nt = v ? 16 : 32;
-        PD_TRY(dev_pack(d, &d->first_wp[v], w->first_w, DM, KFIRST, KFIRST_PAD, nt, 1));
+        PD_TRY(dev_pack(d, &d->first_dp[v], w->first_w, DM, KFIRST, KFIRST_D, nt, PD_FIRST_D));
+        PD_TRY(dev_pack(d, &d->first_zp[v], w->first_w, DM, KFIRST, ZD, nt, PD_FIRST_Z));
         PD_TRY(dev_pack(d, &d->last0_wp[v], w->last0_w, HID, DM, DM, nt));
         for (int l = 0; l < w->num_layers; ++l) {
             const pd_layer_weights &s = w->layers[l];
@@ -845,13 +840,22 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     if (rows >= PD_STREAM_MIN_ROWS) PD_TRY(dev_alloc(d, &d->hn, rows * DM));
     // _first's input rows (materialised by pd_embed_rows_kernel on the streamed path, formerly also by the parked persistent kernel) and the
     // row-major _first / _last.0 the two paths pack from
-    PD_TRY(dev_alloc(d, &d->emb, rows * KFIRST_PAD));
-    PD_TRY(dev_alloc(d, &d->first_wf, (size_t)DM * KFIRST_PAD));
-    hipLaunchKernelGGL(pd_first_rowmajor_kernel, dim3((DM * KFIRST_PAD + 255) / 256), dim3(256), 0, 0, w->first_w, d->first_wf);
+    PD_TRY(dev_alloc(d, &d->emb, rows * KFIRST_D));
+    PD_TRY(dev_alloc(d, &d->zproj, rows * DM));
+    PD_TRY(dev_alloc(d, &d->first_df, (size_t)DM * KFIRST_D));
+    PD_TRY(dev_alloc(d, &d->first_zf, (size_t)DM * ZD));
+    hipLaunchKernelGGL(pd_first_rowmajor_kernel, dim3((DM * KFIRST_D + 255) / 256), dim3(256), 0, 0, w->first_w, d->first_df, PD_FIRST_D, KFIRST_D);
+    hipLaunchKernelGGL(pd_first_rowmajor_kernel, dim3((DM * ZD + 255) / 256), dim3(256), 0, 0, w->first_w, d->first_zf, PD_FIRST_Z, ZD);
+    PD_HIP_CHECK(hipGetLastError());
+    // the time piece of _first for every step: ttab[t] = W_t t_emb(t)
+    PD_TRY(dev_alloc(d, &d->ttab, (size_t)w->timesteps * DM));
+    hipLaunchKernelGGL(pd_first_ttab_kernel, dim3(w->timesteps), dim3(DM), 0, 0, w->first_w, d->t_table, d->ttab);
     PD_HIP_CHECK(hipGetLastError());
     PD_TRY(dev_rowmajor(d, &d->last0_wf, w->last0_w, HID, DM, nullptr));
-    PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0, 32>, 32 * (KFIRST_PAD + 4) * 4));
-    PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0, 16>, 32 * (KFIRST_PAD + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<KFIRST_D, 2, 3, 32>, 32 * (KFIRST_D + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<KFIRST_D, 2, 3, 16>, 32 * (KFIRST_D + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<ZD, 0, 0, 32>, 32 * (ZD + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<ZD, 0, 0, 16>, 32 * (ZD + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 0, 32>, 32 * (DM + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 0, 16>, 32 * (DM + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 1, 32>, 32 * (DM + 4) * 4));
@@ -868,6 +872,7 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(set_lds(pd_attn_seq_kernel<1>, attn_seq_lds(64)));
     PD_TRY(set_lds(pd_attn_seq_kernel<2>, attn_seq_lds(64)));
     PD_TRY(set_lds(pd_attn_mma_kernel<2>, attn_mma_lds(32)));
+    PD_TRY(set_lds(pd_qkv_attn_kernel, 160 * 1024));
     PD_HIP_CHECK(hipDeviceSynchronize());
     return PD_OK;
 }
@@ -1029,27 +1034,54 @@ static void launch_gemm(GemmArgs &g, float *const wp[2], int MT, int wide_min, h
     }
 }
 
+// The step-invariant piece of _first (models/denoiser.py:56-70: z and the pivot flag do not change over the T steps; here the z columns):
+// zproj[m] = z[m] W_z^T + b_first, once per sampling call.  Every step then adds its row of the time table and its 192-column GEMM.
+int pd_denoiser_prepare(pd_engine *eng, const float *z, int B, int N, hipStream_t s) {
+    PdDenoiserDev *d = eng->den;
+    if (!z || B <= 0 || N <= 0 || B > eng->max_B || N > eng->max_N) {
+        pd_set_error("denoiser: invalid arguments (B=%d N=%d; max_B=%d max_N=%d)", B, N, eng->max_B, eng->max_N);
+        return PD_ERR_INVALID_ARG;
+    }
+    const int M = B * N;
+    if (M >= PD_STREAM_MIN_ROWS && d->hn) {
+        pd_gemm_dma<0>(z, ZD, d->first_zf, ZD, d->first_b, d->zproj, M, DM, s);
+    } else {
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.M = M; g.A = z; g.bias = d->first_b; g.C = d->zproj; g.Nout = DM;
+        launch_gemm<ZD, 0, 0>(g, d->first_zp, (M + 31) / 32, eng->gemm_wide_min_tiles, s);
+    }
+    PD_HIP_CHECK(hipGetLastError());
+    return PD_OK;
+}
+
+// z_prepared: pd_denoiser_prepare ran for this z (the sampling loop calls it once); otherwise it is issued here (the step-level API)
 int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, int B, int N, float *eps_out,
-                       float *mean_out, float *x0_out, const float *noise, float *x_next_out, hipStream_t s) {
+                       float *mean_out, float *x0_out, const float *noise, float *x_next_out, hipStream_t s, bool z_prepared) {
     PdDenoiserDev *d = eng->den;
     if (!x || !z || B <= 0 || N <= 0 || B > eng->max_B || N > eng->max_N || N > 64 || t < 0 || t >= d->timesteps) {
         pd_set_error("denoiser: invalid arguments (B=%d N=%d t=%d; max_B=%d max_N=%d, N <= 64, 0 <= t < %d)", B, N, t,
                      eng->max_B, eng->max_N, d->timesteps);
         return PD_ERR_INVALID_ARG;
     }
+    if (!z_prepared) {
+        int rc = pd_denoiser_prepare(eng, z, B, N, s);
+        if (rc) return rc;
+    }
     const int M = B * N, MT = (M + 31) / 32;
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.M = M;
     const bool streamed = M >= PD_STREAM_MIN_ROWS && d->hn;
+    // _first = zproj (z piece + bias, hoisted) + ttab[t] (time piece, a table) + the step piece, K = 192
     if (streamed) {
-        hipLaunchKernelGGL(pd_embed_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, z, d->t_table + (size_t)t * 128, N, M, d->emb);
-        pd_gemm_dma<0>(d->emb, KFIRST_PAD, d->first_wf, KFIRST_PAD, d->first_b, d->h, M, DM, s);
+        hipLaunchKernelGGL(pd_embed_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, N, M, d->emb);
+        pd_gemm_dma<4>(d->emb, KFIRST_D, d->first_df, KFIRST_D, d->ttab + (size_t)t * DM, d->h, M, DM, s, nullptr, d->zproj);
     } else {
-        // _first with the embedding fused into the A staging
-        g.bias = d->first_b; g.C = d->h; g.Nout = DM;
-        g.x = x; g.z = z; g.temb = d->t_table + (size_t)t * 128; g.n_frames = N;
-        launch_gemm<KFIRST_PAD, 2, 0>(g, d->first_wp, MT, eng->gemm_wide_min_tiles, s);
+        // ... with the pose embedding fused into the A staging
+        g.bias = d->ttab + (size_t)t * DM; g.C = d->h; g.Nout = DM; g.R = d->zproj;
+        g.x = x; g.n_frames = N;
+        launch_gemm<KFIRST_D, 2, 3>(g, d->first_dp, MT, eng->gemm_wide_min_tiles, s);
     }
     // >= 1024 token rows (52 sequences of 20 frames): the encoder GEMMs are large enough for 64 x 64 tiles streamed through LDS
     // (pd_gemm_stream.h; same sums in another order than the 32-row split-K tiles below, i.e. rounding-level differences
@@ -1064,11 +1096,17 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
             // bitwise the same results (tools/split3_probe.hip).  PD_DEN_STRIP = bit mask {QKV, out, FF1, FF2} (development A / B)
             static const int strip = pd_dev_knob("PD_DEN_STRIP", 15);
             hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 2>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 512.0f);
-            if (strip & 1) pd_gemm_strip<0, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->hn, DM, L.qkv_wh, DM, L.qkv_b, d->qkv, M, 3 * DM, s, L.qkv_cs);
-            else pd_gemm_split<0, 1, 2, true>((const unsigned *)d->hn, DM, L.qkv_wh, DM, L.qkv_b, d->qkv, M, 3 * DM, s, L.qkv_cs);
             static const int attn_mma = pd_dev_knob("PD_DEN_ATTN_MMA", 1);     // development A / B
-            if (N <= 32 && attn_mma) hipLaunchKernelGGL(pd_attn_mma_kernel<2>, dim3(B * NH), dim3(256), attn_mma_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
-            else hipLaunchKernelGGL(pd_attn_seq_kernel<2>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
+            if (N <= 32 && eng->den_fused_attn) {
+                // in_proj + attention of a head for a group of whole sequences in one workgroup, Q / K / V in LDS only (pd_qkv_attn.h):
+                // bitwise the two launches of the else branch
+                pd_qkv_attn((const unsigned *)d->hn, L.qkv_wh, L.qkv_b, (unsigned *)d->ctx, B, N, L.qkv_cs, L.ctx_scale, s);
+            } else {
+                if (strip & 1) pd_gemm_strip<0, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->hn, DM, L.qkv_wh, DM, L.qkv_b, d->qkv, M, 3 * DM, s, L.qkv_cs);
+                else pd_gemm_split<0, 1, 2, true>((const unsigned *)d->hn, DM, L.qkv_wh, DM, L.qkv_b, d->qkv, M, 3 * DM, s, L.qkv_cs);
+                if (N <= 32 && attn_mma) hipLaunchKernelGGL(pd_attn_mma_kernel<2>, dim3(B * NH), dim3(256), attn_mma_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
+                else hipLaunchKernelGGL(pd_attn_seq_kernel<2>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
+            }
             if (strip & 2) pd_gemm_strip<2, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
             else pd_gemm_split<2, 1, 1, true>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
             hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 2>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 512.0f);

@@ -14,16 +14,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DFF 1024        // feed-forward dim
 #define ZD 384          // z_dim
 #define KFIRST 702      // 189 + 128 + 384 + 1   (denoiser.py:39)
-#define KFIRST_PAD 704
-// The engine permutes the K axis of _first so the wide pieces land 16-byte aligned in LDS:
-//   engine column k' : [0,384) z | [384,512) t_emb | [512,692) harmonic | [692,701) x | 701 pivot | 702,703 pad
+// `_first` (denoiser.py:56-70) is evaluated in THREE pieces (round 5): of its 702 input columns only the 189 pose-embedding columns
+// change from one diffusion step to the next --
 //   reference column : [0,180) harmonic | [180,189) x | [189,317) t_emb | [317,701) z | 701 pivot  (denoiser.py:68)
-__host__ __device__ inline int pd_first_col(int kp) {
-    if (kp < 384) return 317 + kp;
-    if (kp < 512) return 189 + (kp - 384);
-    if (kp < 692) return kp - 512;
-    if (kp < 701) return 180 + (kp - 692);
-    return kp;   // 701 pivot; 702/703 are padding (>= KFIRST -> zero)
+//   PD_FIRST_Z   z columns [317,701), K = 384: zproj[m] = z[m] W_z^T + b_first, ONCE per sampling call (z is the same in all T steps)
+//   PD_FIRST_T   t_emb columns [189,317): a [T, 512] table W_t t_emb(t), built at engine creation (t_emb depends on t only)
+//   PD_FIRST_D   the step's own columns in the engine's order [0,180) harmonic | [180,189) x | 189 pivot | 190,191 pad: K = 192
+// so a step's `_first` is h = zproj + ttab[t] + D W_d^T: K 704 -> 192 inside the loop.
+#define PD_FIRST_D 1
+#define PD_FIRST_Z 2
+#define PD_FIRST_T 3
+#define KFIRST_D 192
+// column of the reference's _first.weight behind column kp of piece `piece` (>= KFIRST: padding -> zero)
+__host__ __device__ inline int pd_first_col(int piece, int kp) {
+    if (piece == PD_FIRST_Z) return kp < ZD ? 317 + kp : KFIRST;
+    if (piece == PD_FIRST_T) return kp < 128 ? 189 + kp : KFIRST;
+    if (kp < 189) return kp;
+    return kp == 189 ? 701 : KFIRST;   // pivot; 190 / 191 are padding
 }
 #define HID 128         // mlp_hidden_dim
 
@@ -44,13 +51,15 @@ struct PdLayerDev {          // [0] = 32-wide-tile packing, [1] = 16-wide-tile p
 struct PdDenoiserDev {
     int num_layers = 0, timesteps = 0, m_cap = 0;
     float *t_table = nullptr;          // [T,128] time embeddings
-    float *first_wp[2] = {nullptr, nullptr}, *first_b = nullptr;
+    float *first_dp[2] = {nullptr, nullptr}, *first_zp[2] = {nullptr, nullptr}, *first_b = nullptr;   // _first's step piece (K = 192) and z piece (K = 384), packed
+    float *ttab = nullptr;             // [T, 512] = W_t t_emb(t): the time piece of _first, added as the step GEMM's bias
+    float *zproj = nullptr;            // [rows, 512] = z W_z^T + b_first of the sampling call in flight (pd_denoiser_prepare)
     PdLayerDev layers[PD_MAX_LAYERS];
     float *last0_wp[2] = {nullptr, nullptr}, *last0_b = nullptr, *last_ln_w = nullptr, *last_ln_b = nullptr;
     float *last3_w = nullptr, *last3_b = nullptr;   // [9,128] plain
     float *h = nullptr, *qkv = nullptr, *ctx = nullptr, *ff = nullptr, *hid = nullptr;   // activations [rows, .]
     float *hn = nullptr;               // LayerNorm(h) without affine, streamed path only
-    float *emb = nullptr, *first_wf = nullptr, *last0_wf = nullptr;   // streamed path: _first's input rows [rows, 704], row-major _first / _last.0 weights
+    float *emb = nullptr, *first_df = nullptr, *first_zf = nullptr, *last0_wf = nullptr;   // streamed path: _first's step rows [rows, 192], row-major _first pieces / _last.0 weights
     bool split_ready = false;          // the fast mode's split weights exist
     bool split_h_ready = false;        // the fp16-plane mode's weights exist
     bool scales_ready = false;         // the fp16-plane scales exist (pd_denoiser_build_scales)

@@ -279,6 +279,10 @@ static int issue_loop(pd_engine *eng, int B, int N, int cond_start, const pd_ggs
     const int T = eng->timesteps;
     const size_t bn9 = (size_t)B * N * 9;
     float *proc = eng->d_process;
+    // the z piece of _first once per call (z is the same in every step, models/denoiser.py:56-70); the guided half of a split call
+    // recomputes it (one GEMM) instead of relying on what the engine's buffer held last
+    int rc0 = pd_denoiser_prepare(eng, eng->d_z, B, N, s);
+    if (rc0) return rc0;
     for (int step = step_begin; step < step_end; ++step) {
         const int t = T - 1 - step;                               // reversed(range(T))  :296
         const float *x = proc + (size_t)step * bn9;
@@ -287,13 +291,13 @@ static int issue_loop(pd_engine *eng, int B, int N, int cond_start, const pd_ggs
         int rc;
         if (guided) {
             // mean -> next slot, GGS refines it in place, noise = 0  (:272-276)
-            rc = pd_denoiser_launch(eng, x, eng->d_z, t, B, N, nullptr, nullptr, nullptr, nullptr, xn, s);
+            rc = pd_denoiser_launch(eng, x, eng->d_z, t, B, N, nullptr, nullptr, nullptr, nullptr, xn, s, true);
             if (rc) return rc;
             float *st = want_stats ? eng->d_stats + (size_t)(cond_start - 1 - t) * B * 5 * 4 : nullptr;
             rc = pd_ggs_guide(eng, xn, B, N, t, ggs, st, s);
         } else {
             const float *nz = (t > 0) ? eng->d_noise + (size_t)(step + 1) * bn9 : nullptr;   // :278
-            rc = pd_denoiser_launch(eng, x, eng->d_z, t, B, N, nullptr, nullptr, nullptr, nz, xn, s);
+            rc = pd_denoiser_launch(eng, x, eng->d_z, t, B, N, nullptr, nullptr, nullptr, nz, xn, s, true);
         }
         if (rc) return rc;
     }
@@ -352,7 +356,7 @@ extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *nois
         key.cond_start = has_ggs ? cond_start_step : 0;
         key.has_ggs = has_ggs;
         key.phase = phase;
-        key.den_split = eng->den_split;      // the option changes the captured launches
+        key.den_split = eng->den_split | (eng->den_fused_attn << 8);      // the options change the captured launches
         if (has_ggs) {
             key.cfg = *ggs;
             // the GGS nodes bake the match-derived launch shape in: a re-upload with another item count must not
@@ -438,6 +442,13 @@ extern "C" int pd_engine_set_option(pd_engine *eng, int option, int value) {
         }
         eng->den_split = value;
         break;
+    case PD_OPT_DENOISER_FUSED_ATTN:
+        if (value != 0 && value != 1) {
+            pd_set_error("pd_engine_set_option: PD_OPT_DENOISER_FUSED_ATTN takes 0 or 1 (got %d)", value);
+            return PD_ERR_INVALID_ARG;
+        }
+        eng->den_fused_attn = value;
+        break;
     case 3:      // (PD_OPT_DENOISER_PERSISTENT of round 3: the persistent small-batch kernel was measured 2.4 x slower and parked, tools/parked/)
         if (value == 0) break;
         pd_set_error("pd_engine_set_option: option 3 (the persistent small-batch denoiser launch of round 3) is no longer built: it measured "
@@ -457,6 +468,7 @@ extern "C" int pd_engine_get_option(pd_engine *eng, int option, int *value_out) 
     }
     switch (option) {
     case PD_OPT_DENOISER_SPLIT: *value_out = eng->den_split; break;
+    case PD_OPT_DENOISER_FUSED_ATTN: *value_out = eng->den_fused_attn; break;
     case PD_OPT_WEIGHTS_NON_FINITE: *value_out = pd_denoiser_weights_non_finite(eng) ? 1 : 0; break;
     default:
         pd_set_error("pd_engine_get_option: unknown option %d", option);
@@ -480,10 +492,11 @@ extern "C" int pd_time_kernel(pd_engine *eng, int what, int B, int N, const pd_g
     int rc = PD_OK;
     // inputs: whatever the sampler buffers currently hold (process slot 0 = a pose sample, d_z)
     if (what == 0) {
-        rc = pd_denoiser_launch(eng, eng->d_process, eng->d_z, 50, B, N, nullptr, eng->d_mean, nullptr, nullptr, nullptr, s);
+        // a step as the sampling loop runs it: the z piece of _first prepared once, outside the timed launches
+        rc = pd_denoiser_launch(eng, eng->d_process, eng->d_z, 50, B, N, nullptr, eng->d_mean, nullptr, nullptr, nullptr, s, false);
         PD_HIP_CHECK(hipEventRecord(e0, s));
         for (int i = 0; i < reps && !rc; ++i)
-            rc = pd_denoiser_launch(eng, eng->d_process, eng->d_z, 50, B, N, nullptr, eng->d_mean, nullptr, nullptr, nullptr, s);
+            rc = pd_denoiser_launch(eng, eng->d_process, eng->d_z, 50, B, N, nullptr, eng->d_mean, nullptr, nullptr, nullptr, s, true);
         PD_HIP_CHECK(hipEventRecord(e1, s));
     } else {
         if ((rc = check_cfg(cfg, "pd_time_kernel"))) return rc;

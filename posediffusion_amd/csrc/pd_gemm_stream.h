@@ -110,12 +110,14 @@ static __global__ void pd_scale_cols_kernel(const float *__restrict__ W, const f
 //   C[m, n] = epi( sum_k A[m, k] W[n, k] + bias[n] ): a (64 WM) x (64 WN) tile per workgroup, one (32 WM) x (32 WN) quadrant
 //   per wave over the whole K; A and W (both row-major, k contiguous) stream through LDS in 32-deep chunks, double buffered
 //   with a register stage.  Blocks walk groups of ~2048 rows x all column tiles, so that a group's A rows and the whole W
-//   stay in the L2s.  EPI 0: + bias   1: relu(+ bias)   2: + bias + C (residual, in place)   3: gelu(+ bias), exact erf form.
+//   stay in the L2s.  EPI 0: + bias   1: relu(+ bias)   2: + bias + C (residual, in place)   3: gelu(+ bias), exact erf form
+//   4 (pd_gemm_dma_kernel only): + bias + R (another [M, Nout] array).
 struct PdStreamArgs {
     const float *A, *W, *bias;
     float *C;
     int M, Nout, K, lda, ldw;
     const float2 *ln_stats;   // ALN only: (mean, rstd) of every A row (pd_ln_stats_kernel)
+    const float *R;           // EPI 4 only: [M, Nout] added to the result (the hoisted z piece of the denoiser's _first)
 };
 #define PD_STREAM_KC 32
 #define PD_STREAM_LR (PD_STREAM_KC + 4)      // LDS row stride: fragment reads and staging writes both conflict free
@@ -390,9 +392,10 @@ __global__ __launch_bounds__(256) void pd_gemm_dma_kernel(PdStreamArgs g) {
             const int col = n0 + (wn * WN + ni) * 32 + l31, r0 = m0 + (wm * WM + mi) * 32 + 4 * hi;
             const float bias = g.bias[col];
             float res[16];
-            if constexpr (EPI == 2) {
+            if constexpr (EPI == 2 || EPI == 4) {
+                const float *rsrc = EPI == 2 ? g.C : g.R;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) res[i] = g.C[(size_t)min(r0 + (i & 3) + 8 * (i >> 2), g.M - 1) * g.Nout + col];
+                for (int i = 0; i < 16; ++i) res[i] = rsrc[(size_t)min(r0 + (i & 3) + 8 * (i >> 2), g.M - 1) * g.Nout + col];
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(256) void pd_gemm_dma_kernel(PdStreamArgs g) {
                 float v = acc[mi][ni][i] + bias;
                 if constexpr (EPI == 1) v = pd_relu(v);
                 if constexpr (EPI == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                if constexpr (EPI == 2) v += res[i];
+                if constexpr (EPI == 2 || EPI == 4) v += res[i];
                 if (row < g.M) g.C[(size_t)row * g.Nout + col] = v;
             }
         }
@@ -408,8 +411,8 @@ __global__ __launch_bounds__(256) void pd_gemm_dma_kernel(PdStreamArgs g) {
 
 template <int EPI, bool ALN = false, int WM = 1, int WN = 1>
 static inline void pd_gemm_dma(const float *A, int lda, const float *W, int K, const float *bias, float *C, int M, int Nout, hipStream_t s,
-                               const float2 *ln_stats = nullptr) {
-    PdStreamArgs g{A, W, bias, C, M, Nout, K, lda, K, ln_stats};
+                               const float2 *ln_stats = nullptr, const float *R = nullptr) {
+    PdStreamArgs g{A, W, bias, C, M, Nout, K, lda, K, ln_stats, R};
     hipLaunchKernelGGL((pd_gemm_dma_kernel<EPI, ALN, WM, WN>), dim3(((M + 64 * WM - 1) / (64 * WM)) * (Nout / (64 * WN))), dim3(256),
                        (size_t)2 * (64 * WM + 64 * WN) * 32 * sizeof(float), s, g);
 }
@@ -422,7 +425,7 @@ static inline void pd_gemm_dma(const float *A, int lda, const float *W, int K, c
 template <int EPI, bool ALN = false, int WM = 1, int WN = 1>
 static inline void pd_gemm_stream(const float *A, int lda, const float *W, int K, const float *bias, float *C, int M, int Nout, hipStream_t s,
                                   const float2 *ln_stats = nullptr) {
-    PdStreamArgs g{A, W, bias, C, M, Nout, K, lda, K, ln_stats};
+    PdStreamArgs g{A, W, bias, C, M, Nout, K, lda, K, ln_stats, nullptr};
     const size_t lds = (size_t)2 * (64 * WM + 64 * WN) * PD_STREAM_LR * sizeof(float);
     hipLaunchKernelGGL((pd_gemm_stream_kernel<EPI, WM, WN, ALN>), dim3(((M + 64 * WM - 1) / (64 * WM)) * (Nout / (64 * WN))), dim3(256), lds, s, g);
 }

@@ -178,6 +178,7 @@ struct pd_engine {
     size_t xchg_granules = 0;            // per (sequence, slot)
     unsigned int *d_err = nullptr;       // [0] async error word; [2..] debug phase counters
     int ggs_prof_on = 0;
+    int den_fused_attn = 1;          // PD_OPT_DENOISER_FUSED_ATTN: in the fp16-plane mode, in_proj + attention as one kernel with Q / K / V in LDS (N <= 32)
     int den_split = 0;               // PD_OPT_DENOISER_SPLIT: encoder GEMMs of the large-batch path: 0 exact fp32, 1 bf16 planes, 2 fp16 planes (default there)
     int gemm_wide_min_tiles = 200;   // launch_gemm: 32-wide tiles when there are at least this many of them
     float *d_stats_scratch = nullptr;
@@ -216,7 +217,9 @@ bool pd_denoiser_weights_non_finite(const pd_engine *eng);  // the fp16-plane sc
 int pd_denoiser_build_split(pd_engine *eng, int mode);    // 1: bf16 planes (fast mode), 2: fp16 planes with static scales
 // eps_out / mean_out / x_next_out may each be null. noise null => 0.
 int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, int B, int N, float *eps_out,
-                       float *mean_out, float *x0_out, const float *noise, float *x_next_out, hipStream_t s);
+                       float *mean_out, float *x0_out, const float *noise, float *x_next_out, hipStream_t s, bool z_prepared = false);
+// the step-invariant piece of _first for this z (once per sampling call; pd_denoiser_launch(..., z_prepared = true) then skips it)
+int pd_denoiser_prepare(pd_engine *eng, const float *z, int B, int N, hipStream_t s);
 
 // pd_ggs.hip
 int pd_ggs_init();

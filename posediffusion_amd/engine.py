@@ -268,6 +268,10 @@ class PoseEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pd_engine_set_option(self._h, _lib.PD_OPT_DENOISER_SPLIT, int(mode)), "pd_engine_set_option")
 
+    def set_option(self, option: int, value: int):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pd_engine_set_option(self._h, int(option), int(value)), "pd_engine_set_option")
+
     def get_option(self, option: int) -> int:
         """pd_engine_get_option: e.g. ``_lib.PD_OPT_DENOISER_SPLIT`` -> the encoder GEMM mode in force (0 after the non-finite-weights downgrade)."""
         v = C.c_int(0)

@@ -135,6 +135,22 @@ def test_noise_draw_order_matches_reference_protocol():
                 assert torch.equal(a[step + 1], noises[t])
 
 
+def test_ggs_print_lines_include_the_drop_line():
+    """geometry_guided_sampling.py:104-108, :124: a GGS_optimize call that leaves through the `min_matches` break prints the drop line,
+    then -- like every call -- its `t=.. | sampson=..` line.  The engine reports iterations stepped per stage; fewer than given = the break."""
+    import io
+    stats = torch.zeros(2, 5, 4)
+    stats[0, :, 0] = torch.tensor([1.5, 0.25, 3.0, 0.125, 9.75])
+    stats[0, :, 1] = torch.tensor([200.0, 100.0, 37.0, 100.0, 0.0])       # stage 2 broke after 37 iterations, stage 4 at once
+    stats[1, :, 1] = 0.0                                                   # (sequence 1 is not printed: one line per call, as the reference)
+    buf = io.StringIO()
+    host.print_ggs_stats(stats, 7, 100, out=buf)
+    assert buf.getvalue().splitlines() == [
+        "t=07 | sampson=1.500000", "t=07 | sampson=0.250000", "Drop this pair because of insufficient valid matches", "t=07 | sampson=3.000000",
+        "t=07 | sampson=0.125000", "Drop this pair because of insufficient valid matches", "t=07 | sampson=9.750000"]
+    assert host.ggs_stage_iters(100) == (200, 100, 100, 100, 200)
+
+
 def test_partition_covers_everything():
     for n in (1, 7, 8, 64, 65):
         for w in (1, 2, 3, 8):

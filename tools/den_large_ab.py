@@ -28,6 +28,11 @@ def child():
         h = hashlib.sha256(out.numpy().tobytes()).hexdigest()[:16]
         ts = [eng.time_kernel(0, B, N, reps=30) * 1e3 for _ in range(3)]
         print(f"  B={B} ({B * N} rows): step alone {min(ts):7.1f} us (of {[round(t, 1) for t in ts]}); sha256 of one step {h}; finite {bool(torch.isfinite(out).all())}", flush=True)
+        if hasattr(eng.lib, "pd_engine_get_option"):         # round 5: the two-launch attention path of the same library beside the fused kernel
+            eng.set_option(5, 0)
+            out0 = eng.denoise(x.to(dev), z, 40).cpu().contiguous()
+            ts = [eng.time_kernel(0, B, N, reps=30) * 1e3 for _ in range(3)]
+            print(f"      PD_OPT_DENOISER_FUSED_ATTN = 0: step alone {min(ts):7.1f} us; bitwise equal to the fused path: {bool(torch.equal(out0, out))}", flush=True)
         eng.close()
 
 
