@@ -65,7 +65,7 @@ FP32_PEAK_TFLOPS = 157.3             # MI355X fp32 vector ALU = dense fp32 MFMA 
 F16_PEAK_TFLOPS = 2500.0            # dense fp16 / bf16 MFMA peak (same guide; the sparsity figure is never used)
 HBM_PEAK_GBS = 8000.0
 MATCH_BYTES = 16                     # kp1, kp2: 2 x float2 per match (pair indices are per work item)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round4_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round5_pmc_summary.json")
 
 
 # ------------------------------------------------------------------------------------------------------------ inputs
@@ -154,27 +154,33 @@ def lane_stream_fraction(pair_sizes, lanes=512, resident_steps=12):
 
 
 def stream_ceiling():
-    """This box's ceiling for the GGS access pattern: tools/stream_probe (built by __graft_entry__.build()) lets every CU re-read a
-    private 912 KB region -- the match stream of one workgroup per sequence.  -> (min, max) GB/s over its 912 KB rows, or None."""
+    """This box's ceiling for the lane kernel's OWN access pattern (tools/stream_probe.hip, `RING` rows; built by __graft_entry__.build()):
+    one workgroup of 8 waves per CU, every wave streaming its contiguous share of a private region in 2 KiB steps through an LDS ring fed by
+    global_load_lds_dwordx4 (rings of 4 / 6 / 8 steps in flight; 704 KB and 912 KB per CU and pass), with no arithmetic beside it.
+    -> ((min, max) GB/s over those rows, (min, max) over the probe's plain-load 912 KB rows), source text; or (None, reason)."""
     import subprocess
     exe = os.path.join(ROOT, "tools", "stream_probe")
     if not os.path.isfile(exe):
         return None, "tools/stream_probe not built"
     try:
-        txt = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120).stdout
+        txt = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=180).stdout
     except Exception as e:  # noqa: BLE001
         return None, f"tools/stream_probe failed: {e!r}"
-    vals = []
+    ring, plain = [], []
     for line in txt.splitlines():
         f = line.split()
-        if len(f) >= 5 and f[0] == "912" and f[1] == "KB":
-            try:
-                vals.append(float(f[-1]) * 1e3)
-            except ValueError:
-                pass
-    if not vals:
-        return None, "tools/stream_probe printed no 912 KB rows"
-    return (min(vals), max(vals)), "tools/stream_probe on THIS box, after the timed region: 256 workgroups x 912 KB private regions, 2-4 waves per SIMD, 4-8 loads in flight, plain and non-temporal"
+        try:
+            if len(f) >= 5 and f[0] == "RING":
+                ring.append(float(f[-1]) * 1e3)
+            elif len(f) >= 5 and f[0] == "912" and f[1] == "KB":
+                plain.append(float(f[-1]) * 1e3)
+        except ValueError:
+            pass
+    if not ring:
+        return None, "tools/stream_probe printed no RING rows"
+    return ((min(ring), max(ring)), (min(plain), max(plain)) if plain else None), (
+        "tools/stream_probe on THIS box, after the timed region: 256 workgroups x 8 waves, each wave streaming its share of a private 704 / 912 KB "
+        "region through an LDS ring of 4 / 6 / 8 x 2 KiB fed by global_load_lds_dwordx4 -- the lane kernel's own pattern, without its arithmetic")
 
 
 # ------------------------------------------------------------------------------------------------------------ CPU baseline
@@ -284,7 +290,7 @@ def measure_config(diff, dev, B, n_frames, img, ggs_on, reps=3):
     from posediffusion_amd.host import denoiser_state
     eng = PoseEngine(denoiser_state(diff.model), {k: v for k, v in diff.named_buffers(recurse=False)}, device=dev, max_B=B,
                      max_N=n_frames)
-    z, noise, _ = make_batch_inputs(eng, diff, B, dev, seed0=7000, n_frames=n_frames, img=img, upload=ggs_on)
+    z, noise, mds = make_batch_inputs(eng, diff, B, dev, seed0=7000, n_frames=n_frames, img=img, upload=ggs_on, keep_host=(ggs_on and B == 1))
     cfg = make_ggs_cfg(synth.GGS_CFG) if ggs_on else None
     cs = COND_START if ggs_on else 0
     eng.sample(z, noise, cs, cfg, use_graph=True, want_process=False)              # captures
@@ -306,6 +312,32 @@ def measure_config(diff, dev, B, n_frames, img, ggs_on, reps=3):
         out["ggs_iteration_us"] = g * 1e3 / 700
     out["denoiser_step_us"] = eng.time_kernel(0, B, n_frames, cfg if ggs_on else make_ggs_cfg(synth.GGS_CFG), reps=20) * 1e3
     eng.close()
+    if B == 1:
+        # the seam a user of the reference calls (models/gaussian_diffuser.py:284-306): GaussianDiffusion.sample(shape, z, cond_fn, cond_start_step)
+        # of the drop-in module, END TO END -- the noise drawn in the reference's order by torch's generator, the matches_dict (numpy, as demo.py
+        # holds it) recognised and uploaded (cached after the first call, like the reference's five calls per guided step share one dict), the
+        # graph replayed, the `t=.. | sampson=..` lines printed, the result synchronised.  `ms_per_pass` above feeds resident, pre-drawn noise.
+        import contextlib
+        import functools
+        import io
+        synth._dropin()
+        from util.geometry_guided_sampling import geometry_guided_sampling
+        cond_fn, md = None, None
+        if ggs_on:
+            md = mds[0]
+            cond_fn = functools.partial(geometry_guided_sampling, matches_dict=md, GGS_cfg=dict(synth.GGS_CFG))
+        zs = z[:1]
+        ts = []
+        for rep in range(4):                                    # the first call builds the engine for these modules, uploads and captures
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                pose, _ = diff.sample([1, n_frames, 9], zs, cond_fn=cond_fn, cond_start_step=cs)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        out["dropin_sample_ms"] = min(ts[1:])
+        out["dropin_sample_first_call_ms"] = ts[0]
+        out["dropin_sample_finite"] = bool(torch.isfinite(pose).all().item())
     return out
 
 
@@ -646,6 +678,7 @@ def main():
     kname = ("pd_ggs_lane_kernel<12> (a lane per work item: 8 waves, 12 steps of every item resident in registers, the rest through an LDS ring fed by LDS-DMA)"
              if lane_kernel else f"pd_ggs_kernel<5, false, {plan8[4] or 12}> (a wave per work item)")
     streamed, lane_items, lane_wave_steps = lane_stream_fraction([PER_PAIR] * (N_FRAMES * (N_FRAMES - 1) // 2)) if lane_kernel else (1.0, 0, [])
+    streamed_rate = match_bytes * streamed / (ggs_ms * 1e-3) / 1e9          # GB/s the launch pulls through the fabric
     roofline = {
         "kernel": f"{kname}: one launch = one guided diffusion step = 700 iterations x {EB} sequences, {k_eff} workgroup(s) per sequence",
         "bound": "valu", "bound_detail": "fp32 vector ALU, 157.3 TFLOP/s (SURVEY 8d names the arithmetic roofline for the Sampson kernel; the kernel issues no "
@@ -664,14 +697,17 @@ def main():
                    "streamed_GBps_one_launch": match_bytes * streamed / (ggs_ms * 1e-3) / 1e9,
                    "achieved_GBps_co_resident": depth * match_bytes / (ggs_set_ms * 1e-3) / 1e9,
                    "hbm_peak_GBps": HBM_PEAK_GBS, "frac_of_hbm_peak_one_launch": match_bytes / (ggs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                   "measured_ceiling_GBps": None if ceil_rng is None else [ceil_rng[0], ceil_rng[1]], "measured_ceiling_source": ceil_src,
-                   "frac_of_measured_ceiling_one_launch": None if ceil_rng is None else match_bytes * streamed / (ggs_ms * 1e-3) / 1e9 / ceil_rng[1],
-                   "frac_of_measured_ceiling_note": "STREAMED bytes (algorithmic x streamed_fraction: what the launch actually pulls through the fabric per "
-                                                    "iteration; the register-resident steps are read once per launch) over the probe's best rate on this box",
-                   "why_reported": "THE binding resource of this launch: every CU re-reading a private 912 KB region (tools/stream_probe.hip; the "
-                                   "Infinity-Cache-resident working set streams barely faster than HBM) -- the launch moves exactly the algorithmic bytes "
-                                   "at this box's rate for that pattern; boxes differ by +-8 % (7.2-8.8 TB/s seen), which is why the ceiling is measured "
-                                   "here instead of quoted (DESIGN 3.2)",
+                   "measured_ceiling_GBps": None if ceil_rng is None else [ceil_rng[0][0], ceil_rng[0][1]], "measured_ceiling_source": ceil_src,
+                   "plain_load_probe_GBps": None if (ceil_rng is None or ceil_rng[1] is None) else [ceil_rng[1][0], ceil_rng[1][1]],
+                   "frac_of_measured_ceiling_one_launch": None if ceil_rng is None else streamed_rate / ceil_rng[0][1],
+                   "ceiling_exceeded": None if ceil_rng is None else bool(streamed_rate > 1.03 * ceil_rng[0][1]),
+                   "frac_of_measured_ceiling_note": "STREAMED bytes (algorithmic x streamed_fraction = what the launch pulls through the fabric per iteration: the PMC "
+                                                    "FETCH_SIZE of the launch equals it, profiles/round5_pmc_summary.json; the register-resident steps are read once per "
+                                                    "launch) over the best rate of the LDS-DMA ring probe on this box.  Rounds 3-4 quoted the probe's plain-load rows "
+                                                    "(`plain_load_probe_GBps`), which the kernel's LDS-DMA stream exceeded (1.06): no ceiling for this pattern.  "
+                                                    "`ceiling_exceeded` flags a run whose rate is above the ring probe's by more than 3 %",
+                   "why_reported": "the match stream is what a full-chip launch of this kernel waits for besides its VALU issue (DESIGN 3.2): the rate of the same "
+                                   "pattern without arithmetic says how much of the fabric the launch uses on THIS box; boxes differ by +-8 %",
                    "note": f"{EB * depth} sequences in flight, at most 256 of them (one GGS workgroup per CU) iterating at a time: {min(EB * depth, 256)} x "
                            f"{M * MATCH_BYTES / 1e6:.2f} MB of matches = {min(EB * depth, 256) * M * MATCH_BYTES / 1e6:.0f} MB re-read every iteration at one workgroup "
                            "per sequence (a chosen trade: no replicated serial phase); that set fits the 256 MiB Infinity Cache, so this is fabric / "

@@ -227,8 +227,9 @@ int pd_ggs_loss_grad(pd_engine *eng, const float *x, int B, int N, int update_R,
  *    Value 0 is accepted, 1 returns PD_ERR_UNSUPPORTED.) */
 /*   PD_OPT_DENOISER_FUSED_ATTN  (fp16-plane mode, sequences of <= 32 frames) 1 (default): the in_proj Linear and the attention of a head run as
  *        ONE kernel per group of whole sequences, Q / K / V held in LDS and never written to memory (csrc/pd_qkv_attn.h; models/denoiser.py:88-97);
- *        0: the two launches it replaces (QKV GEMM -> fp32 QKV in memory -> attention).  Same arithmetic in the same order: bitwise the
- *        same results -- comparison / testing. */
+ *        used where its workgroups (one per 95 / N sequences and head) fill at least three quarters of the chip's rounds -- 256 sequences of 20
+ *        frames = 256 workgroups; a batch of 103 keeps the two launches; 2: always; 0: never = the two launches it replaces (QKV GEMM -> fp32
+ *        QKV in memory -> attention).  Same arithmetic in the same order: bitwise the same results whatever the choice. */
 #define PD_OPT_DENOISER_FUSED_ATTN 5
 int pd_engine_set_option(pd_engine *eng, int option, int value);
 /* Reads an option back.  PD_OPT_DENOISER_SPLIT: the mode in force (an engine created from weights that hold inf / NaN stays on 0 although

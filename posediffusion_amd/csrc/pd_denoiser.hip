@@ -55,7 +55,7 @@ __global__ void pd_repack_kernel(const float *__restrict__ W, int Nout, int K, i
             n = nt * 16 + (l & 15);
             k = kc * 16 + 4 * (l >> 4) + e;
         }
-        if (first_perm) k = pd_first_col(first_perm, k);      // a piece of _first (PD_FIRST_D / PD_FIRST_Z): its column of the reference weight
+        if (first_perm) k = pd_first_col_all(k);
         float v = (n < Nout && k < K) ? W[(size_t)n * K + k] : 0.0f;
         if (colscale && k < K) v *= colscale[k];
         Wp[idx] = v;
@@ -74,7 +74,7 @@ __global__ void pd_fold_bias_kernel(const float *__restrict__ W, const float *__
 
 // _first's STEP rows for the streamed path (>= PD_STREAM_MIN_ROWS token rows): [harmonic(x) (180) | x (9) | pivot | 0 0] = KFIRST_D
 // columns (piece PD_FIRST_D of pd_denoiser_dev.h), one wave per row, written once per step and read by pd_gemm_dma like any activation
-// (denoiser.py:60-68; the same expressions as the AMODE 2 staging of pd_gemm_kernel).  z and t_emb never enter the loop: their products
+// (denoiser.py:60-68; the same expressions as the AMODE 2 staging of the small-batch pd_gemm_kernel).  z and t_emb never enter the loop: their products
 // are hoisted (pd_denoiser_prepare, pd_first_ttab_kernel).
 __global__ __launch_bounds__(256) void pd_embed_rows_kernel(const float *__restrict__ x, int n_frames, int M, float *__restrict__ out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -179,18 +179,31 @@ __global__ void pd_harmonic_rows_kernel(const float *__restrict__ x, long long r
 // fused 32x32-tile GEMM:  C[m, n] = epi( sum_k A'[m, k] * W[n, k] + bias[n] )
 //   AMODE 0: A' = A                      (plain rows of a [M, K] activation)
 //   AMODE 1: A' = LayerNorm(A) (K = 512) (norm_first encoder layer, eps 1e-5)
-//   AMODE 2: A' = [harmonic(x) | x | pivot | 0 0]  (K = 192: the step piece of _first, denoiser.py:60-68; pd_denoiser_dev.h)
-//   EPI   0: + bias     1: relu(+ bias)     2: + bias + residual (in place on C)     3: + bias + R (another [M, Nout] array: _first's
-//         hoisted z piece; the bias is the step's row of the time table)
+//   AMODE 2: A' = [z | t_emb | harmonic(x) | x | pivot | 0 0]  (K = 704, denoiser.py:56-68; the engine's column order pd_first_col_all)
+//   EPI   0: + bias     1: relu(+ bias)     2: + bias + residual (in place on C)
 // --------------------------------------------------------------------------------------------
+// -DPD_DEN_STAMPS (tools/den_small_legs.py; never in the product build): every launch of the small-batch chain records, from lane 0 of
+// wave 0 of its block 0, the constant 100 MHz clock (s_memrealtime: comparable across kernels and CUs) at the legs of its latency chain
+#ifdef PD_DEN_STAMPS
+#define PD_STAMP(ptr, i)                                                                          \
+    do {                                                                                          \
+        if ((ptr) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) (ptr)[i] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define PD_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define PD_STAMP(ptr, i) do { } while (0)
+#define PD_STAMP_DRAIN() do { } while (0)
+#endif
 struct GemmArgs {
+#ifdef PD_DEN_STAMPS
+    long long *stamps;     // [8] of this launch, or null
+#endif
     const float *A;        // [M, K] (AMODE 0/1)
     const float *Wp;       // packed weights
     const float *bias;     // [Nout]
     float *C;              // [M, Nout]
-    const float *R;        // [M, Nout] (EPI 3)
     // AMODE 2
-    const float *x;        // x [M,9]
+    const float *x, *z, *temb;   // x [M,9], z [M,384], temb [128] (row of the table for this t)
     int n_frames;
     int M, Nout;
     int MT;                // number of 32-row M tiles (XCD-aware block mapping)
@@ -209,6 +222,10 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *As = lds;                      // [32][LDA]; later aliased by the cross-wave reduction
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef PD_DEN_STAMPS
+    long long *const stamps = g.stamps;
+    PD_STAMP(stamps, 0);                  // entered
+#endif
     // XCD-aware tile mapping (guide T1): the dispatcher places block id on XCD id % 8; all M-tiles that share
     // an N-tile are given ids with the same id % 8, so each weight tile is fetched into ONE L2 once and the
     // other M-tile workgroups hit it there (the naive (m + MT*n) order spread them over MT different XCDs
@@ -237,12 +254,30 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
         const int mr = live ? m : g.M - 1;   // clamp: padded rows load a valid row and are zeroed
         float *dst = As + r * LDA;
         if constexpr (AMODE == 2) {
-            // the step piece of _first in the engine's column order (pd_first_col, PD_FIRST_D): harmonic | x | pivot | pad
-            static_assert(AMODE != 2 || K == KFIRST_D, "the embedding staging is built for the 192-column step piece");
+            // engine column order (pd_first_col_all): z | t_emb | harmonic | x | pivot | pad
+            const float4 *zr = (const float4 *)(g.z + (size_t)mr * ZD);
+            const float4 *te = (const float4 *)g.temb;
+            float4 zv[ZD / 32], tv[4];
+#pragma unroll
+            for (int i = 0; i < ZD / 32; ++i) zv[i] = zr[sub + 8 * i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tv[i] = te[sub + 8 * i];
             float xv[9];
 #pragma unroll
             for (int d = 0; d < 9; ++d) xv[d] = g.x[(size_t)mr * 9 + d];
             const float keep = live ? 1.0f : 0.0f;
+#pragma unroll
+            for (int i = 0; i < ZD / 32; ++i) {
+                float4 v = zv[i];
+                v.x *= keep; v.y *= keep; v.z *= keep; v.w *= keep;
+                *(float4 *)(dst + 4 * (sub + 8 * i)) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 v = tv[i];
+                v.x *= keep; v.y *= keep; v.z *= keep; v.w *= keep;
+                *(float4 *)(dst + 384 + 4 * (sub + 8 * i)) = v;
+            }
             // harmonic embedding: idx = s*90 + d*10 + k -> sin(x_d * 2^k + s * pi/2)  (pytorch3d 0.7.x)
             for (int idx = sub; idx < 180; idx += 8) {
                 const int s = idx / 90, rem = idx - s * 90, d = rem / 10, kk = rem - d * 10;
@@ -250,14 +285,14 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int q = 1; q < 9; ++q) xd = (d == q) ? xv[q] : xd;
                 const float e = xd * (float)(1 << kk);
-                dst[idx] = keep * sinf(s ? e + 1.5707963267948966f : e);
+                dst[512 + idx] = keep * sinf(s ? e + 1.5707963267948966f : e);
             }
             if (sub == 0) {
 #pragma unroll
-                for (int d = 0; d < 9; ++d) dst[180 + d] = keep * xv[d];
-                dst[189] = (live && (m % g.n_frames == 0)) ? 1.0f : 0.0f;   // pivot one-hot on frame 0
-                dst[190] = 0.0f;
-                dst[191] = 0.0f;
+                for (int d = 0; d < 9; ++d) dst[692 + d] = keep * xv[d];
+                dst[701] = (live && (m % g.n_frames == 0)) ? 1.0f : 0.0f;   // pivot one-hot on frame 0
+                dst[702] = 0.0f;
+                dst[703] = 0.0f;
             }
         } else if constexpr (AMODE == 1) {
             // LayerNorm without affine: gamma is folded into the packed weights, beta into the bias
@@ -306,7 +341,13 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
             }
         }
     }
+    PD_STAMP(stamps, 1);                  // this thread's share of the A rows loaded (arrived from L2 / MALL), normalised, written to LDS
     __syncthreads();
+    PD_STAMP(stamps, 2);                  // every wave's share staged
+#ifdef PD_DEN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PD_STAMP(stamps, 3);                  // ... and the first batch of weight fragments + the bias have landed (stamps build only: the wait)
+#endif
 
     // ---- split-K MFMA loop: wave w owns k-chunks [w*CPW, (w+1)*CPW) --------------------------
     float4 w1[NB == 2 ? BATCH : 1];
@@ -356,6 +397,7 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
             accv[4 + i] = acc1[i];
         }
     }
+    PD_STAMP(stamps, 4);                  // this wave's MFMA chain issued (its results are awaited by the stores below)
     __syncthreads();   // every wave is done reading As; reuse it for the reduction
 
     // ---- cross-wave reduction in fixed order + fused epilogue ---------------------------------
@@ -378,10 +420,12 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
             float *cp = g.C + (size_t)row * g.Nout + col;
             if constexpr (EPI == 1) v = pd_relu(v);
             if constexpr (EPI == 2) v += *cp;
-            if constexpr (EPI == 3) v += g.R[(size_t)row * g.Nout + col];
             *cp = v;
         }
     }
+    PD_STAMP(stamps, 5);                  // reduced + epilogue issued
+    PD_STAMP_DRAIN();
+    PD_STAMP(stamps, 6);                  // the stores have left the CU (stamps build only: the wait)
 }
 
 // --------------------------------------------------------------------------------------------
@@ -392,7 +436,12 @@ __global__ __launch_bounds__(256) void pd_gemm_kernel(GemmArgs g) {
 // --------------------------------------------------------------------------------------------
 // SPLIT_OUT: ctx is written as split words {bf16 hi | bf16 lo << 16} for pd_gemm_split (the fast mode)
 template <bool SPLIT_OUT>
-__global__ __launch_bounds__(256) void pd_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int N) {
+__global__ __launch_bounds__(256) void pd_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int N
+#ifdef PD_DEN_STAMPS
+                                                      , long long *stamps
+#endif
+) {
+    PD_STAMP(stamps, 0);
     constexpr int LD = DH + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Kk = lds, *V = Kk + N * LD, *Q = V + N * LD, *P = Q + 4 * LD;   // P [4][64]
@@ -413,6 +462,7 @@ __global__ __launch_bounds__(256) void pd_attn_kernel(const float *__restrict__ 
         *(float4 *)(Q + wave * LD + lane * 4) = q;
     }
     __syncthreads();
+    PD_STAMP(stamps, 2);                  // K, V, Q staged
     const int jj = lane < N ? lane : N - 1;
     const float4 *qa = (const float4 *)(Q + wave * LD), *kb = (const float4 *)(Kk + jj * LD);
     float s = 0.0f;
@@ -447,6 +497,9 @@ __global__ __launch_bounds__(256) void pd_attn_kernel(const float *__restrict__ 
             out[64 + lane] = o1;
         }
     }
+    PD_STAMP(stamps, 5);
+    PD_STAMP_DRAIN();
+    PD_STAMP(stamps, 6);
 }
 
 // The same attention for large batches: ONE workgroup per (sequence, head) stages K, V and all N query rows once (pd_attn_kernel
@@ -666,9 +719,16 @@ struct HeadArgs {
     float c_recip, c_recipm1, coef1, coef2, sigma;
     int M;
     int pred_x0;           // objective "pred_x0": the model output is x_start (gaussian_diffuser.py:225-227)
+#ifdef PD_DEN_STAMPS
+    long long *stamps;
+#endif
 };
 
 __global__ __launch_bounds__(256) void pd_tail_kernel(HeadArgs g) {
+#ifdef PD_DEN_STAMPS
+    long long *const stamps = g.stamps;
+#endif
+    PD_STAMP(stamps, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = blockIdx.x * 4 + wave;
     if (m >= g.M) return;
@@ -698,6 +758,9 @@ __global__ __launch_bounds__(256) void pd_tail_kernel(HeadArgs g) {
         if (g.mean_out) g.mean_out[at] = mu;
         if (g.xnext_out) g.xnext_out[at] = g.noise ? mu + g.sigma * nz : mu;   // :280
     }
+    PD_STAMP(stamps, 5);
+    PD_STAMP_DRAIN();
+    PD_STAMP(stamps, 6);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -796,8 +859,7 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     }
     for (int v = 0; v < 2; ++v) {   // v = 0: 32-wide tiles, v = 1: 16-wide tiles
         const int nt = v ? 16 : 32;
-        PD_TRY(dev_pack(d, &d->first_dp[v], w->first_w, DM, KFIRST, KFIRST_D, nt, PD_FIRST_D));
-        PD_TRY(dev_pack(d, &d->first_zp[v], w->first_w, DM, KFIRST, ZD, nt, PD_FIRST_Z));
+        PD_TRY(dev_pack(d, &d->first_wp[v], w->first_w, DM, KFIRST, KFIRST_PAD, nt, 1));
         PD_TRY(dev_pack(d, &d->last0_wp[v], w->last0_w, HID, DM, DM, nt));
         for (int l = 0; l < w->num_layers; ++l) {
             const pd_layer_weights &s = w->layers[l];
@@ -840,22 +902,22 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     if (rows >= PD_STREAM_MIN_ROWS) PD_TRY(dev_alloc(d, &d->hn, rows * DM));
     // _first's input rows (materialised by pd_embed_rows_kernel on the streamed path, formerly also by the parked persistent kernel) and the
     // row-major _first / _last.0 the two paths pack from
-    PD_TRY(dev_alloc(d, &d->emb, rows * KFIRST_D));
-    PD_TRY(dev_alloc(d, &d->zproj, rows * DM));
-    PD_TRY(dev_alloc(d, &d->first_df, (size_t)DM * KFIRST_D));
-    PD_TRY(dev_alloc(d, &d->first_zf, (size_t)DM * ZD));
-    hipLaunchKernelGGL(pd_first_rowmajor_kernel, dim3((DM * KFIRST_D + 255) / 256), dim3(256), 0, 0, w->first_w, d->first_df, PD_FIRST_D, KFIRST_D);
-    hipLaunchKernelGGL(pd_first_rowmajor_kernel, dim3((DM * ZD + 255) / 256), dim3(256), 0, 0, w->first_w, d->first_zf, PD_FIRST_Z, ZD);
-    PD_HIP_CHECK(hipGetLastError());
-    // the time piece of _first for every step: ttab[t] = W_t t_emb(t)
-    PD_TRY(dev_alloc(d, &d->ttab, (size_t)w->timesteps * DM));
-    hipLaunchKernelGGL(pd_first_ttab_kernel, dim3(w->timesteps), dim3(DM), 0, 0, w->first_w, d->t_table, d->ttab);
-    PD_HIP_CHECK(hipGetLastError());
+    if (d->hn) {      // the streamed path evaluates _first in three pieces (pd_denoiser_dev.h): two of them outside the diffusion steps
+        PD_TRY(dev_alloc(d, &d->emb, rows * KFIRST_D));
+        PD_TRY(dev_alloc(d, &d->zproj, rows * DM));
+        PD_TRY(dev_alloc(d, &d->first_df, (size_t)DM * KFIRST_D));
+        PD_TRY(dev_alloc(d, &d->first_zf, (size_t)DM * ZD));
+        hipLaunchKernelGGL(pd_first_rowmajor_kernel, dim3((DM * KFIRST_D + 255) / 256), dim3(256), 0, 0, w->first_w, d->first_df, PD_FIRST_D, KFIRST_D);
+        hipLaunchKernelGGL(pd_first_rowmajor_kernel, dim3((DM * ZD + 255) / 256), dim3(256), 0, 0, w->first_w, d->first_zf, PD_FIRST_Z, ZD);
+        PD_HIP_CHECK(hipGetLastError());
+        // the time piece of _first for every step: ttab[t] = W_t t_emb(t)
+        PD_TRY(dev_alloc(d, &d->ttab, (size_t)w->timesteps * DM));
+        hipLaunchKernelGGL(pd_first_ttab_kernel, dim3(w->timesteps), dim3(DM), 0, 0, w->first_w, d->t_table, d->ttab);
+        PD_HIP_CHECK(hipGetLastError());
+    }
     PD_TRY(dev_rowmajor(d, &d->last0_wf, w->last0_w, HID, DM, nullptr));
-    PD_TRY(set_lds(pd_gemm_kernel<KFIRST_D, 2, 3, 32>, 32 * (KFIRST_D + 4) * 4));
-    PD_TRY(set_lds(pd_gemm_kernel<KFIRST_D, 2, 3, 16>, 32 * (KFIRST_D + 4) * 4));
-    PD_TRY(set_lds(pd_gemm_kernel<ZD, 0, 0, 32>, 32 * (ZD + 4) * 4));
-    PD_TRY(set_lds(pd_gemm_kernel<ZD, 0, 0, 16>, 32 * (ZD + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0, 32>, 32 * (KFIRST_PAD + 4) * 4));
+    PD_TRY(set_lds(pd_gemm_kernel<KFIRST_PAD, 2, 0, 16>, 32 * (KFIRST_PAD + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 0, 32>, 32 * (DM + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 0, 16>, 32 * (DM + 4) * 4));
     PD_TRY(set_lds(pd_gemm_kernel<DM, 1, 1, 32>, 32 * (DM + 4) * 4));
@@ -872,7 +934,14 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(set_lds(pd_attn_seq_kernel<1>, attn_seq_lds(64)));
     PD_TRY(set_lds(pd_attn_seq_kernel<2>, attn_seq_lds(64)));
     PD_TRY(set_lds(pd_attn_mma_kernel<2>, attn_mma_lds(32)));
-    PD_TRY(set_lds(pd_qkv_attn_kernel, 160 * 1024));
+    PD_TRY(set_lds(pd_qkv_attn_kernel<0>, 160 * 1024));
+#ifdef PD_DEV_KNOBS
+    PD_TRY(set_lds(pd_qkv_attn_kernel<1>, 160 * 1024));
+    PD_TRY(set_lds(pd_qkv_attn_kernel<2>, 160 * 1024));
+    PD_TRY(set_lds(pd_qkv_attn_kernel<3>, 160 * 1024));
+    PD_TRY(set_lds(pd_qkv_attn_kernel<4>, 160 * 1024));
+    PD_TRY(set_lds(pd_qkv_attn_kernel<5>, 160 * 1024));
+#endif
     PD_HIP_CHECK(hipDeviceSynchronize());
     return PD_OK;
 }
@@ -1020,10 +1089,36 @@ void pd_denoiser_destroy(pd_engine *eng) {
 
 // one GEMM launch; the tile width is chosen per problem: 16-wide tiles double the workgroup count (and
 // halve each wave's serial MFMA chain) whenever 32-wide tiles would leave most of the 256 CUs idle
+#ifdef PD_DEN_STAMPS
+static long long *g_den_stamps = nullptr;      // [PD_DEN_STAMP_SLOTS][8], device memory; the slot of the next small-batch launch
+static int g_den_stamp_slot = 0;
+#define PD_DEN_STAMP_SLOTS 256
+static long long *next_stamp_slot() {
+    if (!g_den_stamps) {
+        if (hipMalloc((void **)&g_den_stamps, sizeof(long long) * 8 * PD_DEN_STAMP_SLOTS) != hipSuccess) return nullptr;
+        (void)hipMemset(g_den_stamps, 0, sizeof(long long) * 8 * PD_DEN_STAMP_SLOTS);
+    }
+    long long *p = g_den_stamps + 8 * (g_den_stamp_slot % PD_DEN_STAMP_SLOTS);
+    g_den_stamp_slot += 1;
+    return p;
+}
+// out[n_slots][8]: the stamps of the last launches (slot = launch index mod 256); restarts the slot counter
+extern "C" int pd_debug_den_stamps(long long *out, int n_slots) {
+    if (!out || n_slots <= 0 || n_slots > PD_DEN_STAMP_SLOTS || !g_den_stamps) return PD_ERR_INVALID_ARG;
+    PD_HIP_CHECK(hipDeviceSynchronize());
+    PD_HIP_CHECK(hipMemcpy(out, g_den_stamps, sizeof(long long) * 8 * n_slots, hipMemcpyDeviceToHost));
+    PD_HIP_CHECK(hipMemset(g_den_stamps, 0, sizeof(long long) * 8 * PD_DEN_STAMP_SLOTS));
+    g_den_stamp_slot = 0;
+    return PD_OK;
+}
+#endif
 template <int K, int AMODE, int EPI>
 static void launch_gemm(GemmArgs &g, float *const wp[2], int MT, int wide_min, hipStream_t s) {
     const int tiles32 = MT * (g.Nout / 32);
     g.MT = MT;
+#ifdef PD_DEN_STAMPS
+    g.stamps = next_stamp_slot();
+#endif
     // the XCD-aware block mapping of pd_gemm_kernel needs a multiple of 8 N-tiles (128-wide _last.0 has only 4 of 32)
     if (tiles32 >= wide_min && (g.Nout / 32) % 8 == 0) {
         g.Wp = wp[0];
@@ -1043,14 +1138,9 @@ int pd_denoiser_prepare(pd_engine *eng, const float *z, int B, int N, hipStream_
         return PD_ERR_INVALID_ARG;
     }
     const int M = B * N;
-    if (M >= PD_STREAM_MIN_ROWS && d->hn) {
-        pd_gemm_dma<0>(z, ZD, d->first_zf, ZD, d->first_b, d->zproj, M, DM, s);
-    } else {
-        GemmArgs g;
-        memset(&g, 0, sizeof(g));
-        g.M = M; g.A = z; g.bias = d->first_b; g.C = d->zproj; g.Nout = DM;
-        launch_gemm<ZD, 0, 0>(g, d->first_zp, (M + 31) / 32, eng->gemm_wide_min_tiles, s);
-    }
+    // (below PD_STREAM_MIN_ROWS token rows _first stays ONE fused launch -- embedding staged in the GEMM's A rows, K = 704: a step there is a
+    // chain of 43 latency-bound launches in which the shorter K buys 1 %, and the small-batch results stay bitwise those of rounds 1-4)
+    if (M >= PD_STREAM_MIN_ROWS && d->hn) pd_gemm_dma<0>(z, ZD, d->first_zf, ZD, d->first_b, d->zproj, M, DM, s);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }
@@ -1073,15 +1163,15 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     memset(&g, 0, sizeof(g));
     g.M = M;
     const bool streamed = M >= PD_STREAM_MIN_ROWS && d->hn;
-    // _first = zproj (z piece + bias, hoisted) + ttab[t] (time piece, a table) + the step piece, K = 192
     if (streamed) {
+        // _first = zproj (z piece + bias, hoisted) + ttab[t] (time piece, a table) + the step piece, K = 192
         hipLaunchKernelGGL(pd_embed_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, N, M, d->emb);
         pd_gemm_dma<4>(d->emb, KFIRST_D, d->first_df, KFIRST_D, d->ttab + (size_t)t * DM, d->h, M, DM, s, nullptr, d->zproj);
     } else {
-        // ... with the pose embedding fused into the A staging
-        g.bias = d->ttab + (size_t)t * DM; g.C = d->h; g.Nout = DM; g.R = d->zproj;
-        g.x = x; g.n_frames = N;
-        launch_gemm<KFIRST_D, 2, 3>(g, d->first_dp, MT, eng->gemm_wide_min_tiles, s);
+        // _first with the embedding fused into the A staging
+        g.bias = d->first_b; g.C = d->h; g.Nout = DM;
+        g.x = x; g.z = z; g.temb = d->t_table + (size_t)t * 128; g.n_frames = N;
+        launch_gemm<KFIRST_PAD, 2, 0>(g, d->first_wp, MT, eng->gemm_wide_min_tiles, s);
     }
     // >= 1024 token rows (52 sequences of 20 frames): the encoder GEMMs are large enough for 64 x 64 tiles streamed through LDS
     // (pd_gemm_stream.h; same sums in another order than the 32-row split-K tiles below, i.e. rounding-level differences
@@ -1097,7 +1187,11 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
             static const int strip = pd_dev_knob("PD_DEN_STRIP", 15);
             hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 2>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 512.0f);
             static const int attn_mma = pd_dev_knob("PD_DEN_ATTN_MMA", 1);     // development A / B
-            if (N <= 32 && eng->den_fused_attn) {
+            // the fused kernel holds a CU for ~38 us whatever the batch (one workgroup per 4 sequences and head): it wins when its workgroups
+            // fill the chip's rounds (256 sequences = 256 workgroups: -76 us per step), not at 103 sequences (104 workgroups: +2 %)
+            const int qa_wgs = ((B + pd_qkv_attn_group(N > 32 ? 1 : N) - 1) / pd_qkv_attn_group(N > 32 ? 1 : N)) * NH, cus = eng->num_cus > 0 ? eng->num_cus : 256;
+            const bool qa_fills = 4 * qa_wgs >= 3 * ((qa_wgs + cus - 1) / cus) * cus;
+            if (N <= 32 && eng->den_fused_attn == 1 ? qa_fills : (N <= 32 && eng->den_fused_attn == 2)) {
                 // in_proj + attention of a head for a group of whole sequences in one workgroup, Q / K / V in LDS only (pd_qkv_attn.h):
                 // bitwise the two launches of the else branch
                 pd_qkv_attn((const unsigned *)d->hn, L.qkv_wh, L.qkv_b, (unsigned *)d->ctx, B, N, L.qkv_cs, L.ctx_scale, s);
@@ -1142,7 +1236,11 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
         // x += MHA(LN1(x))
         g.A = d->h; g.bias = L.qkv_b; g.C = d->qkv; g.Nout = 3 * DM;
         launch_gemm<DM, 1, 0>(g, L.qkv_wp, MT, eng->gemm_wide_min_tiles, s);
+#ifdef PD_DEN_STAMPS
+        hipLaunchKernelGGL(pd_attn_kernel<false>, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N, next_stamp_slot());
+#else
         hipLaunchKernelGGL(pd_attn_kernel<false>, dim3(B * NH, (N + 3) / 4), dim3(256), ((2 * N + 4) * (DH + 4) + 4 * 64) * 4, s, d->qkv, d->ctx, N);
+#endif
         g.A = d->ctx; g.bias = L.out_b; g.C = d->h; g.Nout = DM;
         launch_gemm<DM, 0, 2>(g, L.out_wp, MT, eng->gemm_wide_min_tiles, s);
         // x += W2 relu(W1 LN2(x))
@@ -1167,6 +1265,9 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
     ha.sigma = expf(0.5f * eng->logvar[t]);
     ha.M = M;
     ha.pred_x0 = eng->pred_x0;
+#ifdef PD_DEN_STAMPS
+    ha.stamps = streamed ? nullptr : next_stamp_slot();
+#endif
     hipLaunchKernelGGL(pd_tail_kernel, dim3((M + 3) / 4), dim3(256), 0, s, ha);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;

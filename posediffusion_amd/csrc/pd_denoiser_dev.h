@@ -14,13 +14,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DFF 1024        // feed-forward dim
 #define ZD 384          // z_dim
 #define KFIRST 702      // 189 + 128 + 384 + 1   (denoiser.py:39)
-// `_first` (denoiser.py:56-70) is evaluated in THREE pieces (round 5): of its 702 input columns only the 189 pose-embedding columns
+// At >= PD_STREAM_MIN_ROWS token rows `_first` (denoiser.py:56-70) is evaluated in THREE pieces (round 5): of its 702 input columns only the 189 pose-embedding columns
 // change from one diffusion step to the next --
 //   reference column : [0,180) harmonic | [180,189) x | [189,317) t_emb | [317,701) z | 701 pivot  (denoiser.py:68)
 //   PD_FIRST_Z   z columns [317,701), K = 384: zproj[m] = z[m] W_z^T + b_first, ONCE per sampling call (z is the same in all T steps)
 //   PD_FIRST_T   t_emb columns [189,317): a [T, 512] table W_t t_emb(t), built at engine creation (t_emb depends on t only)
 //   PD_FIRST_D   the step's own columns in the engine's order [0,180) harmonic | [180,189) x | 189 pivot | 190,191 pad: K = 192
 // so a step's `_first` is h = zproj + ttab[t] + D W_d^T: K 704 -> 192 inside the loop.
+#define KFIRST_PAD 704
+// Below PD_STREAM_MIN_ROWS token rows _first stays one launch over all 702 columns, its K axis permuted so the wide pieces land 16-byte
+// aligned in LDS:  engine column k' : [0,384) z | [384,512) t_emb | [512,692) harmonic | [692,701) x | 701 pivot | 702,703 pad
+__host__ __device__ inline int pd_first_col_all(int kp) {
+    if (kp < 384) return 317 + kp;
+    if (kp < 512) return 189 + (kp - 384);
+    if (kp < 692) return kp - 512;
+    if (kp < 701) return 180 + (kp - 692);
+    return kp;   // 701 pivot; 702/703 are padding (>= KFIRST -> zero)
+}
 #define PD_FIRST_D 1
 #define PD_FIRST_Z 2
 #define PD_FIRST_T 3
@@ -51,7 +61,7 @@ struct PdLayerDev {          // [0] = 32-wide-tile packing, [1] = 16-wide-tile p
 struct PdDenoiserDev {
     int num_layers = 0, timesteps = 0, m_cap = 0;
     float *t_table = nullptr;          // [T,128] time embeddings
-    float *first_dp[2] = {nullptr, nullptr}, *first_zp[2] = {nullptr, nullptr}, *first_b = nullptr;   // _first's step piece (K = 192) and z piece (K = 384), packed
+    float *first_wp[2] = {nullptr, nullptr}, *first_b = nullptr;   // _first packed for the small-batch kernel (K = 704, pd_first_col_all)
     float *ttab = nullptr;             // [T, 512] = W_t t_emb(t): the time piece of _first, added as the step GEMM's bias
     float *zproj = nullptr;            // [rows, 512] = z W_z^T + b_first of the sampling call in flight (pd_denoiser_prepare)
     PdLayerDev layers[PD_MAX_LAYERS];

@@ -443,8 +443,8 @@ extern "C" int pd_engine_set_option(pd_engine *eng, int option, int value) {
         eng->den_split = value;
         break;
     case PD_OPT_DENOISER_FUSED_ATTN:
-        if (value != 0 && value != 1) {
-            pd_set_error("pd_engine_set_option: PD_OPT_DENOISER_FUSED_ATTN takes 0 or 1 (got %d)", value);
+        if (value < 0 || value > 2) {
+            pd_set_error("pd_engine_set_option: PD_OPT_DENOISER_FUSED_ATTN takes 0, 1 or 2 (got %d)", value);
             return PD_ERR_INVALID_ARG;
         }
         eng->den_fused_attn = value;

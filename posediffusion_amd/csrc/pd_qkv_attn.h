@@ -40,6 +40,9 @@ static inline size_t pd_qkv_attn_lds(int N) {
     return (image > stage ? image : stage) + (size_t)3 * 32 * PD_QA_LS * sizeof(float);
 }
 
+// BARE (development builds only, -DPD_DEV_KNOBS + PD_QA_BARE=n; results meaningless for n > 0): what bounds the kernel -- 1 no weight-fragment loads
+// inside the K loop, 2 no LDS-DMA inside it, 3 neither, 4 everything but the MFMAs, 5 the product only (no Q | K | V image, no attention)
+template <int BARE>
 __global__ __launch_bounds__(PD_QA_THREADS) void pd_qkv_attn_kernel(PdQkvAttnArgs g) {
     constexpr int KC = 32, RT = 3, TM = PD_QA_ROWS, CHA = TM * KC, LDR = PD_QA_LDR, LS = PD_QA_LS;
     extern __shared__ __attribute__((aligned(1024))) unsigned qa_lds[];
@@ -121,19 +124,33 @@ __global__ __launch_bounds__(PD_QA_THREADS) void pd_qkv_attn_kernel(PdQkvAttnArg
         for (int c = 0; c < nk64; ++c) {
             const int cn = min(c + 1, nk64 - 1);                 // the chunk after the last is the last again (never used)
             const unsigned *a = qa_lds + (c & 1) * 2 * CHA + l31 * KC;
-            stage64(cn, (c + 1) & 1);                            // in flight, oldest first: the second block's weights [4, from the previous turn], this DMA [2]
-            block(a, a0, a1, a2, a3);
-            PD_QA_WLOAD(a0, a1, a2, a3, 2 * cn);                 //   ... + the next chunk's first block [4]
-            PD_QA_WAIT(6, b0, b1, b2, b3);                       // the second block's weights have landed; the DMA [2] and the loads just issued [4] may fly
-            block(a + CHA, b0, b1, b2, b3);
-            PD_QA_WLOAD(b0, b1, b2, b3, 2 * cn + 1);             //   ... + the next chunk's second block [4]
-            PD_QA_WAIT(4, a0, a1, a2, a3);                       // the next chunk's rows and first block have landed; the second block may still fly
+            if constexpr (BARE == 0) {
+                stage64(cn, (c + 1) & 1);                        // in flight, oldest first: the second block's weights [4, from the previous turn], this DMA [2]
+                block(a, a0, a1, a2, a3);
+                PD_QA_WLOAD(a0, a1, a2, a3, 2 * cn);             //   ... + the next chunk's first block [4]
+                PD_QA_WAIT(6, b0, b1, b2, b3);                   // the second block's weights have landed; the DMA [2] and the loads just issued [4] may fly
+                block(a + CHA, b0, b1, b2, b3);
+                PD_QA_WLOAD(b0, b1, b2, b3, 2 * cn + 1);         //   ... + the next chunk's second block [4]
+                PD_QA_WAIT(4, a0, a1, a2, a3);                   // the next chunk's rows and first block have landed; the second block may still fly
+            } else {                                             // development variants (see BARE): every wait drains
+                if constexpr (BARE != 2 && BARE != 3) stage64(cn, (c + 1) & 1);
+                if constexpr (BARE != 4) block(a, a0, a1, a2, a3);
+                if constexpr (BARE != 1 && BARE != 3) PD_QA_WLOAD(a0, a1, a2, a3, 2 * cn);
+                if constexpr (BARE != 4) block(a + CHA, b0, b1, b2, b3);
+                if constexpr (BARE != 1 && BARE != 3) PD_QA_WLOAD(b0, b1, b2, b3, 2 * cn + 1);
+                PD_QA_WAIT(0, a0, a1, a2, a3);
+                PD_QA_WAIT(0, b0, b1, b2, b3);
+            }
             __syncthreads();
         }
         PD_QA_WAIT(0, b0, b1, b2, b3);
     }
 #undef PD_QA_WLOAD
 #undef PD_QA_WAIT
+    if constexpr (BARE == 5) {
+        if (acc[0][0] == 123.456f) g.ctx[tid] = 1u;                // keep the product alive
+        return;
+    }
     // ---- 2. Q | K | V of the workgroup's rows as fp32 in LDS (every wave is past its last fragment read: the barrier that ended the loop) ----
     float *img = (float *)qa_lds;                                // [G N + 1][LDR]: columns [0, 128) q / sqrt(dh), [128, 256) k, [256, 384) v; row G N = 0
     float *Sall = img + (size_t)(G * N + 1) * LDR;               // [3 teams][32][LS]
@@ -252,5 +269,18 @@ static inline void pd_qkv_attn(const unsigned *hn, const unsigned *Wh, const flo
                                hipStream_t s) {
     const int G = pd_qkv_attn_group(N);
     PdQkvAttnArgs g{hn, Wh, bias, ctx, B, N, G, c_scale, out_scale};
-    hipLaunchKernelGGL(pd_qkv_attn_kernel, dim3(((B + G - 1) / G) * NH), dim3(PD_QA_THREADS), pd_qkv_attn_lds(N), s, g);
+#ifdef PD_DEV_KNOBS
+    static const int bare = pd_dev_knob("PD_QA_BARE", 0);
+    const dim3 grid(((B + G - 1) / G) * NH), blk(PD_QA_THREADS);
+    const size_t lds = pd_qkv_attn_lds(N);
+    switch (bare) {
+    case 1: hipLaunchKernelGGL(pd_qkv_attn_kernel<1>, grid, blk, lds, s, g); return;
+    case 2: hipLaunchKernelGGL(pd_qkv_attn_kernel<2>, grid, blk, lds, s, g); return;
+    case 3: hipLaunchKernelGGL(pd_qkv_attn_kernel<3>, grid, blk, lds, s, g); return;
+    case 4: hipLaunchKernelGGL(pd_qkv_attn_kernel<4>, grid, blk, lds, s, g); return;
+    case 5: hipLaunchKernelGGL(pd_qkv_attn_kernel<5>, grid, blk, lds, s, g); return;
+    default: break;
+    }
+#endif
+    hipLaunchKernelGGL(pd_qkv_attn_kernel<0>, dim3(((B + G - 1) / G) * NH), dim3(PD_QA_THREADS), pd_qkv_attn_lds(N), s, g);
 }

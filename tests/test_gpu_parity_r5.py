@@ -60,8 +60,9 @@ def test_lane_kernel_at_the_headline_launch(engine, headline_batch, B):
     and the ds_read of a slot is a counted `s_waitcnt vmcnt` (pd_ggs_lane.inc).  What only this launch has -- B rings competing for the
     fabric, DMA landing latencies several times those of a 3-sequence launch -- is what a miscounted wait would need to corrupt a slot.
       (a) 20 iterations of GGS_optimize (the ring wraps ~19 x 20 times per wave): nine slots spread over all XCDs are compared BITWISE
-          with the same sequence run alone (a launch of ONE workgroup on an idle chip: DMA latency at its minimum) and within 2e-5 with
-          the oracle's GGS_optimize (iteration counts equal);
+          with the same sequence run alone (a launch of ONE workgroup on an idle chip: DMA latency at its minimum); against the oracle's
+          GGS_optimize the teacher-forced bound 2e-5 is asserted after 6 iterations of the same launch shape and the contract's 1e-4
+          after the 20 (a free-running trajectory through a hard threshold: measured 1e-6 .. 8e-5 over the compared slots);
       (b) a full geometry_guided_sampling (5 stages, 700 iterations: ~13 000 ring turns per wave): the same nine slots bitwise with the
           sequence run alone, every slot finite with all 700 iterations stepped, and the whole launch repeated: bitwise the same."""
     eng, mds, x0_all = headline_batch
@@ -71,6 +72,8 @@ def test_lane_kernel_at_the_headline_launch(engine, headline_batch, B):
     plan = _plan(eng, B, N20, cfg_f)
     assert plan[0] == 1 and plan[6] == 1, plan                    # one workgroup per sequence on the lane-per-item kernel
     o20, st20, _ = eng.ggs_optimize(x0, cfg=cfg_s)
+    eng.check_async()
+    o6, st6, _ = eng.ggs_optimize(x0, cfg=make_ggs_cfg(iter_num=3, wgs_per_seq=1, reserved=LANE))
     eng.check_async()
     of, stf = eng.ggs_guide(x0, 0, cfg_f)
     eng.check_async()
@@ -83,7 +86,7 @@ def test_lane_kernel_at_the_headline_launch(engine, headline_batch, B):
     slots = sorted({(33 * i) % B for i in range(8)} | {B - 1})     # 0, 33, 66, ...: block b runs on XCD b % 8 -> all eight XCDs
     assert {b % 8 for b in slots} == set(range(8))
     assert _plan(engine, 1, N20, cfg_f)[6] == 1
-    worst = 0.0
+    worst = worst6 = 0.0
     for b in slots:
         md = mds[b]
         engine.set_matches(0, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
@@ -96,8 +99,12 @@ def test_lane_kernel_at_the_headline_launch(engine, headline_batch, B):
         ref, _, steps = O.ggs_optimize(x0[b:b + 1].cpu().clone(), pm, iter_num=10)
         assert steps == 20
         worst = max(worst, rel_err(o20[b:b + 1], ref))
-    print(f"lane kernel, {B}-sequence launch: slots {slots} bitwise = alone (20 and 700 iterations); worst deviation from the oracle after 20 iterations {worst:.2e}")
-    assert worst < TOL, worst
+        ref6, _, steps6 = O.ggs_optimize(x0[b:b + 1].cpu().clone(), pm, iter_num=3)
+        assert steps6 == 6 == int(st6[b, 1])
+        worst6 = max(worst6, rel_err(o6[b:b + 1], ref6))
+    print(f"lane kernel, {B}-sequence launch: slots {slots} bitwise = alone (20 and 700 iterations); worst deviation from the oracle after 6 / 20 iterations "
+          f"{worst6:.2e} / {worst:.2e}")
+    assert worst6 < TOL and worst < 1e-4, (worst6, worst)
 
 
 def test_free_running_full_size_seeds_1_and_2(engine, golden):
@@ -160,7 +167,7 @@ def test_fused_qkv_attention_is_bitwise_the_two_launch_path(seeded_diffuser, ora
     G = 95 // N
     sub = sorted({0, 1, G - 1, G, B // 2, B - G - 1, B - 2, B - 1})
     for t in (99, 40, 0):
-        eng.set_option(_lib.PD_OPT_DENOISER_FUSED_ATTN, 1)
+        eng.set_option(_lib.PD_OPT_DENOISER_FUSED_ATTN, 2)          # (2 = always; the default 1 takes the fused kernel only where it fills the chip)
         fused = eng.denoise(x.to(DEV), z.to(DEV), t)
         eng.set_option(_lib.PD_OPT_DENOISER_FUSED_ATTN, 0)
         plain = eng.denoise(x.to(DEV), z.to(DEV), t)
@@ -171,7 +178,7 @@ def test_fused_qkv_attention_is_bitwise_the_two_launch_path(seeded_diffuser, ora
             ref = O.denoiser_forward(sd64, x[sub].double(), torch.full((len(sub),), t, dtype=torch.long), z[sub].double())
         worst = max(rel_err(fused[s], ref[i]) for i, s in enumerate(sub))
         assert worst < 3e-6, (t, worst)
-    eng.set_option(_lib.PD_OPT_DENOISER_FUSED_ATTN, 1)
+    eng.set_option(_lib.PD_OPT_DENOISER_FUSED_ATTN, 2)
     # the option is part of the graph key: a sampling pass replayed from its graph must follow the switch
     noise = torch.randn(101, B, N, 9, generator=g).to(DEV)
     p1 = eng.sample(z.to(DEV), noise, 0, None, use_graph=True, want_process=False)[0].clone()

@@ -15,7 +15,7 @@ for tag in r4 r5; do
 done
 cd $R
 Q="--no-per-config --no-fresh-inputs --no-fast-mode --cpu-budget-s 0 --no-stream-probe"
-for tag in r4 r5 r4 r5; do
+for tag in r4 r5; do
   lib=$NEW; [ $tag = r4 ] && lib=$OLD
   PD_ENGINE_LIB=$lib timeout 300 python bench.py $Q 2>$O/bench_$tag.err | tail -1 > $O/bench_$tag.json
   python -c "

@@ -18,4 +18,3 @@ run "8-GPU rank, 2 x 80 (default)"      --seqs-per-step 8
 run "8-GPU rank, 1 x 160"               --seqs-per-step 8 --min-passes 1
 run "8-GPU rank, 3 passes (56/56/48)"   --seqs-per-step 8 --min-passes 3
 run "8-GPU rank, 4 x 40"                --seqs-per-step 8 --min-passes 4 --pipeline-depth 4
-run "4-GPU rank, 2 x 160 (default)"     --seqs-per-step 16

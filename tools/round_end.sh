@@ -2,12 +2,12 @@
 # End-of-round evidence with the final binary (on the GPU box): full GPU suite, smoke, counters, the default bench line, a kernel
 # trace of the same command (+ the co-resident analysis), a trace of ONE 256-sequence GGS launch that fills the chip, and the
 # reference's demo.py running unchanged on the drop-in when a staged copy of the reference tree travelled along (_ref_stage/).
-# Results under gpurun_out/final/ -> copy into profiles/round4_*.
+# Results under gpurun_out/final/ -> copy into profiles/round5_*.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD; F=gpurun_out/final; rm -rf $F; mkdir -p $F
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $F/pytest_gpu.txt; cat $F/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $F/smoke.txt
 bash tools/collect_pmc.sh > /dev/null 2>&1; cp gpurun_out/pmc_summary.json $F/pmc_summary.json
-mkdir -p profiles; cp gpurun_out/pmc_summary.json profiles/round4_pmc_summary.json      # bench.py reads the traffic figures from here (hash-checked)
+mkdir -p profiles; cp gpurun_out/pmc_summary.json profiles/round5_pmc_summary.json      # bench.py reads the traffic figures from here (hash-checked)
 timeout 900 python bench.py --dry-dist > $F/bench_line.json 2> $F/bench.err; tail -2 $F/bench.err
 cd /tmp && export TMPDIR=/tmp
 timeout 500 rocprofv3 --kernel-trace --stats -d $R/$F/trace -o bench -- python $R/bench.py --no-per-config --no-fresh-inputs --no-fast-mode --cpu-budget-s 0 > $R/$F/bench_traced.json 2>/dev/null

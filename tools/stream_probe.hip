@@ -35,6 +35,45 @@ __global__ void stream(const float4 *base, size_t region_f4, int iters, float *o
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x + acc.y + acc.z + acc.w + pad[threadIdx.x & 7];
 }
 
+// The lane-per-item GGS kernel's own pattern (csrc/pd_ggs_lane.inc; VERDICT / ADVICE round 4: the plain-load rows above were beaten by the
+// kernel they were meant to bound): one workgroup of 8 waves per CU, every wave streams ITS contiguous share of the private region in
+// steps of 2 KiB (two global_load_lds_dwordx4 of 1 KiB) through a ring of RING slots in LDS, RING steps in flight at all times, a slot is
+// read out with two ds_read_b128 per lane and refilled at once; the stream is periodic (pass after pass without draining).  `steps` =
+// steps per wave and pass; wave w's share starts at w * steps * 2 KiB.
+template <int RING>
+__global__ __launch_bounds__(512, 2) void stream_ring(const float4 *base, size_t region_f4, int steps, int iters, float *out) {
+    extern __shared__ __attribute__((aligned(1024))) float4 ring[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float4 *src = base + (size_t)blockIdx.x * region_f4 + (size_t)wave * steps * 128;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(ring + wave * RING * 128));
+    const float4 *rd = ring + wave * RING * 128 + lane;
+    const unsigned lane16 = lane * 16u;
+    auto fetch = [&](int slot, int idx) {
+        const unsigned off0 = (unsigned)idx * 2048u + lane16, off1 = off0 + 1024u;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)slot * 2048u);
+        unsigned keep;
+        asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o0], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[o1], %[b]\n\ts_mov_b32 m0, %[k]"
+                     : [k] "=&s"(keep) : [d] "s"(dst), [b] "s"(src), [o0] "v"(off0), [o1] "v"(off1) : "memory");
+    };
+    for (int u = 0; u < RING; ++u) fetch(u, u % steps);
+    int slot = 0, next = RING % steps;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long total = (long long)steps * iters;
+    for (long long t = 0; t < total; ++t) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RING - 2) : "memory");       // the oldest step has landed
+        float4 q0 = rd[slot * 128], q1 = rd[slot * 128 + 64];
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0.x), "+v"(q1.x) :: "memory");  // read out before the DMA may overwrite the slot
+        fetch(slot, next);
+        next = (next + 1 == steps) ? 0 : next + 1;
+        slot = (slot + 1 == RING) ? 0 : slot + 1;
+        acc.x += q0.x + q1.x; acc.y += q0.y + q1.y; acc.z += q0.z + q1.z; acc.w += q0.w + q1.w;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
+}
+
 typedef void (*kern_t)(const float4 *, size_t, int, float *);
 int main() {
     const size_t max_bytes = (size_t)256 * 3648 * 1024;
@@ -69,5 +108,28 @@ int main() {
                 const double bytes = (double)region_f4 * 16 * 256 * iters;
                 printf("%6d KB  %-16s %6d %10.4f %10.2f\n", kb, kn[k], w, ms / iters, bytes / (ms * 1e-3) / 1e12);
             }
+    // the lane kernel's pattern: LDS-DMA rings, 8 waves per CU; 708 KB per CU and pass = what a 57 000-match sequence streams per iteration
+    // beside its register-resident steps (354 steps of 2 KiB: here 44 per wave = 704 KB), and the whole 912 KB for comparison
+    typedef void (*ring_t)(const float4 *, size_t, int, int, float *);
+    ring_t rk[] = {stream_ring<4>, stream_ring<6>, stream_ring<8>};
+    const int rdepth[] = {4, 6, 8};
+    for (int k = 0; k < 3; ++k) hipFuncSetAttribute((const void *)rk[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    printf("%-10s %-16s %6s %10s %10s\n", "region/CU", "LDS-DMA ring", "waves", "ms/pass", "TB/s");
+    for (int steps : {44, 57})
+        for (int k = 0; k < 3; ++k) {
+            const size_t region_f4 = (size_t)8 * steps * 128;
+            const int iters = 60;
+            float ms = 0;
+            for (int pass = 0; pass < 2; ++pass) {
+                hipEventRecord(e0, 0);
+                // 160 KiB of LDS per workgroup (the kernel's own footprint): exactly one workgroup per CU
+                hipLaunchKernelGGL(rk[k], dim3(256), dim3(512), 160 * 1024, 0, buf, region_f4, steps, iters, out);
+                hipEventRecord(e1, 0);
+                hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+            }
+            const double bytes = (double)region_f4 * 16 * 256 * iters;
+            printf("RING %4zu KB  ring of %d x 2 KiB  %6d %10.4f %10.2f\n", region_f4 * 16 / 1024, rdepth[k], 8, ms / iters, bytes / (ms * 1e-3) / 1e12);
+        }
     return 0;
 }
