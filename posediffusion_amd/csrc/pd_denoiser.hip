@@ -934,8 +934,9 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(set_lds(pd_attn_seq_kernel<1>, attn_seq_lds(64)));
     PD_TRY(set_lds(pd_attn_seq_kernel<2>, attn_seq_lds(64)));
     PD_TRY(set_lds(pd_attn_mma_kernel<2>, attn_mma_lds(32)));
-    PD_TRY(set_lds(pd_qkv_attn_kernel<0>, 160 * 1024));
+    PD_TRY(set_lds((pd_qkv_attn_kernel<0, PD_QA_DEEP_DEFAULT != 0>), 160 * 1024));
 #ifdef PD_DEV_KNOBS
+    PD_TRY(set_lds((pd_qkv_attn_kernel<0, PD_QA_DEEP_DEFAULT == 0>), 160 * 1024));
     PD_TRY(set_lds(pd_qkv_attn_kernel<1>, 160 * 1024));
     PD_TRY(set_lds(pd_qkv_attn_kernel<2>, 160 * 1024));
     PD_TRY(set_lds(pd_qkv_attn_kernel<3>, 160 * 1024));

@@ -756,7 +756,7 @@ __device__ __forceinline__ void pd_glds_item(const float4 *base, const unsigned 
                      "global_load_lds_dwordx4 %[o0], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %[o1], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %[o2], %[b]\n\ts_mov_b32 m0, %[k]"
-                     : [k] "=&s"(keep) : [d] "s"(lds_dst), [b] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]) : "memory");
+                     : [k] "=&s"(keep) : [d] "s"(lds_dst), [b] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]) : "memory", "scc");
     else if constexpr (P == 5)
         asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %[o0], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
@@ -765,7 +765,7 @@ __device__ __forceinline__ void pd_glds_item(const float4 *base, const unsigned 
                      "global_load_lds_dwordx4 %[o3], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %[o4], %[b]\n\ts_mov_b32 m0, %[k]"
                      : [k] "=&s"(keep) : [d] "s"(lds_dst), [b] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]),
-                       [o3] "v"(off[3]), [o4] "v"(off[4]) : "memory");
+                       [o3] "v"(off[3]), [o4] "v"(off[4]) : "memory", "scc");
     else
         asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %[o0], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
@@ -775,7 +775,7 @@ __device__ __forceinline__ void pd_glds_item(const float4 *base, const unsigned 
                      "global_load_lds_dwordx4 %[o4], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %[o5], %[b]\n\ts_mov_b32 m0, %[k]"
                      : [k] "=&s"(keep) : [d] "s"(lds_dst), [b] "s"(base), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]),
-                       [o3] "v"(off[3]), [o4] "v"(off[4]), [o5] "v"(off[5]) : "memory");
+                       [o3] "v"(off[3]), [o4] "v"(off[4]), [o5] "v"(off[5]) : "memory", "scc");
 }
 template <int N>
 __device__ __forceinline__ void pd_vmcnt() {
@@ -1412,12 +1412,18 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
     unsigned epoch = 0;
     int trace_row = 0;
     const float inv_M = 1.0f / (float)D.M;
+    // phase clocks (pd_debug_ggs_prof; round 5): wave 0 of workgroup 0 (owner of frame 0) -> prof[0..7], of the last workgroup (owns no frame when
+    // k > N) -> prof[8..15]: {P1, P2, P3a, hop-1 publish + totals, P3b owner loop, hop-2 gathers, frame gradients + totals, P4}, shader cycles
+    const bool prof2 = P.prof != nullptr && b == 0 && wave == 0 && (wg == 0 || wg == k - 1);
+    long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0, q7 = 0, qc = 0;
+#define PD_PROF2H(acc) do { if (prof2) { const long long n_ = __builtin_amdgcn_s_memtime(); acc += n_ - qc; qc = n_; } } while (0)
     for (int st = 0; st < P.n_stages; ++st) {
         const PdGgsStage S = P.stages[st];
         int stepped = 0;
         float last_print = __int_as_float(0x7fc00000), last_cnt = 0.0f, last_loss = __int_as_float(0x7fc00000);
         const bool need_rt = S.update_R || S.update_T;
         for (int it = 0; it < S.iters; ++it) {
+            if (prof2) qc = __builtin_amdgcn_s_memtime();
             // ---- P1: F for the pairs of this workgroup's items
             const Cam cam = {L.cam[0], L.cam[1], L.cam[2], L.cam[3]};
             for (int s = tid; s < n_slots; s += PD_GGS_THREADS) {
@@ -1435,6 +1441,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                 }
             }
             __syncthreads();
+            PD_PROF2H(q0);
             // ---- P2: per-match Sampson residual + dL/dF, a wave per item; the 12 sums stay in this workgroup's LDS
             ++epoch;
             u64 *xs = xbase + (size_t)(epoch & 1) * P.xchg_stride;
@@ -1470,6 +1477,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                 }
             }
             __syncthreads();
+            PD_PROF2H(q1);
             // ---- P3a: backward of this workgroup's pairs (thread per local item), rows 2s (side 0), 2s + 1 (side 1)
             if (tid < n_slots && L.itab[tid].y > 0) {
                 const int4 e = L.itab[tid];
@@ -1481,6 +1489,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
 #include "pd_ggs_pairbwd.inc"
             }
             __syncthreads();
+            PD_PROF2H(q2);
             // ---- hop 1: publish the (pair, side) rows; thread (row = tid / 16, component = tid % 16), 32 rows per pass
             for (int r0 = 0; r0 < 2 * n_slots; r0 += PD_GGS_THREADS / 16) {
                 const int row = r0 + (tid >> 4);
@@ -1509,6 +1518,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            PD_PROF2H(q3);
             // ---- P3b: the owner of frame n sums that frame's rows in row order and publishes the frame line
             bool ok = true;
             for (int n = wg; n < N; n += k) {
@@ -1523,6 +1533,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                 }
                 __syncthreads();
             }
+            PD_PROF2H(q4);
             // ---- hop 2: everybody gathers the N frame lines and the k totals lines
             ok = ggs2_gather<2>(xs + (size_t)(n_inc + k) * PD_XCHG_LINE, tid, N * 8, 8, epoch, L.psum, 16, P.err_flag) && ok;
             ok = ggs2_gather<1>(xs + (size_t)n_inc * PD_XCHG_LINE, tid, k * 2, 2, epoch, tot_rows, 4, P.err_flag) && ok;
@@ -1532,6 +1543,7 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
             }
             __syncthreads();
             if (L.ctl[1] != 0.0f) return;
+            PD_PROF2H(q5);
             // per-frame gradients back through tc = D T and Rc[a][b] = D[a] R[b][a]; totals in workgroup order
             for (int q = tid; q < N * 16; q += PD_GGS_THREADS) {
                 const int n = q >> 4, c = q & 15;
@@ -1560,8 +1572,10 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                 }
             }
             __syncthreads();
+            PD_PROF2H(q6);
 #include "pd_ggs_p4.inc"
             __syncthreads();
+            PD_PROF2H(q7);
             if (L.ctl[0] != 0.0f) break;
         }
         if (wave == 0 && lane == 0 && wg == 0 && P.stats) {
@@ -1573,6 +1587,11 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
         }
         if (P.eval_only) break;
     }
+    if (prof2 && lane == 0) {
+        long long *o = P.prof + (wg == 0 ? 0 : 8);
+        o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3; o[4] = q4; o[5] = q5; o[6] = q6; o[7] = q7;
+    }
+#undef PD_PROF2H
     if (own && wg == 0 && !P.eval_only) {
 #pragma unroll
         for (int c = 0; c < 9; ++c) xg[lane * 9 + c] = L.xst[lane * PD_XS_STRIDE + c];

@@ -22,6 +22,9 @@
 #define PD_QA_ROWS 96                       // three 32-row tiles
 #define PD_QA_LDR (3 * DH + 4)              // row stride of the Q | K | V image in LDS (floats): 388 = 4 mod 32 banks, like DH + 4
 #define PD_QA_LS 36                         // row stride of a team's score tile
+#ifndef PD_QA_DEEP_DEFAULT
+#define PD_QA_DEEP_DEFAULT 1                // weight fragments a whole chunk ahead (see DEEP below)
+#endif
 
 struct PdQkvAttnArgs {
     const unsigned *A;        // LayerNorm output as split words [M][DM] (pd_ln_rows_kernel<DM, 2>)
@@ -42,7 +45,10 @@ static inline size_t pd_qkv_attn_lds(int N) {
 
 // BARE (development builds only, -DPD_DEV_KNOBS + PD_QA_BARE=n; results meaningless for n > 0): what bounds the kernel -- 1 no weight-fragment loads
 // inside the K loop, 2 no LDS-DMA inside it, 3 neither, 4 everything but the MFMAs, 5 the product only (no Q | K | V image, no attention)
-template <int BARE>
+// DEEP: the weight fragments of chunk c + 1 (both 32-k blocks: 8 KiB per wave) are requested at the START of chunk c into a second register set,
+// before any MFMA of the chunk is issued (a wave issues in order: loads placed behind a block's 18 MFMAs leave only when the matrix pipe has
+// taken them all) -- a whole chunk of matrix work to hide behind instead of half of one; the same MFMA order, bitwise the same result.
+template <int BARE, bool DEEP = false>
 __global__ __launch_bounds__(PD_QA_THREADS) void pd_qkv_attn_kernel(PdQkvAttnArgs g) {
     constexpr int KC = 32, RT = 3, TM = PD_QA_ROWS, CHA = TM * KC, LDR = PD_QA_LDR, LS = PD_QA_LS;
     extern __shared__ __attribute__((aligned(1024))) unsigned qa_lds[];
@@ -121,6 +127,35 @@ __global__ __launch_bounds__(PD_QA_THREADS) void pd_qkv_attn_kernel(PdQkvAttnArg
         PD_QA_WAIT(0, a0, a1, a2, a3);
         PD_QA_WAIT(0, b0, b1, b2, b3);
         __syncthreads();
+        if constexpr (DEEP) {
+            static_assert(!DEEP || BARE == 0, "the deep form has no development variants");
+            wv4 c0, c1, c2, c3, d0, d1, d2, d3;              // the second set: chunk c + 1 while a / b hold chunk c, and vice versa
+            for (int c = 0; c < nk64; c += 2) {              // nk64 is even
+                {
+                    const unsigned *a = qa_lds + 0 * 2 * CHA + l31 * KC;
+                    stage64(c + 1, 1);
+                    PD_QA_WLOAD(c0, c1, c2, c3, 2 * (c + 1));
+                    PD_QA_WLOAD(d0, d1, d2, d3, 2 * (c + 1) + 1);
+                    block(a, a0, a1, a2, a3);
+                    block(a + CHA, b0, b1, b2, b3);
+                    PD_QA_WAIT(0, c0, c1, c2, c3);           // everything requested at the start of this chunk has landed
+                    PD_QA_WAIT(0, d0, d1, d2, d3);
+                    __syncthreads();
+                }
+                {
+                    const int cn = min(c + 2, nk64 - 1);     // the chunk after the last is the last again (never used)
+                    const unsigned *a = qa_lds + 1 * 2 * CHA + l31 * KC;
+                    stage64(cn, 0);
+                    PD_QA_WLOAD(a0, a1, a2, a3, 2 * cn);
+                    PD_QA_WLOAD(b0, b1, b2, b3, 2 * cn + 1);
+                    block(a, c0, c1, c2, c3);
+                    block(a + CHA, d0, d1, d2, d3);
+                    PD_QA_WAIT(0, a0, a1, a2, a3);
+                    PD_QA_WAIT(0, b0, b1, b2, b3);
+                    __syncthreads();
+                }
+            }
+        } else
         for (int c = 0; c < nk64; ++c) {
             const int cn = min(c + 1, nk64 - 1);                 // the chunk after the last is the last again (never used)
             const unsigned *a = qa_lds + (c & 1) * 2 * CHA + l31 * KC;
@@ -273,6 +308,8 @@ static inline void pd_qkv_attn(const unsigned *hn, const unsigned *Wh, const flo
     static const int bare = pd_dev_knob("PD_QA_BARE", 0);
     const dim3 grid(((B + G - 1) / G) * NH), blk(PD_QA_THREADS);
     const size_t lds = pd_qkv_attn_lds(N);
+    static const int deep = pd_dev_knob("PD_QA_DEEP", PD_QA_DEEP_DEFAULT);
+    if (bare == 0 && !deep) { hipLaunchKernelGGL((pd_qkv_attn_kernel<0, false>), grid, blk, lds, s, g); return; }
     switch (bare) {
     case 1: hipLaunchKernelGGL(pd_qkv_attn_kernel<1>, grid, blk, lds, s, g); return;
     case 2: hipLaunchKernelGGL(pd_qkv_attn_kernel<2>, grid, blk, lds, s, g); return;
@@ -282,5 +319,5 @@ static inline void pd_qkv_attn(const unsigned *hn, const unsigned *Wh, const flo
     default: break;
     }
 #endif
-    hipLaunchKernelGGL(pd_qkv_attn_kernel<0>, dim3(((B + G - 1) / G) * NH), dim3(PD_QA_THREADS), pd_qkv_attn_lds(N), s, g);
+    hipLaunchKernelGGL((pd_qkv_attn_kernel<0, PD_QA_DEEP_DEFAULT != 0>), dim3(((B + G - 1) / G) * NH), dim3(PD_QA_THREADS), pd_qkv_attn_lds(N), s, g);
 }

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(512, 2) void stream_ring(const float4 *base, size_t
         asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %[o0], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %[o1], %[b]\n\ts_mov_b32 m0, %[k]"
-                     : [k] "=&s"(keep) : [d] "s"(dst), [b] "s"(src), [o0] "v"(off0), [o1] "v"(off1) : "memory");
+                     : [k] "=&s"(keep) : [d] "s"(dst), [b] "s"(src), [o0] "v"(off0), [o1] "v"(off1) : "memory", "scc");
     };
     for (int u = 0; u < RING; ++u) fetch(u, u % steps);
     int slot = 0, next = RING % steps;
@@ -129,7 +129,7 @@ int main() {
                 hipEventElapsedTime(&ms, e0, e1);
             }
             const double bytes = (double)region_f4 * 16 * 256 * iters;
-            printf("RING %4zu KB  ring of %d x 2 KiB  %6d %10.4f %10.2f\n", region_f4 * 16 / 1024, rdepth[k], 8, ms / iters, bytes / (ms * 1e-3) / 1e12);
+            fflush(stdout); printf("RING %4zu KB  ring of %d x 2 KiB  %6d %10.4f %10.2f\n", region_f4 * 16 / 1024, rdepth[k], 8, ms / iters, bytes / (ms * 1e-3) / 1e12);
         }
     return 0;
 }
