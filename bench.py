@@ -682,7 +682,8 @@ def main():
     roofline = {
         "kernel": f"{kname}: one launch = one guided diffusion step = 700 iterations x {EB} sequences, {k_eff} workgroup(s) per sequence",
         "bound": "valu", "bound_detail": "fp32 vector ALU, 157.3 TFLOP/s (SURVEY 8d names the arithmetic roofline for the Sampson kernel; the kernel issues no "
-                                         "MFMA).  What actually binds the one-workgroup-per-sequence launch is the match stream: see `fabric`",
+                                         "MFMA).  A full-chip launch of it waits for VALU issue (~80 % of the packed-fp32 issue rate the SIMDs sustain) and for "
+                                         "its match stream (`fabric`: ~94 % of the HBM peak figure, out of the Infinity Cache) at once",
         "achieved": ggs_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ggs_tflops / FP32_PEAK_TFLOPS,
         "algorithmic_flops_per_launch": ggs_flops, "algorithmic_flop_per_match_iteration": FLOP_PER_MATCH_ITER,
         "launch_ms": ggs_ms, "launch_ms_each": ggs_each, "launch_timing": "hipEvents around the launch on its stream (pd_time_kernel), one launch alone on the chip: "
@@ -697,17 +698,18 @@ def main():
                    "streamed_GBps_one_launch": match_bytes * streamed / (ggs_ms * 1e-3) / 1e9,
                    "achieved_GBps_co_resident": depth * match_bytes / (ggs_set_ms * 1e-3) / 1e9,
                    "hbm_peak_GBps": HBM_PEAK_GBS, "frac_of_hbm_peak_one_launch": match_bytes / (ggs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                   "measured_ceiling_GBps": None if ceil_rng is None else [ceil_rng[0][0], ceil_rng[0][1]], "measured_ceiling_source": ceil_src,
-                   "plain_load_probe_GBps": None if (ceil_rng is None or ceil_rng[1] is None) else [ceil_rng[1][0], ceil_rng[1][1]],
-                   "frac_of_measured_ceiling_one_launch": None if ceil_rng is None else streamed_rate / ceil_rng[0][1],
-                   "ceiling_exceeded": None if ceil_rng is None else bool(streamed_rate > 1.03 * ceil_rng[0][1]),
-                   "frac_of_measured_ceiling_note": "STREAMED bytes (algorithmic x streamed_fraction = what the launch pulls through the fabric per iteration: the PMC "
-                                                    "FETCH_SIZE of the launch equals it, profiles/round5_pmc_summary.json; the register-resident steps are read once per "
-                                                    "launch) over the best rate of the LDS-DMA ring probe on this box.  Rounds 3-4 quoted the probe's plain-load rows "
-                                                    "(`plain_load_probe_GBps`), which the kernel's LDS-DMA stream exceeded (1.06): no ceiling for this pattern.  "
-                                                    "`ceiling_exceeded` flags a run whose rate is above the ring probe's by more than 3 %",
-                   "why_reported": "the match stream is what a full-chip launch of this kernel waits for besides its VALU issue (DESIGN 3.2): the rate of the same "
-                                   "pattern without arithmetic says how much of the fabric the launch uses on THIS box; boxes differ by +-8 %",
+                   "frac_of_hbm_peak_streamed_one_launch": streamed_rate / HBM_PEAK_GBS,
+                   "probe_rates_GBps": None if ceil_rng is None else {"lds_dma_ring_like_the_kernel": [ceil_rng[0][0], ceil_rng[0][1]],
+                                                                        "plain_loads": None if ceil_rng[1] is None else [ceil_rng[1][0], ceil_rng[1][1]]},
+                   "probe_rates_source": ceil_src,
+                   "ratio_to_best_probe_rate": None if ceil_rng is None else streamed_rate / max(ceil_rng[0][1], ceil_rng[1][1] if ceil_rng[1] else 0.0),
+                   "probe_rates_note": "REFERENCE rates of two synthetic streams on this box, not ceilings: rounds 3-4 called the plain-load probe a 'measured ceiling' "
+                                       "and the kernel exceeded it (1.06); round 5 rebuilt the probe with the kernel's own pattern (8 waves per CU, 2 KiB steps through "
+                                       "LDS rings fed by global_load_lds_dwordx4) and the kernel still streams faster than it (ratio > 1: its requests are spread "
+                                       "over the iteration by 59 VALU instructions per step instead of arriving in lockstep).  The hard bounds are the HBM peak "
+                                       "(`hbm_peak_GBps`; the 233 MB working set is Infinity-Cache resident, so even that is not binding by itself) and the "
+                                       "fp32 ALU peak of `roofline.peak`; STREAMED bytes = algorithmic x streamed_fraction = the PMC FETCH_SIZE of the launch "
+                                       "(profiles/round5_pmc_summary.json)",
                    "note": f"{EB * depth} sequences in flight, at most 256 of them (one GGS workgroup per CU) iterating at a time: {min(EB * depth, 256)} x "
                            f"{M * MATCH_BYTES / 1e6:.2f} MB of matches = {min(EB * depth, 256) * M * MATCH_BYTES / 1e6:.0f} MB re-read every iteration at one workgroup "
                            "per sequence (a chosen trade: no replicated serial phase); that set fits the 256 MiB Infinity Cache, so this is fabric / "

@@ -23,7 +23,7 @@
 #define PD_QA_LDR (3 * DH + 4)              // row stride of the Q | K | V image in LDS (floats): 388 = 4 mod 32 banks, like DH + 4
 #define PD_QA_LS 36                         // row stride of a team's score tile
 #ifndef PD_QA_DEEP_DEFAULT
-#define PD_QA_DEEP_DEFAULT 1                // weight fragments a whole chunk ahead (see DEEP below)
+#define PD_QA_DEEP_DEFAULT 0                // 1: weight fragments a whole chunk ahead (DEEP below) -- measured no faster (925 vs 926 us per step), 35 more registers
 #endif
 
 struct PdQkvAttnArgs {
