@@ -417,9 +417,6 @@ def main():
     tables = {k: v for k, v in diff.named_buffers(recurse=False)}
     eng = get_engine(diff.model, diff, EB, N_FRAMES)
     engines = [eng] + [PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=EB, max_N=N_FRAMES) for _ in range(depth - 1)]
-    if os.environ.get("PD_BENCH_BIG_GEMM") is not None:          # A / B switch (pd_engine.h PD_OPT_DENOISER_BIG_GEMM: bit mask out-projection | FF1 | FF2)
-        for e in engines:
-            e.set_option(_lib.PD_OPT_DENOISER_BIG_GEMM, int(os.environ["PD_BENCH_BIG_GEMM"]))
     slots = depth if args.ggs_slots <= 0 else min(args.ggs_slots, depth)
     pipe = SamplingPipeline(engines, slots, dev, unguided_streams=max(0, args.unguided_streams), trace=args.trace)
     # one resident engine batch per context (different sequences: seeds offset per context and rank)

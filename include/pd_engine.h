@@ -231,12 +231,6 @@ int pd_ggs_loss_grad(pd_engine *eng, const float *x, int B, int N, int update_R,
  *        frames = 256 workgroups; a batch of 103 keeps the two launches; 2: always; 0: never = the two launches it replaces (QKV GEMM -> fp32
  *        QKV in memory -> attention).  Same arithmetic in the same order: bitwise the same results whatever the choice. */
 #define PD_OPT_DENOISER_FUSED_ATTN 5
-/*   PD_OPT_DENOISER_BIG_GEMM  (fp16-plane mode) bit mask {1 out-projection, 2 FF1, 4 FF2}, default 7: those GEMMs run on 96 x 256 tiles with 8
- *        wavefronts per workgroup (the fused kernel's K loop: ~65 % of the matrix pipe against 26 - 34 % for the 64 x 128-tile kernel) where their
- *        workgroups fill at least three quarters of the chip's rounds (5 120 token rows: 216 workgroups; + 8: whatever the fill -- testing); 0 keeps
- *        the 64 x 128-tile kernel.
- *        Same products in the same order: bitwise the same results. */
-#define PD_OPT_DENOISER_BIG_GEMM 6
 int pd_engine_set_option(pd_engine *eng, int option, int value);
 /* Reads an option back.  PD_OPT_DENOISER_SPLIT: the mode in force (an engine created from weights that hold inf / NaN stays on 0 although
  * it is large enough for 2 -- the only downgrade pd_engine_create performs by itself; PD_OPT_WEIGHTS_NON_FINITE (read-only) then reads 1). */

@@ -61,7 +61,6 @@ PD_GGS_CFG_XCHG_SPREAD = 32     # k > 1: no XCD-local placement of a sequence's 
 PD_OPT_DENOISER_SPLIT = 2
 PD_OPT_WEIGHTS_NON_FINITE = 4   # pd_engine_get_option only
 PD_OPT_DENOISER_FUSED_ATTN = 5  # in_proj + attention as one kernel, Q / K / V in LDS (default 1)
-PD_OPT_DENOISER_BIG_GEMM = 6    # bit mask {out-projection, FF1, FF2}: 96 x 256-tile GEMM where it fills the chip (default 7)
 PD_MATCH_HINT_ONE_ORDER = 1 << 30   # pd_match_hints.max_pairs flag: every frame pair in one order only (hloc's i < j pairs)
 
 

@@ -935,8 +935,6 @@ int pd_denoiser_create(pd_engine *eng, const pd_weights *w) {
     PD_TRY(set_lds(pd_attn_seq_kernel<2>, attn_seq_lds(64)));
     PD_TRY(set_lds(pd_attn_mma_kernel<2>, attn_mma_lds(32)));
     PD_TRY(set_lds((pd_qkv_attn_kernel<0, PD_QA_DEEP_DEFAULT != 0>), 160 * 1024));
-    PD_TRY(set_lds(pd_gemm_big_kernel<2>, 64 * 1024));
-    PD_TRY(set_lds(pd_gemm_big_kernel<4>, 64 * 1024));
 #ifdef PD_DEV_KNOBS
     PD_TRY(set_lds((pd_qkv_attn_kernel<0, PD_QA_DEEP_DEFAULT == 0>), 160 * 1024));
     PD_TRY(set_lds(pd_qkv_attn_kernel<1>, 160 * 1024));
@@ -1204,19 +1202,12 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
                 if (N <= 32 && attn_mma) hipLaunchKernelGGL(pd_attn_mma_kernel<2>, dim3(B * NH), dim3(256), attn_mma_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
                 else hipLaunchKernelGGL(pd_attn_seq_kernel<2>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
             }
-            // the 96 x 256-tile GEMM (pd_gemm_big_kernel: the fused kernel's K loop, ~65 % of the matrix pipe against the strip kernel's 26 - 34 %) where its
-            // workgroups fill the chip like the fused kernel's; den_big_gemm: bit mask {out-projection, FF1, FF2} of the GEMMs that may take it
-            const bool big_fills = 4 * pd_gemm_big_blocks(M, DFF) >= 3 * ((pd_gemm_big_blocks(M, DFF) + cus - 1) / cus) * cus;
-            const int big = (big_fills || (eng->den_big_gemm & 8)) ? (eng->den_big_gemm & 7) : 0;      // (bit 3: whatever the fill -- testing)
-            if (big & 1) pd_gemm_big<2>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
-            else if (strip & 2) pd_gemm_strip<2, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
+            if (strip & 2) pd_gemm_strip<2, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
             else pd_gemm_split<2, 1, 1, true>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
             hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 2>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 512.0f);
-            if (big & 2) pd_gemm_big<4>((const unsigned *)d->hn, DM, L.ff1_wh, DM, L.ff1_b, d->ff, M, DFF, s, L.ff1_cs, L.ff_scale);
-            else if (strip & 4) pd_gemm_strip<4, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->hn, DM, L.ff1_wh, DM, L.ff1_b, d->ff, M, DFF, s, L.ff1_cs, L.ff_scale);
+            if (strip & 4) pd_gemm_strip<4, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->hn, DM, L.ff1_wh, DM, L.ff1_b, d->ff, M, DFF, s, L.ff1_cs, L.ff_scale);
             else pd_gemm_split<4, 1, 2, true>((const unsigned *)d->hn, DM, L.ff1_wh, DM, L.ff1_b, d->ff, M, DFF, s, L.ff1_cs, L.ff_scale);
-            if (big & 4) pd_gemm_big<2>((const unsigned *)d->ff, DFF, L.ff2_wh, DFF, L.ff2_b, d->h, M, DM, s, L.ff2_cs);
-            else if (strip & 8) pd_gemm_strip<2, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->ff, DFF, L.ff2_wh, DFF, L.ff2_b, d->h, M, DM, s, L.ff2_cs);
+            if (strip & 8) pd_gemm_strip<2, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->ff, DFF, L.ff2_wh, DFF, L.ff2_b, d->h, M, DM, s, L.ff2_cs);
             else pd_gemm_split<2, 1, 1, true>((const unsigned *)d->ff, DFF, L.ff2_wh, DFF, L.ff2_b, d->h, M, DM, s, L.ff2_cs);
             continue;
         }

@@ -356,7 +356,7 @@ extern "C" int pd_sample_phase(pd_engine *eng, const float *z, const float *nois
         key.cond_start = has_ggs ? cond_start_step : 0;
         key.has_ggs = has_ggs;
         key.phase = phase;
-        key.den_split = eng->den_split | (eng->den_fused_attn << 8) | (eng->den_big_gemm << 12);      // the options change the captured launches
+        key.den_split = eng->den_split | (eng->den_fused_attn << 8);      // the options change the captured launches
         if (has_ggs) {
             key.cfg = *ggs;
             // the GGS nodes bake the match-derived launch shape in: a re-upload with another item count must not
@@ -449,13 +449,6 @@ extern "C" int pd_engine_set_option(pd_engine *eng, int option, int value) {
         }
         eng->den_fused_attn = value;
         break;
-    case PD_OPT_DENOISER_BIG_GEMM:
-        if (value < 0 || value > 15) {
-            pd_set_error("pd_engine_set_option: PD_OPT_DENOISER_BIG_GEMM takes a bit mask 0 .. 15 (got %d)", value);
-            return PD_ERR_INVALID_ARG;
-        }
-        eng->den_big_gemm = value;
-        break;
     case 3:      // (PD_OPT_DENOISER_PERSISTENT of round 3: the persistent small-batch kernel was measured 2.4 x slower and parked, tools/parked/)
         if (value == 0) break;
         pd_set_error("pd_engine_set_option: option 3 (the persistent small-batch denoiser launch of round 3) is no longer built: it measured "
@@ -476,7 +469,6 @@ extern "C" int pd_engine_get_option(pd_engine *eng, int option, int *value_out) 
     switch (option) {
     case PD_OPT_DENOISER_SPLIT: *value_out = eng->den_split; break;
     case PD_OPT_DENOISER_FUSED_ATTN: *value_out = eng->den_fused_attn; break;
-    case PD_OPT_DENOISER_BIG_GEMM: *value_out = eng->den_big_gemm; break;
     case PD_OPT_WEIGHTS_NON_FINITE: *value_out = pd_denoiser_weights_non_finite(eng) ? 1 : 0; break;
     default:
         pd_set_error("pd_engine_get_option: unknown option %d", option);

@@ -178,7 +178,6 @@ struct pd_engine {
     size_t xchg_granules = 0;            // per (sequence, slot)
     unsigned int *d_err = nullptr;       // [0] async error word; [2..] debug phase counters
     int ggs_prof_on = 0;
-    int den_big_gemm = 7;            // PD_OPT_DENOISER_BIG_GEMM: bit mask {1 out-projection, 2 FF1, 4 FF2} of the fp16-plane GEMMs that take the 96 x 256-tile kernel where it fills the chip
     int den_fused_attn = 1;          // PD_OPT_DENOISER_FUSED_ATTN: in the fp16-plane mode, in_proj + attention as one kernel with Q / K / V in LDS (N <= 32)
     int den_split = 0;               // PD_OPT_DENOISER_SPLIT: encoder GEMMs of the large-batch path: 0 exact fp32, 1 bf16 planes, 2 fp16 planes (default there)
     int gemm_wide_min_tiles = 200;   // launch_gemm: 32-wide tiles when there are at least this many of them

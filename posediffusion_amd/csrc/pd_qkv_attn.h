@@ -321,139 +321,3 @@ static inline void pd_qkv_attn(const unsigned *hn, const unsigned *Wh, const flo
 #endif
     hipLaunchKernelGGL((pd_qkv_attn_kernel<0, PD_QA_DEEP_DEFAULT != 0>), dim3(((B + G - 1) / G) * NH), dim3(PD_QA_THREADS), pd_qkv_attn_lds(N), s, g);
 }
-
-// ---- the same K loop as a plain GEMM: 96 x 256 tiles, 8 waves (round 5) -----------------------------------------------------------------
-// pd_gemm_strip_kernel (64 x 128 tile, 4 waves, several workgroups per CU) keeps the matrix pipe 26 - 34 % busy at 5 120 rows; the K loop above --
-// three row tiles per wave, 36 MFMAs per wave and 64-k chunk, one barrier per chunk for the whole CU -- ~65 % (profiles/round5_qkv_attn_bare.txt,
-// counters).  pd_gemm_big_kernel is that loop with the strip kernel's epilogues: a workgroup of 8 waves owns 96 rows x 256 columns (every wave a
-// 32-column strip over three 32-row tiles), A rows (split words) by LDS-DMA in 64-k chunks, weight fragments straight to registers half a chunk
-// ahead.  The products of an output element are accumulated in pd_gemm_strip_kernel's order: BITWISE its C.  EPI 2: + bias + C (residual, fp32, in
-// place); EPI 4: relu(+ bias) as split words of v * out_scale.  Nout must be a multiple of 256, K of 64.
-// A 32-k block of A is 12 pieces of 1 KiB for 8 waves: wave w moves pieces w and (w < 4 ? w + 8 : w again -- the same bytes to the same place),
-// so that every wave has the same number of vector-memory operations in flight (the hand-written s_waitcnt counts them).
-#define PD_BIG_WAVES 8
-#define PD_BIG_THREADS (PD_BIG_WAVES * 64)
-template <int EPI>
-__global__ __launch_bounds__(PD_BIG_THREADS) void pd_gemm_big_kernel(VitSplitArgs g) {
-    constexpr int KC = 32, RT = 3, TM = 96, CHA = TM * KC;
-    static_assert(EPI == 2 || EPI == 4, "residual (fp32) or relu (split words) epilogue");
-    extern __shared__ __attribute__((aligned(1024))) unsigned big_lds[];
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ncg = g.Nout >> 8;                                   // column groups of 256; neighbours in the block order (XCD b % 8 hosts group b % ncg)
-    const int cg = blockIdx.x % ncg, rg = blockIdx.x / ncg;
-    const int m0 = rg * TM, n0 = cg * 256;
-    const int prow = lane >> 3, pslot = lane & 7;
-    unsigned oa[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int piece = (j == 0 || wave >= 4) ? wave : wave + 8;
-        const int r = 8 * piece + prow;
-        oa[j] = (unsigned)(((size_t)min(m0 + r, g.M - 1) * g.lda + 4 * (pslot ^ ((r >> 1) & 7))) * sizeof(unsigned));
-    }
-    const unsigned lds_p0 = (unsigned)(size_t)(big_lds + wave * 256), lds_p1 = (unsigned)(size_t)(big_lds + (wave >= 4 ? wave : wave + 8) * 256);
-    const int KS = g.K / 16;
-    const uint4 *wq = (const uint4 *)g.W + (size_t)(n0 / 32 + wave) * KS * 128 + lane;
-    typedef unsigned wv4 __attribute__((ext_vector_type(4)));
-    f32x16 acc[RT];
-#pragma unroll
-    for (int mi = 0; mi < RT; ++mi)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mi][i] = 0.0f;
-    auto mmaw = [](const uint4 &a, const wv4 &b, const f32x16 &c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    };
-#define PD_BIG_WLOAD(w0, w1, w2, w3, b)                                                                                              \
-    do {                                                                                                                             \
-        const uint4 *wp_ = wq + (size_t)(b) * 256;                                                                                   \
-        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"                           \
-                     "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"                    \
-                     : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(wp_) : "memory");                                            \
-    } while (0)
-#define PD_BIG_WAIT(n, w0, w1, w2, w3) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : : "memory")
-    auto stage64 = [&](int c, int buf) {            // both 32-k blocks of chunk c: four pieces per wave
-        const unsigned d0 = __builtin_amdgcn_readfirstlane(lds_p0 + buf * 2 * CHA * 4), d1 = __builtin_amdgcn_readfirstlane(lds_p1 + buf * 2 * CHA * 4);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float *ab = (const float *)(g.A + (2 * c + h) * KC);
-            pd_dma_piece(ab, oa[0], d0 + h * CHA * 4);
-            pd_dma_piece(ab, oa[1], d1 + h * CHA * 4);
-        }
-    };
-    auto block = [&](const unsigned *a, const wv4 &w0, const wv4 &w1, const wv4 &w2, const wv4 &w3) {
-        uint4 ah[RT], al[RT];
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-#pragma unroll
-            for (int mi = 0; mi < RT; ++mi) {
-                const uint4 p = *(const uint4 *)(a + mi * 32 * KC + 4 * ((4 * st + 2 * hi) ^ ((l31 >> 1) & 7)));
-                const uint4 q = *(const uint4 *)(a + mi * 32 * KC + 4 * ((4 * st + 2 * hi + 1) ^ ((l31 >> 1) & 7)));
-                ah[mi] = make_uint4(__builtin_amdgcn_perm(p.y, p.x, 0x05040100u), __builtin_amdgcn_perm(p.w, p.z, 0x05040100u),
-                                    __builtin_amdgcn_perm(q.y, q.x, 0x05040100u), __builtin_amdgcn_perm(q.w, q.z, 0x05040100u));
-                al[mi] = make_uint4(__builtin_amdgcn_perm(p.y, p.x, 0x07060302u), __builtin_amdgcn_perm(p.w, p.z, 0x07060302u),
-                                    __builtin_amdgcn_perm(q.y, q.x, 0x07060302u), __builtin_amdgcn_perm(q.w, q.z, 0x07060302u));
-            }
-            const wv4 &wh = st ? w2 : w0, &wl = st ? w3 : w1;
-#pragma unroll
-            for (int mi = 0; mi < RT; ++mi) acc[mi] = mmaw(al[mi], wh, acc[mi]);
-#pragma unroll
-            for (int mi = 0; mi < RT; ++mi) acc[mi] = mmaw(ah[mi], wl, acc[mi]);
-#pragma unroll
-            for (int mi = 0; mi < RT; ++mi) acc[mi] = mmaw(ah[mi], wh, acc[mi]);
-        }
-    };
-    {
-        wv4 a0, a1, a2, a3, b0, b1, b2, b3;
-        const int nk64 = g.K / 64;
-        stage64(0, 0);
-        PD_BIG_WLOAD(a0, a1, a2, a3, 0);
-        PD_BIG_WLOAD(b0, b1, b2, b3, 1);
-        PD_BIG_WAIT(0, a0, a1, a2, a3);
-        PD_BIG_WAIT(0, b0, b1, b2, b3);
-        __syncthreads();
-        for (int c = 0; c < nk64; ++c) {
-            const int cn = min(c + 1, nk64 - 1);                 // the chunk after the last is the last again (never used)
-            const unsigned *a = big_lds + (c & 1) * 2 * CHA + l31 * KC;
-            stage64(cn, (c + 1) & 1);                            // in flight, oldest first: the second block's weights [4, from the previous turn], this DMA [4]
-            block(a, a0, a1, a2, a3);
-            PD_BIG_WLOAD(a0, a1, a2, a3, 2 * cn);                //   ... + the next chunk's first block [4]
-            PD_BIG_WAIT(8, b0, b1, b2, b3);                      // the second block's weights have landed
-            block(a + CHA, b0, b1, b2, b3);
-            PD_BIG_WLOAD(b0, b1, b2, b3, 2 * cn + 1);            //   ... + the next chunk's second block [4]
-            PD_BIG_WAIT(4, a0, a1, a2, a3);                      // the next chunk's rows and first block have landed
-            __syncthreads();
-        }
-        PD_BIG_WAIT(0, b0, b1, b2, b3);
-    }
-#undef PD_BIG_WLOAD
-#undef PD_BIG_WAIT
-    const int col = n0 + wave * 32 + l31;
-    const float bias = g.bias[col];
-#pragma unroll
-    for (int mi = 0; mi < RT; ++mi) {
-        const int r0 = m0 + mi * 32 + 4 * hi;
-        float res[16];
-        if constexpr (EPI == 2) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) res[i] = ((const float *)g.C)[(size_t)min(r0 + (i & 3) + 8 * (i >> 2), g.M - 1) * g.Nout + col];
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = r0 + (i & 3) + 8 * (i >> 2);
-            float v = fmaf(acc[mi][i], g.c_scale, bias);
-            if constexpr (EPI == 4) v = pd_relu(v);
-            if constexpr (EPI == 2) v += res[i];
-            if (row < g.M) {
-                if constexpr (EPI == 4) ((unsigned *)g.C)[(size_t)row * g.Nout + col] = pd_split_word_as<2>(v, g.out_scale);
-                else ((float *)g.C)[(size_t)row * g.Nout + col] = v;
-            }
-        }
-    }
-}
-static inline int pd_gemm_big_blocks(int M, int Nout) { return ((M + 95) / 96) * (Nout / 256); }
-template <int EPI>
-static inline void pd_gemm_big(const unsigned *A, int lda, const unsigned *W, int K, const float *bias, void *C, int M, int Nout, hipStream_t s,
-                               float c_scale, float out_scale = 1.0f) {
-    VitSplitArgs g{A, W, bias, C, M, Nout, K, lda, c_scale, out_scale};
-    hipLaunchKernelGGL((pd_gemm_big_kernel<EPI>), dim3(pd_gemm_big_blocks(M, Nout)), dim3(PD_BIG_THREADS), (size_t)4 * 96 * 32 * sizeof(unsigned), s, g);
-}

@@ -159,14 +159,14 @@ def test_noise_drawn_straight_into_its_slots():
 
 @pytest.mark.parametrize("B,N", [(256, 20), (103, 20), (40, 32), (160, 7), (50, 24), (64, 17)])
 def test_fused_qkv_attention_is_bitwise_the_two_launch_path(seeded_diffuser, oracle_weights, B, N):
-    """models/denoiser.py:79-98 in the fp16-plane mode, the round-5 kernels against the ones they replace, bit for bit.  pd_qkv_attn_kernel -- one workgroup per
+    """models/denoiser.py:88-97 (in_proj + attention of the encoder layers) in the fp16-plane mode: pd_qkv_attn_kernel -- one workgroup per
     (group of 95 // N whole sequences, head), Q / K / V only ever in LDS -- against the two launches it replaces (pd_gemm_strip_kernel ->
     fp32 QKV in memory -> pd_attn_mma_kernel): the same sums in the same order, so a whole denoiser evaluation must agree BIT FOR BIT, at the
     bench's 5 120 rows, with a ragged last group (103 = 25 x 4 + 3), two sequences of 32 frames per workgroup (one row tile idle), thirteen
     of 7 (five rounds of the three attention teams), three of 24 and five of 17 (85 rows); and within the teacher-forced bound of the fp64
     oracle on a few sequences (first / last group, a ragged one)."""
     eng = _engine(seeded_diffuser, B, N)
-    assert eng.get_option(_lib.PD_OPT_DENOISER_SPLIT) == 2 and eng.get_option(_lib.PD_OPT_DENOISER_FUSED_ATTN) == 1 and eng.get_option(_lib.PD_OPT_DENOISER_BIG_GEMM) == 7
+    assert eng.get_option(_lib.PD_OPT_DENOISER_SPLIT) == 2 and eng.get_option(_lib.PD_OPT_DENOISER_FUSED_ATTN) == 1
     g = torch.Generator().manual_seed(7 * B + N)
     x, z = torch.randn(B, N, 9, generator=g), synth.make_z(B, N, seed=B + N)
     sd64 = {k: v.double() for k, v in oracle_weights.items()}
@@ -180,16 +180,6 @@ def test_fused_qkv_attention_is_bitwise_the_two_launch_path(seeded_diffuser, ora
         assert torch.isfinite(fused).all()
         bad = (fused != plain).reshape(B, -1).any(dim=1).nonzero().flatten().tolist()
         assert not bad, f"t={t}: sequences {bad[:12]} (of {len(bad)}) differ between the fused and the two-launch attention"
-        # ... and the 96 x 256-tile GEMM (pd_gemm_big_kernel: out-projection, FF1, FF2; here whatever the fill) against the 64 x 128-tile strip kernel
-        eng.set_option(_lib.PD_OPT_DENOISER_BIG_GEMM, 0)
-        strip = eng.denoise(x.to(DEV), z.to(DEV), t)
-        for mask in (8 | 1, 8 | 2, 8 | 4, 8 | 7):
-            eng.set_option(_lib.PD_OPT_DENOISER_BIG_GEMM, mask)
-            big = eng.denoise(x.to(DEV), z.to(DEV), t)
-            bad = (big != strip).reshape(B, -1).any(dim=1).nonzero().flatten().tolist()
-            assert not bad, f"t={t}, big-tile mask {mask & 7}: sequences {bad[:12]} (of {len(bad)}) differ from the strip kernel's"
-        assert torch.equal(strip, plain)
-        eng.set_option(_lib.PD_OPT_DENOISER_BIG_GEMM, 7)
         with torch.no_grad():
             ref = O.denoiser_forward(sd64, x[sub].double(), torch.full((len(sub),), t, dtype=torch.long), z[sub].double())
         worst = max(rel_err(fused[s], ref[i]) for i, s in enumerate(sub))
@@ -201,9 +191,7 @@ def test_fused_qkv_attention_is_bitwise_the_two_launch_path(seeded_diffuser, ora
     eng.set_option(_lib.PD_OPT_DENOISER_FUSED_ATTN, 0)
     p0 = eng.sample(z.to(DEV), noise, 0, None, use_graph=True, want_process=False)[0].clone()
     pe = eng.sample(z.to(DEV), noise, 0, None, use_graph=False, want_process=False)[0]
-    eng.set_option(_lib.PD_OPT_DENOISER_BIG_GEMM, 8 | 7)
-    pb = eng.sample(z.to(DEV), noise, 0, None, use_graph=True, want_process=False)[0].clone()
-    assert torch.equal(p1, p0) and torch.equal(p0, pe) and torch.equal(pb, pe)
+    assert torch.equal(p1, p0) and torch.equal(p0, pe)
     eng.close()
 
 

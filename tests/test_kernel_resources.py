@@ -74,10 +74,6 @@ def test_denoiser_kernels_keep_their_register_budget(tmp_path):
     for name, r in dma.items():
         assert r["Occupancy"] >= (5 if "ILi4E" in name else 6) and r["ScratchSize"] == 0, (name, r)    # (EPI 4 carries one more pointer: 5 waves, K = 192 only)
     # round 5: in_proj + attention in one workgroup of 12 waves (three per SIMD: <= 168 registers), Q / K / V in LDS only -- nothing spilled
-    big = {k: v for k, v in kernels.items() if "pd_gemm_big_kernel" in k}
-    assert len(big) == 2, sorted(kernels)                       # EPI 2 / 4: 8 waves per workgroup, two workgroups per CU (<= 128 registers)
-    for name, r in big.items():
-        assert r["VGPRs"] + r.get("AGPRs", 0) <= 128 and r["Occupancy"] >= 4 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
     fused = {k: v for k, v in kernels.items() if "pd_qkv_attn_kernel" in k}
     assert len(fused) == 1, sorted(kernels)                     # (the BARE > 0 variants exist in -DPD_DEV_KNOBS builds only)
     for name, r in fused.items():

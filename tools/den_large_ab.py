@@ -33,12 +33,6 @@ def child():
             out0 = eng.denoise(x.to(dev), z, 40).cpu().contiguous()
             ts = [eng.time_kernel(0, B, N, reps=30) * 1e3 for _ in range(3)]
             print(f"      PD_OPT_DENOISER_FUSED_ATTN = 0: step alone {min(ts):7.1f} us; bitwise equal to the fused path: {bool(torch.equal(out0, out))}", flush=True)
-            eng.set_option(5, 1)
-            for mask in (0, 1, 2, 4, 7):                      # PD_OPT_DENOISER_BIG_GEMM: out-projection | FF1 | FF2 on the 96 x 256-tile kernel
-                eng.set_option(6, mask)
-                outm = eng.denoise(x.to(dev), z, 40).cpu().contiguous()
-                ts = [eng.time_kernel(0, B, N, reps=30) * 1e3 for _ in range(3)]
-                print(f"      PD_OPT_DENOISER_BIG_GEMM = {mask}: step alone {min(ts):7.1f} us; bitwise equal: {bool(torch.equal(outm, out))}", flush=True)
         eng.close()
 
 

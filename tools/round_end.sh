@@ -15,7 +15,10 @@ cd $R; python tools/rocpd_stats.py $F/trace/bench_results.db 16 > $F/kernel_stat
 python tools/coresident_from_trace.py $F/trace/bench_results.db $(python -c "import json; print(json.load(open('$F/bench_traced.json'))['roofline']['algorithmic_flops_per_launch'])") > $F/coresident.txt 2>&1; cat $F/coresident.txt; rm -rf $F/trace
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$F/trace256 -o t256 -- python $R/tools/pmc_target.py 256 1 > /dev/null 2>&1
-cd $R; python tools/rocpd_stats.py $F/trace256/t256_results.db 6 > $F/fullchip_launch_stats.txt
+cd /tmp
+timeout 200 rocprofv3 --kernel-trace --stats -d $R/$F/trace_den -o den -- python $R/tools/den_large.py 256 > $R/$F/den_large.txt 2>&1
+cd $R; python tools/rocpd_stats.py $F/trace_den/den_results.db 20 > $F/denoiser_step_kernel_stats.txt 2>&1; rm -rf $F/trace_den       # steps alone, no GGS in the process
+python tools/rocpd_stats.py $F/trace256/t256_results.db 6 > $F/fullchip_launch_stats.txt
 python tools/coresident_from_trace.py $F/trace256/t256_results.db $(python -c "print(256*57000*100.0*700)") >> $F/fullchip_launch_stats.txt 2>&1; rm -rf $F/trace256; cat $F/fullchip_launch_stats.txt | tail -4
 if [ -d _ref_stage/pose_diffusion ]; then
   python tools/make_synthetic_ckpt.py /tmp/synth.pth --cfg _ref_stage/cfgs/default.yaml > /dev/null 2>&1
