@@ -1522,25 +1522,28 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
             // ---- P3b: the owner of frame n sums that frame's rows in row order and publishes the frame line
             bool ok = true;
             for (int n = wg; n < N; n += k) {
-                const int lo = L.incoff[n], cn = L.incoff[n + 1] - lo;   // <= 63 rows
+                const int lo = L.incoff[n], cn = L.incoff[n + 1] - lo;   // <= 2 (N - 1) <= 126 rows
                 ok = ggs2_gather<1>(xs + (size_t)lo * PD_XCHG_LINE, tid, cn * 8, 8, epoch, frame_rows, 16, P.err_flag) && ok;
                 __syncthreads();
-                if (tid < 16) {
-                    // the frame's rows summed IN ROW ORDER (the bits do not depend on the workgroup count), eight LDS reads in flight at a time: as a
-                    // plain loop this was a chain of <= 63 dependent LDS round trips -- 5 700 of the 22 100 cycles of an iteration at 50 frames
-                    // (tools/ggs_prof_n50.py, round 5)
+                if (tid < 64) {
+                    // the frame's rows summed in a FIXED order that does not depend on the workgroup count: the four 16-lane rows of wave 0 each sum
+                    // every fourth row (rows p, p + 4, ...: eight LDS reads in flight at a time), then (p0 + p1) + (p2 + p3) on the permlane swaps.
+                    // History (tools/ggs_prof_n50.py, round 5): a plain loop over the rows was a chain of <= 63 dependent LDS round trips -- 5 700 of the
+                    // 22 100 cycles of an iteration at 50 frames; eight reads in flight on 16 lanes: 3 300; this form: see profiles/round5_ggs_n50_phase_clocks.txt
+                    const int c16 = tid & 15, part = tid >> 4;
                     float a = 0.0f;
-                    int e2 = 0;
-                    for (; e2 + 8 <= cn; e2 += 8) {
+                    for (int e0 = part; e0 < cn; e0 += 32) {              // (cn <= 2 (N - 1) rows; the loop bound differs between the four parts: no cross-lane operation inside)
                         float r[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) r[u] = frame_rows[(e2 + u) * 16 + tid];
+                        for (int u = 0; u < 8; ++u) r[u] = e0 + 4 * u < cn ? frame_rows[(e0 + 4 * u) * 16 + c16] : 0.0f;
 #pragma unroll
                         for (int u = 0; u < 8; ++u) a += r[u];
                     }
-                    for (; e2 < cn; ++e2) a += frame_rows[e2 * 16 + tid];
-                    __hip_atomic_store(xs + (size_t)(n_inc + k + n) * PD_XCHG_LINE + tid, ((u64)epoch << 32) | (u64)__float_as_uint(a),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a = add_xor16(a);
+                    a = add_xor32(a);
+                    if (tid < 16)
+                        __hip_atomic_store(xs + (size_t)(n_inc + k + n) * PD_XCHG_LINE + tid, ((u64)epoch << 32) | (u64)__float_as_uint(a),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 __syncthreads();
             }
@@ -1568,19 +1571,14 @@ __global__ __launch_bounds__(PD_GGS_THREADS) void pd_ggs2_kernel(PdGgsParams P, 
                     L.gA[n * 4 + (c - 12)] = v;
                 }
             }
-            if (wave == PD_GGS_WAVES - 1) {
-                float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+            if (wave >= PD_GGS_WAVES - 3) {                 // one wave per total (round 5: one wave ran the 3 x ceil(k / 64) reductions back to back)
+                const int c = wave - (PD_GGS_WAVES - 3);
+                float t = 0.0f;
                 for (int w0 = 0; w0 < k; w0 += 64) {      // fixed order: 64 workgroups at a time, tree inside
                     const int w = w0 + lane;
-                    t0 += wave_allsum(w < k ? tot_rows[w * 4 + 0] : 0.0f);
-                    t1 += wave_allsum(w < k ? tot_rows[w * 4 + 1] : 0.0f);
-                    t2 += wave_allsum(w < k ? tot_rows[w * 4 + 2] : 0.0f);
+                    t += wave_allsum(w < k ? tot_rows[w * 4 + c] : 0.0f);
                 }
-                if (lane == 0) {
-                    L.cam[6] = t0;
-                    L.cam[7] = t1;
-                    L.ctl[2] = t2;
-                }
+                if (lane == 0) *(c == 0 ? &L.cam[6] : (c == 1 ? &L.cam[7] : &L.ctl[2])) = t;
             }
             __syncthreads();
             PD_PROF2H(q6);
