@@ -8,7 +8,7 @@ timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $F/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $F/smoke.txt
 bash tools/collect_pmc.sh > /dev/null 2>&1; cp gpurun_out/pmc_summary.json $F/pmc_summary.json
 mkdir -p profiles; cp gpurun_out/pmc_summary.json profiles/round5_pmc_summary.json      # bench.py reads the traffic figures from here (hash-checked)
-timeout 900 python bench.py --dry-dist > $F/bench_line.json 2> $F/bench.err; tail -2 $F/bench.err
+T0=$SECONDS; timeout 900 python bench.py --dry-dist > $F/bench_line.json 2> $F/bench.err; echo "default bench.py run: $((SECONDS - T0)) s wall" | tee $F/bench_wall.txt; tail -2 $F/bench.err
 cd /tmp && export TMPDIR=/tmp
 timeout 500 rocprofv3 --kernel-trace --stats -d $R/$F/trace -o bench -- python $R/bench.py --no-per-config --no-fresh-inputs --no-fast-mode --cpu-budget-s 0 > $R/$F/bench_traced.json 2>/dev/null
 cd $R; python tools/rocpd_stats.py $F/trace/bench_results.db 16 > $F/kernel_stats.txt
