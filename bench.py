@@ -129,11 +129,11 @@ def pmc_traffic(which, eb=None):
         "library hash as this run")
 
 
-def lane_stream_fraction(pair_sizes, lanes=512, resident_steps=15):
+def lane_stream_fraction(pair_sizes, lanes=512, resident_steps=17):
     """Share of the algorithmic match bytes the lane-per-item GGS kernel pulls through the fabric per iteration (reporting only; the rule
     is pd_ggs_set_matches' in csrc/pd_ggs.hip: the smallest item length that leaves <= `lanes` lane items, one more cut for the pairs with
     the longest items while lanes are left, items ordered by length, 64 per wave, a wave's stream padded to its longest item; the first
-    `resident_steps` steps (two matches per lane each) of every wave live on chip for the whole launch: 12 in registers + 3 in LDS, PD_LANE_RV + PD_LANE_RL)."""
+    `resident_steps` steps (two matches per lane each) of every wave live on chip for the whole launch: 14 in registers + 3 in LDS, PD_LANE_RV + PD_LANE_RL)."""
     ms = [m for m in pair_sizes if m > 0]
     lo, hi = 1, max(ms)
     while lo < hi:
@@ -666,7 +666,7 @@ def main():
     ggs_set_ms = max(evs[0][0].elapsed_time(e1) for _, e1 in evs)
     ggs_set_tflops = depth * ggs_flops / (ggs_set_ms * 1e-3) / 1e12
     match_bytes = float(EB) * M * MATCH_BYTES * 7 * cfg.iter_num             # streamed once per iteration at one workgroup per sequence
-    # (the lane-per-item kernel keeps 12 steps of every lane item in registers and 3 in LDS: it streams ~74 % of these bytes -- `fabric.streamed_fraction`)
+    # (the lane-per-item kernel keeps 14 steps of every lane item in registers and 3 in LDS: it streams ~70 % of these bytes -- `fabric.streamed_fraction`)
     ceil_rng, ceil_src = (None, "skipped (--no-stream-probe)") if (args.no_stream_probe or rank != 0) else stream_ceiling()
     ggs_traffic, traffic_src = pmc_traffic("ggs_launch", EB) if (wgs or 24) == 1 else (None, "PMC summary is for one workgroup per sequence")
     k_eff = wgs or 24
@@ -675,7 +675,7 @@ def main():
     lane_kernel = False
     if hasattr(eng.lib, "pd_debug_ggs_plan") and eng.lib.pd_debug_ggs_plan(eng._h, EB, N_FRAMES, _C.byref(cfg), plan8) == 0:
         lane_kernel = bool(plan8[6])
-    kname = ("pd_ggs_lane_kernel<12> (a lane per work item: 8 waves, 12 steps of every item resident in registers + 3 in LDS, the rest through an LDS ring fed by LDS-DMA)"
+    kname = ("pd_ggs_lane_kernel<14> (a lane per work item: 8 waves, 14 steps of every item resident in registers + 3 in LDS, the rest through an LDS ring fed by LDS-DMA)"
              if lane_kernel else f"pd_ggs_kernel<5, false, {plan8[4] or 12}> (a wave per work item)")
     streamed, lane_items, lane_wave_steps = lane_stream_fraction([PER_PAIR] * (N_FRAMES * (N_FRAMES - 1) // 2)) if lane_kernel else (1.0, 0, [])
     streamed_rate = match_bytes * streamed / (ggs_ms * 1e-3) / 1e9          # GB/s the launch pulls through the fabric

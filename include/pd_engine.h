@@ -104,7 +104,7 @@ typedef struct pd_ggs_cfg {
 #define PD_GGS_CFG_WAVES8 4           /* pd_ggs_cfg.reserved: keep 8 wavefronts per workgroup where the staged one-workgroup-per-
                                        * sequence shape would run 12 (three per SIMD); bitwise the same results -- comparison */
 #define PD_GGS_CFG_LANE_ITEMS 8       /* pd_ggs_cfg.reserved: run the lane-per-item kernel (one workgroup of 8 wavefronts per sequence,
-                                       * every LANE owns <= l matches of one frame pair, 12 steps of every lane item resident in registers and 3 in LDS
+                                       * every LANE owns <= l matches of one frame pair, 14 steps of every lane item resident in registers and 3 in LDS
                                        * for the whole launch, the rest streamed through an LDS ring) whatever the batch size, where its tables
                                        * exist (<= 24 frames, <= 512 frame pairs) and its LDS image fits.  Without the flag it is picked only
                                        * when wgs_per_seq == 0 and the launch holds more sequences than half the CUs.  Same valid sets and

@@ -1,4 +1,4 @@
-"""GPU (-m gpu), round 5 ("Next round" items 1, 2, 6): the kernel the headline is made of -- pd_ggs_lane_kernel<12> --
+"""GPU (-m gpu), round 5 ("Next round" items 1, 2, 6): the kernel the headline is made of -- pd_ggs_lane_kernel<14> --
 AT THE HEADLINE LAUNCH (256 workgroups x 190 pairs x 300 matches: 256 LDS rings competing for the fabric) and at the 160- / 80-sequence
 rank shapes of the multi-GPU run, against the oracle and against every compared sequence run ALONE on the same kernel; the free-running
 criterion at configs[2]'s real size on all three seeds; the step-invariant part of `_first` hoisted out of the diffusion steps; the
@@ -55,7 +55,7 @@ def headline_batch(seeded_diffuser):
 
 @pytest.mark.parametrize("B", [256, 160, 80])
 def test_lane_kernel_at_the_headline_launch(engine, headline_batch, B):
-    """geometry_guided_sampling.py:67-172 on pd_ggs_lane_kernel<12> at bench.py's launch: B workgroups (one per sequence; 256 = every CU),
+    """geometry_guided_sampling.py:67-172 on pd_ggs_lane_kernel<14> at bench.py's launch: B workgroups (one per sequence; 256 = every CU),
     each streaming its own 57 000 matches through a per-wave LDS ring fed by hand-issued LDS-DMA whose only guard between the DMA write
     and the ds_read of a slot is a counted `s_waitcnt vmcnt` (pd_ggs_lane.inc).  What only this launch has -- B rings competing for the
     fabric, DMA landing latencies several times those of a 3-sequence launch -- is what a miscounted wait would need to corrupt a slot.

@@ -37,7 +37,7 @@ def test_ggs_kernel_variants_keep_their_register_budget(tmp_path):
         else:
             assert r["VGPRs"] <= 256 and r["Occupancy"] >= 2, (name, r)
             assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
-    # the lane-per-item kernel: 8 waves of up to 256 registers (two per SIMD), twelve steps of every lane item resident in
+    # the lane-per-item kernel: 8 waves of up to 256 registers (two per SIMD), fourteen steps of every lane item resident in
     # them for the whole launch and NOTHING spilled (round 4: its pass is bound by instruction issue; 16 resident steps spill 26 registers and
     # cost 4 % of a launch, profiles/round4_lane_ring.txt)
     lane = {k: v for k, v in kernels.items() if "pd_ggs_lane_kernel" in k}
