@@ -131,8 +131,8 @@ def pmc_traffic(which, eb=None):
 
 def lane_stream_fraction(pair_sizes, lanes=512, resident_steps=17):
     """Share of the algorithmic match bytes the lane-per-item GGS kernel pulls through the fabric per iteration (reporting only; the rule
-    is pd_ggs_set_matches' in csrc/pd_ggs.hip: the smallest item length that leaves <= `lanes` lane items, one more cut for the pairs with
-    the longest items while lanes are left, items ordered by length, 64 per wave, a wave's stream padded to its longest item; the first
+    is pd_ggs_set_matches' in csrc/pd_ggs.hip: the smallest item length that leaves <= `lanes` lane items, k = 1..3 more cuts for the spare / k - d
+    pairs with the longest items ((k, d) by the modelled match pass), items ordered by length, 64 per wave, a wave's stream padded to its longest item; the first
     `resident_steps` steps (two matches per lane each) of every wave live on chip for the whole launch: 14 in registers + 3 in LDS, PD_LANE_RV + PD_LANE_RL)."""
     ms = [m for m in pair_sizes if m > 0]
     lo, hi = 1, max(ms)
@@ -142,12 +142,26 @@ def lane_stream_fraction(pair_sizes, lanes=512, resident_steps=17):
             hi = mid
         else:
             lo = mid + 1
-    nch = [-(-m // lo) for m in ms]
-    spare = lanes - sum(nch)
-    order = sorted(range(len(ms)), key=lambda p: (-(-(-ms[p] // nch[p])), p))
-    for p in [p for p in order if ms[p] > nch[p]][:max(spare, 0)]:
-        nch[p] += 1
-    steps = sorted(((-(-ms[p] // nch[p]) + 1) // 2 for p in range(len(ms)) for _ in range(nch[p])), reverse=True)
+    base = [-(-m // lo) for m in ms]
+    spare = lanes - sum(base)
+    order = sorted(range(len(ms)), key=lambda p: (-(-(-ms[p] // base[p])), p))
+    rank = {p: r for r, p in enumerate(order)}
+
+    def cuts(k, d):                                                        # k more cuts for the spare // k - d pairs with the longest items
+        return [base[p] + (min(k, ms[p] - base[p]) if ms[p] > base[p] and rank[p] < spare // k - d else 0) for p in range(len(ms))]
+
+    def wave_steps(nch):
+        st = sorted(((-(-ms[p] // nch[p]) + 1) // 2 for p in range(len(ms)) for _ in range(nch[p])), reverse=True)
+        return st, [st[w] for w in range(0, len(st), 64)], [st[min(w + 63, len(st) - 1)] for w in range(0, len(st), 64)]
+
+    def cost(nch):                                                         # pd_lane_pass_cost (csrc/pd_internal.h): waves w and w + 4 share a SIMD
+        _, tmax, tmin = wave_steps(nch)
+        t = [100 * a + 15 * (a - b) for a, b in zip(tmax, tmin)] + [0] * (8 - len(tmax))
+        return max(max(t[s], (45 * t[s]) // 100 + t[s + 4]) for s in range(4))
+
+    cands = [cuts(k, d) for k in (1, 2, 3) for d in range(16) if d == 0 or spare // k - d > 0]
+    nch = min(cands, key=cost)                                             # ties: the smaller k, then the smaller d (min keeps the first)
+    steps = wave_steps(nch)[0]
     waves = [steps[w] for w in range(0, len(steps), 64)]                   # a wave runs (and streams) as many steps as its longest item
     streamed = sum(max(t - resident_steps, 0) for t in waves) * 64 * 32     # bytes per iteration and sequence
     return streamed / (16.0 * sum(ms)), len(steps), waves

@@ -129,7 +129,11 @@ const char *pd_version(void);
 /* ---- denoiser + DDPM (GaussianDiffusion.p_sample pieces) --------------------------------- */
 
 /* eps_out[B,N,9] = Denoiser.forward(x[B,N,9], t (same for all B), z[B,N,z_dim])
- * (models/denoiser.py:53-76).  x, z, eps_out DEVICE. */
+ * (models/denoiser.py:53-76).  x, z, eps_out DEVICE.
+ * Cost note for the step-level entry points (pd_denoise_step, pd_p_mean): at >= 1 024 token rows `_first` is computed as a
+ * step-invariant z piece + a per-step piece (models/denoiser.py:56-70: z does not change over the T steps).  pd_sample /
+ * pd_sample_phase compute the z piece ONCE per call; the step-level API cannot know that z is unchanged and recomputes it on
+ * every call (one extra launch and a K = 384 GEMM per step) -- a host loop over T steps should use pd_sample. */
 int pd_denoise_step(pd_engine *eng, const float *x, const float *z, int t, int B, int N,
                     float *eps_out, void *stream);
 
@@ -188,6 +192,11 @@ int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n_seqs, cons
  * per optimisation {sampson_to_print (:169), iterations stepped, last n_valid, last loss}. */
 int pd_ggs_guide(pd_engine *eng, float *model_mean, int B, int N, int t, const pd_ggs_cfg *cfg,
                  float *stats_out, void *stream);
+
+/* Iterations each of the five GGS_optimize calls of one guided step is GIVEN under `cfg` (geometry_guided_sampling.py:48-63, :86-87:
+ * all (2 x iter_num), FL, R, T, all (2 x)) -- the engine's own stage table, for hosts that compare it with the iterations a stage
+ * STEPPED (stats[.., 1]) to reproduce the reference's "Drop this pair ..." line (:104-108).  No GPU needed. */
+int pd_ggs_stage_iters(const pd_ggs_cfg *cfg, int *iters_out5);
 
 /* One GGS_optimize call (geometry_guided_sampling.py:67-126) with explicit update flags;
  * used by the parity tests.  trace_out (DEVICE, may be NULL): [B, iters, N*9 + 3] per-iteration
@@ -274,6 +283,12 @@ int pd_sample_phase(pd_engine *eng, const float *z, const float *noise, int B, i
  * R[B*N,9] row-major 3x3, T[B*N,3], focal[B*N,2] (PyTorch3D NDC).  DEVICE pointers. */
 int pd_pose_to_camera(pd_engine *eng, const float *enc, int n_cameras, float *R_out, float *T_out,
                       float *focal_out, void *stream);
+/* The same with the reference function's three keyword parameters (camera_transform.py:64-70, :89-97):
+ * focal = clamp(exp(logFL + log_focal_length_bias), min_focal_length, max_focal_length); pd_pose_to_camera = (1.8, 0.1, 20).
+ * (The guided sampler itself always decodes with the defaults, as geometry_guided_sampling.py:139 does.) */
+int pd_pose_to_camera_ex(pd_engine *eng, const float *enc, int n_cameras, float *R_out, float *T_out,
+                         float *focal_out, float log_focal_length_bias, float min_focal_length, float max_focal_length,
+                         void *stream);
 
 /* ---- rows D2 / D3 as stand-alone operators (stateless, all pointers DEVICE fp32) --------------------
  * The engine fuses both embeddings into the denoiser (a [T,128] table built at creation; the harmonic columns formed while

@@ -404,8 +404,28 @@ def make_pred_x0():
     print("pred_x0.npz", os.path.getsize(os.path.join(OUT, "pred_x0.npz")))
 
 
+def make_decode_args():
+    """tests/golden/decode_args.npz -- the reference's pose_encoding_to_camera (util/camera_transform.py:64-105, executed in place) with
+    its three keyword parameters at the defaults and at two other settings, on encodings whose log focal lengths straddle every clamp
+    (missing item 4: log_focal_length_bias / min_focal_length / max_focal_length are real parameters)."""
+    ref = RS.load_reference()
+    N = 12
+    enc = torch.from_numpy(synth.make_cameras(N, seed=4242)).float().reshape(1, N, 9).clone()
+    enc[0, :, 7] = torch.linspace(-6.0, 3.0, N)          # exp(x + bias) from far below every minimum to far above every maximum
+    enc[0, :, 8] = torch.linspace(2.5, -5.5, N)
+    out = {"enc": enc.numpy()}
+    for tag, (bias, fmin, fmax) in {"default": (1.8, 0.1, 20), "a": (1.2, 0.5, 5.0), "b": (0.0, 0.01, 15.0)}.items():
+        d = ref.pose_encoding_to_camera(enc, log_focal_length_bias=bias, min_focal_length=fmin, max_focal_length=fmax, return_dict=True)
+        out[f"{tag}_args"] = np.array([bias, fmin, fmax], dtype=np.float64)
+        out[f"{tag}_R"], out[f"{tag}_T"], out[f"{tag}_focal"] = d["R"].numpy(), d["T"].numpy(), d["focal_length"].numpy()
+    np.savez(os.path.join(OUT, "decode_args.npz"), **out)
+    print("decode_args.npz", os.path.getsize(os.path.join(OUT, "decode_args.npz")))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "pred_x0":
+    if len(sys.argv) > 1 and sys.argv[1] == "decode_args":
+        make_decode_args()      # only the decode-parameter fixture
+    elif len(sys.argv) > 1 and sys.argv[1] == "pred_x0":
         make_pred_x0()          # only the objective="pred_x0" fixture
     elif len(sys.argv) > 1 and sys.argv[1] == "guided_free":
         make_guided_free()      # only the free-running GGS-on fixture
@@ -423,3 +443,4 @@ if __name__ == "__main__":
         make_preprocess()
         make_guided_free()
         make_guided_free(seeds=(0,), N=20, cond_start=10, per_pair=300, name="guided_free_full")
+        make_decode_args()

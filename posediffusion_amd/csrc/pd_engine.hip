@@ -31,8 +31,11 @@ __global__ void pd_finish_kernel(const float *__restrict__ mean, const float *__
     if (i < n) out[i] = noise ? mean[i] + sigma * noise[i] : mean[i];   // gaussian_diffuser.py:280
 }
 
+// torch.clamp: NaN stays NaN (fminf / fmaxf would return the bound)
+__device__ __forceinline__ float pd_clamp_torch(float v, float lo, float hi) { return v != v ? v : fminf(fmaxf(v, lo), hi); }
+
 __global__ void pd_camera_kernel(const float *__restrict__ enc, int n, float *__restrict__ R, float *__restrict__ T,
-                                 float *__restrict__ F) {
+                                 float *__restrict__ F, float fl_bias, float fl_min, float fl_max) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     const float *x = enc + (size_t)c * 9;
@@ -51,8 +54,8 @@ __global__ void pd_camera_kernel(const float *__restrict__ enc, int n, float *__
     T[c * 3 + 0] = x[0];
     T[c * 3 + 1] = x[1];
     T[c * 3 + 2] = x[2];
-    F[c * 2 + 0] = fminf(fmaxf(expf(x[7] + 1.8f), 0.1f), 20.0f);   // camera_transform.py:89-97
-    F[c * 2 + 1] = fminf(fmaxf(expf(x[8] + 1.8f), 0.1f), 20.0f);
+    F[c * 2 + 0] = pd_clamp_torch(expf(x[7] + fl_bias), fl_min, fl_max);   // camera_transform.py:89-97
+    F[c * 2 + 1] = pd_clamp_torch(expf(x[8] + fl_bias), fl_min, fl_max);
 }
 
 // ---- lifecycle ----------------------------------------------------------------------------------
@@ -207,16 +210,21 @@ extern "C" int pd_p_finish(pd_engine *eng, const float *mean, const float *noise
     return PD_OK;
 }
 
-extern "C" int pd_pose_to_camera(pd_engine *eng, const float *enc, int n_cameras, float *R_out, float *T_out,
-                                 float *focal_out, void *stream) {
+extern "C" int pd_pose_to_camera_ex(pd_engine *eng, const float *enc, int n_cameras, float *R_out, float *T_out,
+                                    float *focal_out, float log_focal_length_bias, float min_focal_length, float max_focal_length,
+                                    void *stream) {
     if (!eng || !enc || !R_out || !T_out || !focal_out || n_cameras <= 0) {
         pd_set_error("pd_pose_to_camera: invalid arguments");
         return PD_ERR_INVALID_ARG;
     }
     hipLaunchKernelGGL(pd_camera_kernel, dim3((n_cameras + 63) / 64), dim3(64), 0, (hipStream_t)stream, enc, n_cameras,
-                       R_out, T_out, focal_out);
+                       R_out, T_out, focal_out, log_focal_length_bias, min_focal_length, max_focal_length);
     PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
+}
+extern "C" int pd_pose_to_camera(pd_engine *eng, const float *enc, int n_cameras, float *R_out, float *T_out,
+                                 float *focal_out, void *stream) {
+    return pd_pose_to_camera_ex(eng, enc, n_cameras, R_out, T_out, focal_out, 1.8f, 0.1f, 20.0f, stream);
 }
 
 // ---- GGS API ------------------------------------------------------------------------------------
@@ -228,6 +236,17 @@ static void guide_stages(const pd_ggs_cfg *cfg, PdGgsStage *st) {
     st[2] = {1, 0, 0, it};
     st[3] = {0, 1, 0, it};
     st[4] = {1, 1, 1, 2 * it};
+}
+
+extern "C" int pd_ggs_stage_iters(const pd_ggs_cfg *cfg, int *iters_out5) {
+    if (!cfg || !iters_out5 || cfg->iter_num < 0) {
+        pd_set_error("pd_ggs_stage_iters: invalid arguments");
+        return PD_ERR_INVALID_ARG;
+    }
+    PdGgsStage st[PD_GGS_MAX_STAGES];
+    guide_stages(cfg, st);
+    for (int i = 0; i < 5; ++i) iters_out5[i] = st[i].iters;
+    return PD_OK;
 }
 
 static int check_cfg(const pd_ggs_cfg *cfg, const char *who) {

@@ -1828,15 +1828,38 @@ extern "C" int pd_ggs_set_matches(pd_engine *eng, int seq, const double *kp1, co
         }
         const int spare = PD_LANE_MAX_ITEMS - l_total;
         {
-            std::vector<int> more(n_pairs, 0);
-            for (int p = 0; p < n_pairs; ++p) {
-                if (l_nch[p] == 0 || l_m[p] <= l_nch[p]) continue;
-                more[p] = pd_lane_rank(l_m.data(), l_nch.data(), n_pairs, p, false) < spare ? 1 : 0;
-            }
-            for (int p = 0; p < n_pairs; ++p) l_nch[p] += more[p];
+            // round 6: k more cuts for the spare / k pairs with the longest items, k by the modelled match pass (pd_lane_pass_cost)
+            std::vector<int> rank(n_pairs, 0), nch_k(n_pairs), steps_k(n_pairs), best_nch = l_nch;
+            for (int p = 0; p < n_pairs; ++p)
+                if (l_nch[p] != 0 && l_m[p] > l_nch[p]) rank[p] = pd_lane_rank(l_m.data(), l_nch.data(), n_pairs, p, false);
+            int best_cost = 0x7fffffff;
+            for (int k = 1; k <= PD_LANE_MORE_MAX; ++k)
+                for (int d = 0; d < PD_LANE_MORE_SLACK && (d == 0 || spare / k - d > 0); ++d) {
+                    int n_items = 0;
+                    for (int p = 0; p < n_pairs; ++p) {
+                        const bool elig = l_nch[p] != 0 && l_m[p] > l_nch[p] && rank[p] < spare / k - d;
+                        nch_k[p] = l_nch[p] + (elig ? std::min(k, l_m[p] - l_nch[p]) : 0);
+                        steps_k[p] = nch_k[p] ? (pd_lane_items_of(l_m[p], nch_k[p]) + 1) / 2 : 0;
+                        n_items += nch_k[p];
+                    }
+                    int T[PD_LANE_WAVES] = {}, Tmin[PD_LANE_WAVES] = {};
+                    for (int p = 0; p < n_pairs; ++p) {
+                        if (!nch_k[p]) continue;
+                        const int first = pd_lane_rank(steps_k.data(), nch_k.data(), n_pairs, p, true), end = first + nch_k[p];
+                        for (int w = (first + 63) / 64; w < PD_LANE_WAVES && 64 * w < end; ++w) T[w] = steps_k[p];                       // item 64 w: the wave's longest
+                        for (int w = first / 64; w < PD_LANE_WAVES && 64 * w < end; ++w)
+                            if (std::min(64 * w + 63, n_items - 1) < end && std::min(64 * w + 63, n_items - 1) >= first) Tmin[w] = steps_k[p];   // its last item
+                    }
+                    const int cost = pd_lane_pass_cost(T, Tmin);
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_nch = nch_k;
+                    }
+                }
+            l_nch = best_nch;
         }
         for (int p = 0; p < n_pairs; ++p) l_steps[p] = l_nch[p] ? (pd_lane_items_of(l_m[p], l_nch[p]) + 1) / 2 : 0;
-        litems.assign((size_t)l_total + (size_t)std::max(0, std::min(spare, n_pairs)), make_int4(0, 0, 0, 0));
+        litems.assign((size_t)PD_LANE_MAX_ITEMS, make_int4(0, 0, 0, 0));
         int n_lit = 0;
         for (int p = 0; p < n_pairs; ++p) {
             const int q = pair_ij[p].x * N + pair_ij[p].y, m = l_m[p], nch = l_nch[p];
@@ -2019,7 +2042,7 @@ int pd_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, PdGgsPlan *
             const size_t lds = lane_lds_bytes(pinc_rows);        // tables + the waves' rings (PD_LANE_RING steps of 2 KiB each)
             if (lds <= 160 * 1024) {
                 out->lane = 1;
-                out->lane_rl = std::max(0, std::min(PD_LANE_RING, steps - PD_LANE_RV));   // (reported: steps of a lane item that live in the ring)
+                out->lane_rl = std::max(0, std::min(PD_LANE_RL, steps - PD_LANE_RV));     // (reported: steps of the longest wave that live in LDS for the launch, beside the ring)
                 out->k = 1;
                 out->waves = PD_LANE_WAVES;
                 out->pinc_rows = pinc_rows;

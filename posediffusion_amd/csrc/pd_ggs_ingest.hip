@@ -295,9 +295,57 @@ __global__ __launch_bounds__(ING_TABLE_THREADS) void ingest_tables_kernel(Ingest
         block_scan_incl(part, scratch, tot0);
         __syncthreads();
         const int spare = PD_LANE_MAX_ITEMS - tot0;
+        // round 6: k more cuts for the spare / k pairs with the longest items, k = 1 .. PD_LANE_MORE_MAX by the modelled match pass
+        // (pd_lane_pass_cost over the waves' steps) -- pd_ggs_set_matches' loop, line by line
+        int *lrk = lstp + NN, *lnk = lrk + NN, *lsk = lnk + NN, *lwt = lsk + NN;      // rank by item length at the base cuts | cuts, steps of a candidate | its waves' longest / shortest item [2][PD_LANE_WAVES]
         for (int key = tid; key < NN; key += ING_TABLE_THREADS) {
             const int m = totals[key], nch = lnch[key];
-            lstp[key] = (nch > 0 && m > nch && pd_lane_rank(totals, lnch, NN, key, false) < spare) ? 1 : 0;
+            lrk[key] = (nch > 0 && m > nch) ? pd_lane_rank(totals, lnch, NN, key, false) : 0;
+        }
+        __syncthreads();
+        int best_cost = 0x7fffffff, best_k = 1, best_d = 0;
+        for (int k = 1; k <= PD_LANE_MORE_MAX; ++k)
+            for (int d = 0; d < PD_LANE_MORE_SLACK && (d == 0 || spare / k - d > 0); ++d) {        // block-uniform
+                int part_k = 0, n_items_k;
+                for (int key = tid; key < NN; key += ING_TABLE_THREADS) {
+                    const int m = totals[key], nch = lnch[key];
+                    const bool elig = nch > 0 && m > nch && lrk[key] < spare / k - d;
+                    const int nk = nch + (elig ? min(k, m - nch) : 0);
+                    lnk[key] = nk;
+                    lsk[key] = nk ? (pd_lane_items_of(m, nk) + 1) / 2 : 0;
+                    part_k += nk;
+                }
+                block_scan_incl(part_k, scratch, n_items_k);
+                __syncthreads();
+                if (tid < 2 * PD_LANE_WAVES) lwt[tid] = 0;
+                __syncthreads();
+                for (int key = tid; key < NN; key += ING_TABLE_THREADS) {
+                    const int nk = lnk[key];
+                    if (!nk) continue;
+                    const int first = pd_lane_rank(lsk, lnk, NN, key, true), end = first + nk;
+                    for (int w = (first + 63) / 64; w < PD_LANE_WAVES && 64 * w < end; ++w) lwt[w] = lsk[key];
+                    for (int w = first / 64; w < PD_LANE_WAVES && 64 * w < end; ++w) {
+                        const int last = min(64 * w + 63, n_items_k - 1);
+                        if (last < end && last >= first) lwt[PD_LANE_WAVES + w] = lsk[key];
+                    }
+                }
+                __syncthreads();
+                int T[PD_LANE_WAVES], Tmin[PD_LANE_WAVES];
+                for (int w = 0; w < PD_LANE_WAVES; ++w) {
+                    T[w] = lwt[w];
+                    Tmin[w] = lwt[PD_LANE_WAVES + w];
+                }
+                const int cost = pd_lane_pass_cost(T, Tmin);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_k = k;
+                    best_d = d;
+                }
+                __syncthreads();
+            }
+        for (int key = tid; key < NN; key += ING_TABLE_THREADS) {
+            const int m = totals[key], nch = lnch[key];
+            lstp[key] = (nch > 0 && m > nch && lrk[key] < spare / best_k - best_d) ? min(best_k, m - nch) : 0;
         }
         __syncthreads();
         part = 0;
@@ -464,7 +512,8 @@ __global__ __launch_bounds__(64) void ingest_interleave_kernel(IngestArgs A) {
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 static size_t tables_lds_bytes(int N, int P_cap, int C_cap) {
-    return sizeof(int) * ((size_t)4 * N * N + 2 * (size_t)P_cap + (size_t)(C_cap + 1) * (N + 1) + 16 + 4);
+    // (+ 3 N^2 for the cut-rule candidates of the lane tables, which exist up to PD_LANE_MAX_FRAMES frames)
+    return sizeof(int) * ((size_t)(N <= PD_LANE_MAX_FRAMES ? 7 : 4) * N * N + 2 * PD_LANE_WAVES + 2 * (size_t)P_cap + (size_t)(C_cap + 1) * (N + 1) + 16 + 4);
 }
 
 extern "C" int pd_ggs_set_matches_csr_async(pd_engine *eng, int seq_first, int n_seqs, const int64_t *seq_offsets,

@@ -128,7 +128,8 @@ struct PdGgsPlan {
     int k, n_slots, lds, two_hop, max_items;
     int pinc_rows, stage_p;    // one-hop kernel: LDS rows of the pair backward; LDS-DMA staging pieces per item (0 = through registers)
     int waves;                 // one-hop kernel: waves per workgroup (8, or 12 for the staged k = 1 shape)
-    int lane, lane_rl;         // lane-per-item kernel chosen; its LDS-resident steps per wave
+    int lane, lane_rl;         // lane-per-item kernel chosen; steps RV .. RV + lane_rl - 1 of its longest wave's stream live in LDS for the whole
+                               //   launch (<= PD_LANE_RL; the PD_LANE_RING slots of the ring come on top)
     int xchg_local;            // one-hop kernel: XCD-local placement of a sequence's workgroups (see PdGgsParams)
 };
 
@@ -147,6 +148,34 @@ __host__ __device__ inline int pd_lane_rank(const int *val, const int *nch, int 
         if (vq > vp || (vq == vp && q < p)) r += by_steps ? nch[q] : 1;
     }
     return r;
+}
+
+// Which cut rule the spare lanes get (host and device builders): candidate (k, d), k = 1 .. PD_LANE_MORE_MAX, d = 0 .. PD_LANE_MORE_SLACK - 1,
+// gives k MORE cuts to each of the spare / k - d pairs with the longest items; the candidate with the cheapest MODELLED match pass wins
+// (ties: the smaller k, then the smaller d).  The model is what the phase clocks of the 8-wave kernel show (profiles/round5_lane_phase_clocks.txt,
+// round6_lane_balance.txt): waves w and w + 4 share a SIMD, the older one (w) runs at its own dependent-issue rate (~ 440 cycles per step)
+// whatever its partner does, the younger one gets the issue slots that leaves (~ 0.55 steps per step of the older wave) and runs the rest of
+// its steps alone afterwards -- so a SIMD with T1 >= T2 steps costs max(T1, 0.45 T1 + T2) step times, cheapest at T2 ~ 0.55 T1 ([75, 38]
+// instead of [75, 50] + [50, 50]); and a wave that MIXES item lengths runs the steps past its shortest item masked, ~ 15 % dearer each (the
+// wave of 56 x 75 + 8 x 38 steps: 35.6 k cycles per pass against 33.1 k for its unmixed neighbours), which is what d is for: it moves the
+// boundary between long and short items onto a wave boundary.
+// T[w] = steps of wave w = of its longest item (0: no such wave), Tmin[w] = steps of its shortest item; in units of 1/100 step.
+#ifndef PD_LANE_MORE_MAX
+#define PD_LANE_MORE_MAX 3
+#endif
+#ifndef PD_LANE_MORE_SLACK
+#define PD_LANE_MORE_SLACK 16
+#endif
+__host__ __device__ inline int pd_lane_pass_cost(const int *T, const int *Tmin) {
+    int c = 0;
+    for (int s = 0; s < 4; ++s) {
+        int t1 = 100 * T[s] + 15 * (T[s] - Tmin[s]), t2 = 0;
+        for (int w = s + 4; w < PD_LANE_WAVES; w += 4) t2 += 100 * T[w] + 15 * (T[w] - Tmin[w]);
+        const int a = t1, b = (45 * t1) / 100 + t2;
+        c = c > a ? c : a;
+        c = c > b ? c : b;
+    }
+    return c;
 }
 
 struct PdSeqHost {

@@ -10,12 +10,10 @@ def pose_encoding_to_camera(pose_encoding, pose_encoding_type="absT_quaR_logFL",
                             min_focal_length=0.1, max_focal_length=20, return_dict=False, engine=None):
     if pose_encoding_type != "absT_quaR_logFL":
         raise ValueError(f"Unknown pose encoding {pose_encoding_type}")           # camera_transform.py:98-99
-    if (log_focal_length_bias, min_focal_length, max_focal_length) != (1.8, 0.1, 20):
-        raise ValueError("the HIP decode kernel is built for bias 1.8 and clamp [0.1, 20]")
     if engine is None:
         from posediffusion_amd.host import current_engine
         engine = current_engine(pose_encoding.device)
-    R, T, f = engine.pose_to_camera(pose_encoding)
+    R, T, f = engine.pose_to_camera(pose_encoding, log_focal_length_bias, min_focal_length, max_focal_length)
     if return_dict:
         return {"focal_length": f, "R": R, "T": T}
     return PerspectiveCameras(focal_length=f, R=R, T=T, device=R.device)

@@ -278,14 +278,17 @@ class PoseEngine:
         _lib.check(self.lib.pd_engine_get_option(self._h, int(option), C.byref(v)), "pd_engine_get_option")
         return int(v.value)
 
-    def pose_to_camera(self, enc: torch.Tensor):
+    def pose_to_camera(self, enc: torch.Tensor, log_focal_length_bias: float = 1.8, min_focal_length: float = 0.1,
+                       max_focal_length: float = 20.0):
+        """pose_encoding_to_camera (camera_transform.py:64-105) with its three focal-length parameters."""
         enc = self._f32(enc).reshape(-1, 9)
         n = enc.shape[0]
         R = torch.empty(n, 3, 3, device=self.device)
         T = torch.empty(n, 3, device=self.device)
         F = torch.empty(n, 2, device=self.device)
-        _lib.check(self.lib.pd_pose_to_camera(self._h, enc.data_ptr(), n, R.data_ptr(), T.data_ptr(), F.data_ptr(),
-                                              self._stream()), "pd_pose_to_camera")
+        _lib.check(self.lib.pd_pose_to_camera_ex(self._h, enc.data_ptr(), n, R.data_ptr(), T.data_ptr(), F.data_ptr(),
+                                                 float(log_focal_length_bias), float(min_focal_length), float(max_focal_length),
+                                                 self._stream()), "pd_pose_to_camera_ex")
         return R, T, F
 
     def time_kernel(self, what: int, B: int, N: int, cfg=None, reps: int = 10) -> float:

@@ -95,22 +95,33 @@ def draw_noise(shape, timesteps: int, device, guided_from: int = 0, has_cond: bo
 
 
 def ggs_stage_iters(iter_num: int):
-    """Iterations each of the five GGS_optimize calls of one guided step is given (geometry_guided_sampling.py:48-63, :86-87)."""
-    return (2 * iter_num, iter_num, iter_num, iter_num, 2 * iter_num)
+    """Iterations each of the five GGS_optimize calls of one guided step is given (geometry_guided_sampling.py:48-63, :86-87) -- asked of
+    the engine's own stage table (pd_ggs_stage_iters), so that the drop line below cannot drift from the rule the kernels run."""
+    import ctypes as C
+    from . import _lib
+    out = (C.c_int * 5)()
+    cfg = make_ggs_cfg(iter_num=int(iter_num))
+    _lib.check(_lib.load().pd_ggs_stage_iters(C.byref(cfg), out), "pd_ggs_stage_iters")
+    return tuple(int(v) for v in out)
 
 
 def print_ggs_stats(stats, t: int, iter_num: int, out=None):
     """The lines the reference prints for one guided step (geometry_guided_sampling.py:104-108, :124), from the engine's per-stage
     statistics ``stats`` [B, 5, 4] = {sampson_to_print, iterations stepped, last n_valid, last loss}: a stage that stepped fewer
     iterations than it was given left through the `min_matches` break and printed the drop line first.  One line per GGS_optimize
-    call as in the reference, which is defined for B = 1; for a batch the lines are those of sequence 0."""
+    call as in the reference, which is defined for B = 1: its lines exactly.  A batch (this package's list-of-matches extension) prints
+    every sequence's lines, sequence after sequence, each prefixed ``[b] `` -- so a break in ANY sequence is shown."""
     import sys
     out = out or sys.stdout
     st = stats.detach().cpu() if hasattr(stats, "detach") else stats
-    for s, given in enumerate(ggs_stage_iters(int(iter_num))):
-        if int(st[0, s, 1]) < given:
-            print("Drop this pair because of insufficient valid matches", file=out)      # :107
-        print(f"t={t:02d} | sampson={float(st[0, s, 0]):05f}", file=out)                  # :124
+    given_all = ggs_stage_iters(int(iter_num))
+    B = int(st.shape[0])
+    for b in range(B):
+        pre = f"[{b}] " if B > 1 else ""
+        for s, given in enumerate(given_all):
+            if int(st[b, s, 1]) < given:
+                print(pre + "Drop this pair because of insufficient valid matches", file=out)      # :107
+            print(f"{pre}t={t:02d} | sampson={float(st[b, s, 0]):05f}", file=out)                  # :124
 
 
 _ENGINES = {}   # device index -> most recently built engine (used by the free functions of dropin/util)

@@ -34,6 +34,49 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
+# BASELINE.json north_star: "R, T, focal ... within 1e-4 relative".  A whole-tensor maximum norm over a [.., 9] pose encoding is dominated by
+# |T| ~ 6 (|logFL| ~ 0.1: a 1e-3 relative error in focal would pass a 2e-5 bound): the teacher-forced tests assert the three column groups
+# SEPARATELY, each against its own largest reference magnitude.
+POSE_GROUPS = {"T": slice(0, 3), "quaternion": slice(3, 7), "logFL": slice(7, 9)}
+_WORST = {}           # test id -> {group: worst relative error seen}; written to gpurun_out/pose_group_errors.json at session end
+
+
+def pose_group_errs(a, b):
+    """{group: max|a - b| / max|b| over that group's columns} for pose encodings [.., 9] (or flattened [.., N*9])."""
+    a = torch.as_tensor(a).detach().cpu().double().reshape(-1, 9)
+    b = torch.as_tensor(b).detach().cpu().double().reshape(-1, 9)
+    return {g: ((a[:, sl] - b[:, sl]).abs().max() / b[:, sl].abs().max().clamp_min(1e-30)).item() for g, sl in POSE_GROUPS.items()}
+
+
+def pose_err(a, b, tag=None):
+    """Largest of the three per-group relative errors (assert `pose_err(..) < tol` binds every group); recorded under `tag`."""
+    e = pose_group_errs(a, b)
+    if tag is not None:
+        w = _WORST.setdefault(tag, {})
+        for g, v in e.items():
+            w[g] = max(w.get(g, 0.0), v)
+    return max(e.values())
+
+
+def camera_errs(R, T, f, ref):
+    """Decoded cameras against a reference dict(R, T, focal_length): per-component relative errors (R / T / focal separately)."""
+    return {"R": rel_err(R, ref["R"]), "T": rel_err(T, ref["T"]), "focal": rel_err(f, ref["focal_length"])}
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _WORST:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        worst = {g: max(w.get(g, 0.0) for w in _WORST.values()) for g in POSE_GROUPS}
+        with open(os.path.join(out, "pose_group_errors.json"), "w") as fh:
+            json.dump({"worst_over_all_tests": worst, "per_test": _WORST}, fh, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def golden():
     return {n[:-4]: load_golden(n) for n in os.listdir(GOLDEN) if n.endswith(".npz")}

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import pose_err, rel_err
 from oracle import pd_oracle as O
 from posediffusion_amd import synth
 from posediffusion_amd.engine import make_ggs_cfg
@@ -71,7 +71,7 @@ def test_long_sequence_n50_full_size_m367500(engine):
         engine.check_async()
         assert int(st[0, 1].item()) == 6, label
         # 6 free-running iterations: a straddling match moves the result by ~1e-5 of |x| per iteration it flips in
-        assert rel_err(o, ref) < (TOL if n_valid == n_oracle else 1e-4), (label, rel_err(o, ref))
+        assert pose_err(o, ref, "configs4_full_size_6_iterations") < (TOL if n_valid == n_oracle else 1e-4), (label, rel_err(o, ref))
         outs[label] = o
     print("configs[4] full size: engine valid counts", sorted(cache), "oracle", n_oracle)
     assert torch.equal(outs["k1"], outs["one_hop"])

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import pose_err, rel_err
 from oracle import pd_oracle as O
 from posediffusion_amd import _lib, synth
 from posediffusion_amd.engine import make_ggs_cfg
@@ -101,7 +101,10 @@ def test_lane_kernel_vs_wave_kernels_and_oracle(engine, case):
         assert len(v) == int(l[0][b, 1]) and abs(l[0][b, 0].item() - v.mean().item()) < TOL * v.mean().item()
         assert rel_err(l[1][b:b + 1], go) < 1e-4
         ref5, _, steps = O.ggs_optimize(x0[b:b + 1].cpu().clone(), pm, iter_num=5)
-        assert steps == int(l[3][b, 1]) and rel_err(l[2][b:b + 1], ref5) < step_tol
+        # per column group (T / quaternion / logFL) except in the ill-conditioned tiny case, whose 10 free-running iterations keep the whole-tensor bound
+        # of the earlier rounds (its logFL columns, |x| ~ 0.1, drift 1.4e-4 of their own scale in both kernel families)
+        e5 = rel_err(l[2][b:b + 1], ref5) if case == "n20_x7_odd_tiny" else pose_err(l[2][b:b + 1], ref5, f"lane_tables_{case}")
+        assert steps == int(l[3][b, 1]) and e5 < step_tol, (case, e5)
 
 
 @pytest.mark.parametrize("shape", ["n20_ragged_100_to_300", "n20_x96_uneven_cuts", "n10_skewed_one_pair_6000", "n12_ragged_3_to_400"])
@@ -170,9 +173,9 @@ def test_objective_pred_x0_against_reference_fixture(golden):
     for t in (99, 50, 10, 1, 0):
         torch.manual_seed(0)
         mean, _, logvar, x0 = diff.p_mean_variance(x, torch.full((2,), t, dtype=torch.long, device=DEV), z)
-        assert rel_err(x0, d[f"ps_x0_t{t}"]) < TOL
+        assert pose_err(x0, d[f"ps_x0_t{t}"], "pred_x0_pieces") < TOL
         pred = mean.cpu().double() + np.exp(0.5 * float(logvar.reshape(-1)[0])) * torch.from_numpy(d[f"ps_noise_t{t}"]).double()
-        assert rel_err(pred, d[f"ps_pred_t{t}"]) < TOL
+        assert pose_err(pred, d[f"ps_pred_t{t}"], "pred_x0_pieces") < TOL
     eng = den._pd_engine_cache["e"][1]
     assert eng.objective == "pred_x0"
     mp = diff.model_predictions(x, torch.full((2,), 50, dtype=torch.long, device=DEV), z)
@@ -184,7 +187,7 @@ def test_objective_pred_x0_against_reference_fixture(golden):
         t = 99 - step
         mean, _ = eng.p_mean(proc[step], zt, t)
         nxt = eng.p_finish(mean, noise[step + 1] if t > 0 else None, t)
-        worst = max(worst, rel_err(nxt, proc[step + 1]))
+        worst = max(worst, pose_err(nxt, proc[step + 1], "pred_x0_teacher_forced"))
     # free-running: hipGraph replay == eager, and the chaos-free prefix against the fp64 oracle / the reference's fp32
     pose_g, process_g, _ = eng.sample(zt, noise, use_graph=True)
     pose_e, process_e, _ = eng.sample(zt, noise, use_graph=False)

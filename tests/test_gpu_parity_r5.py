@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import pose_err, rel_err
 from oracle import pd_oracle as O
 from posediffusion_amd import _lib, synth
 from posediffusion_amd.engine import PoseEngine, make_ggs_cfg
@@ -102,7 +102,7 @@ def test_lane_kernel_at_the_headline_launch(engine, headline_batch, B):
         worst = max(worst, rel_err(o20[b:b + 1], ref))
         ref6, _, steps6 = O.ggs_optimize(x0[b:b + 1].cpu().clone(), pm, iter_num=3)
         assert steps6 == 6 == int(st6[b, 1])
-        worst6 = max(worst6, rel_err(o6[b:b + 1], ref6))
+        worst6 = max(worst6, pose_err(o6[b:b + 1], ref6, f"lane_headline_launch_{B}_6_iterations"))
     print(f"lane kernel, {B}-sequence launch: slots {slots} bitwise = alone (20 and 700 iterations); worst deviation from the oracle after 6 / 20 iterations "
           f"{worst6:.2e} / {worst:.2e}")
     assert worst6 < TOL, (worst6, worst)      # (the 20-iteration figure is printed, not asserted: see the docstring)
@@ -215,7 +215,7 @@ def test_first_layer_hoist_matches_stepwise_and_the_oracle(seeded_diffuser, orac
             t = 99 - step
             mean, _ = eng.p_mean(process[step], z, t)
             nxt = eng.p_finish(mean, noise[step + 1] if t > 0 else None, t)
-            assert rel_err(nxt, process[step + 1]) < 1e-6, (seed, step, rel_err(nxt, process[step + 1]))     # (the loop's update is fused into the tail kernel)
+            assert pose_err(nxt, process[step + 1], "first_hoist_step_api") < 1e-6, (seed, step, rel_err(nxt, process[step + 1]))     # (the loop's update is fused into the tail kernel)
             other, _ = eng.p_mean(process[step], z_other, t)             # another z through the same engine ...
             again, _ = eng.p_mean(process[step], z, t)                   # ... must not leave its z piece behind
             assert torch.equal(again, mean) and not torch.equal(other, mean), (seed, step)

@@ -139,16 +139,26 @@ def test_ggs_print_lines_include_the_drop_line():
     """geometry_guided_sampling.py:104-108, :124: a GGS_optimize call that leaves through the `min_matches` break prints the drop line,
     then -- like every call -- its `t=.. | sampson=..` line.  The engine reports iterations stepped per stage; fewer than given = the break."""
     import io
-    stats = torch.zeros(2, 5, 4)
+    stats = torch.zeros(1, 5, 4)
     stats[0, :, 0] = torch.tensor([1.5, 0.25, 3.0, 0.125, 9.75])
     stats[0, :, 1] = torch.tensor([200.0, 100.0, 37.0, 100.0, 0.0])       # stage 2 broke after 37 iterations, stage 4 at once
-    stats[1, :, 1] = 0.0                                                   # (sequence 1 is not printed: one line per call, as the reference)
     buf = io.StringIO()
     host.print_ggs_stats(stats, 7, 100, out=buf)
-    assert buf.getvalue().splitlines() == [
-        "t=07 | sampson=1.500000", "t=07 | sampson=0.250000", "Drop this pair because of insufficient valid matches", "t=07 | sampson=3.000000",
-        "t=07 | sampson=0.125000", "Drop this pair because of insufficient valid matches", "t=07 | sampson=9.750000"]
-    assert host.ggs_stage_iters(100) == (200, 100, 100, 100, 200)
+    one = ["t=07 | sampson=1.500000", "t=07 | sampson=0.250000", "Drop this pair because of insufficient valid matches", "t=07 | sampson=3.000000",
+           "t=07 | sampson=0.125000", "Drop this pair because of insufficient valid matches", "t=07 | sampson=9.750000"]
+    assert buf.getvalue().splitlines() == one                              # B = 1: the reference's lines exactly
+    # a batch (the list-of-matches extension): every sequence's lines, prefixed -- a break in sequence 1 must not go unseen (ADVICE round 5)
+    two = torch.cat([stats, stats])
+    two[1, :, 1] = torch.tensor([200.0, 100.0, 100.0, 100.0, 200.0])
+    two[1, 1, 1] = 5.0
+    buf = io.StringIO()
+    host.print_ggs_stats(two, 7, 100, out=buf)
+    lines = buf.getvalue().splitlines()
+    assert lines[:7] == ["[0] " + l for l in one]
+    assert lines[7:] == ["[1] t=07 | sampson=1.500000", "[1] Drop this pair because of insufficient valid matches", "[1] t=07 | sampson=0.250000",
+                         "[1] t=07 | sampson=3.000000", "[1] t=07 | sampson=0.125000", "[1] t=07 | sampson=9.750000"]
+    # the iterations given come from the engine's own stage table (pd_ggs_stage_iters: no GPU needed)
+    assert host.ggs_stage_iters(100) == (200, 100, 100, 100, 200) and host.ggs_stage_iters(3) == (6, 3, 3, 3, 6)
 
 
 def test_partition_covers_everything():

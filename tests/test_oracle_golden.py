@@ -129,6 +129,19 @@ def test_focal_clamp_edges_golden(golden):
     assert (grad[0, 0, 7:9] == 0).all() and (grad[0, 1, 7:9] == 0).all()      # clamped frames get no focal gradient
 
 
+@pytest.mark.parametrize("tag", ["default", "a", "b"])
+def test_pose_decode_parameters_golden(golden, tag):
+    """The oracle's pose_encoding_to_camera against the reference's (executed in place by oracle/make_golden.py decode_args) at the default
+    and two non-default (log_focal_length_bias, min_focal_length, max_focal_length) -- util/camera_transform.py:64-70, :89-97."""
+    g = golden["decode_args"]
+    bias, fmin, fmax = (float(v) for v in g[f"{tag}_args"])
+    d = O.pose_encoding_to_camera(torch.from_numpy(g["enc"]), bias, fmin, fmax)
+    assert np.array_equal(d["T"].numpy(), g[f"{tag}_T"])
+    assert rel_err(d["R"], g[f"{tag}_R"]) < 1e-6 and rel_err(d["focal_length"], g[f"{tag}_focal"]) < 1e-6
+    f = g[f"{tag}_focal"]
+    assert (f == np.float32(fmin)).any() and (f == np.float32(fmax)).any() and ((f > fmin) & (f < fmax)).any(), "the fixture straddles both clamps"
+
+
 @pytest.mark.parametrize("fname", ["all", "fl", "r"])
 @pytest.mark.parametrize("k", [1, 5, 20])
 def test_ggs_optimize_iterations_golden(golden, fname, k):

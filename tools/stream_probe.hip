@@ -40,7 +40,9 @@ __global__ void stream(const float4 *base, size_t region_f4, int iters, float *o
 // steps of 2 KiB (two global_load_lds_dwordx4 of 1 KiB) through a ring of RING slots in LDS, RING steps in flight at all times, a slot is
 // read out with two ds_read_b128 per lane and refilled at once; the stream is periodic (pass after pass without draining).  `steps` =
 // steps per wave and pass; wave w's share starts at w * steps * 2 KiB.
-template <int RING>
+// ZIGZAG (round 6): the passes alternate direction (0 .. steps-1, steps-1 .. 0, ...): what a pass touched last the next one touches first, so the
+// tail of every wave's stream can still sit in the XCD's L2 (4 MB per 32 CUs = 64 steps of 2 KiB per CU) instead of coming from the Infinity Cache
+template <int RING, bool ZIGZAG = false>
 __global__ __launch_bounds__(512, 2) void stream_ring(const float4 *base, size_t region_f4, int steps, int iters, float *out) {
     extern __shared__ __attribute__((aligned(1024))) float4 ring[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -57,8 +59,20 @@ __global__ __launch_bounds__(512, 2) void stream_ring(const float4 *base, size_t
                      "global_load_lds_dwordx4 %[o1], %[b]\n\ts_mov_b32 m0, %[k]"
                      : [k] "=&s"(keep) : [d] "s"(dst), [b] "s"(src), [o0] "v"(off0), [o1] "v"(off1) : "memory", "scc");
     };
-    for (int u = 0; u < RING; ++u) fetch(u, u % steps);
-    int slot = 0, next = RING % steps;
+    int next = 0, dir = 1;
+    auto advance = [&]() {
+        if (ZIGZAG) {
+            if (next + dir < 0 || next + dir >= steps) dir = -dir;      // the turning step is fetched twice in a row (it is in the L2 by then)
+            else next += dir;
+        } else {
+            next = (next + 1 == steps) ? 0 : next + 1;
+        }
+    };
+    for (int u = 0; u < RING; ++u) {
+        fetch(u, next);
+        advance();
+    }
+    int slot = 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const long long total = (long long)steps * iters;
     for (long long t = 0; t < total; ++t) {
@@ -66,7 +80,7 @@ __global__ __launch_bounds__(512, 2) void stream_ring(const float4 *base, size_t
         float4 q0 = rd[slot * 128], q1 = rd[slot * 128 + 64];
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0.x), "+v"(q1.x) :: "memory");  // read out before the DMA may overwrite the slot
         fetch(slot, next);
-        next = (next + 1 == steps) ? 0 : next + 1;
+        advance();
         slot = (slot + 1 == RING) ? 0 : slot + 1;
         acc.x += q0.x + q1.x; acc.y += q0.y + q1.y; acc.z += q0.z + q1.z; acc.w += q0.w + q1.w;
     }
@@ -105,6 +119,8 @@ int main() {
                     hipEventSynchronize(e1);
                     hipEventElapsedTime(&ms, e0, e1);
                 }
+                // a launch the device refused (resource limits) is not a measurement: say so instead of printing its 0.0001 ms
+                if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { printf("%6d KB  %-16s %6d  launch failed\n", kb, kn[k], w); continue; }
                 const double bytes = (double)region_f4 * 16 * 256 * iters;
                 printf("%6d KB  %-16s %6d %10.4f %10.2f\n", kb, kn[k], w, ms / iters, bytes / (ms * 1e-3) / 1e12);
             }
@@ -128,8 +144,31 @@ int main() {
                 hipEventSynchronize(e1);
                 hipEventElapsedTime(&ms, e0, e1);
             }
+            if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { printf("FAILED ring of %d, %d steps\n", rdepth[k], steps); continue; }
             const double bytes = (double)region_f4 * 16 * 256 * iters;
             fflush(stdout); printf("RING %4zu KB  ring of %d x 2 KiB  %6d %10.4f %10.2f\n", region_f4 * 16 / 1024, rdepth[k], 8, ms / iters, bytes / (ms * 1e-3) / 1e12);
         }
+    // round 6: the same rings with passes of alternating direction (rows "ZIGZAG": not a bench.py ceiling row), ring of 3 and 4, 40 steps per wave = the
+    // streamed part of a sequence under the [75 x 4, 38 x 4] cuts (58 + 21 steps per wave pair)
+    ring_t zk[] = {stream_ring<3, false>, stream_ring<3, true>, stream_ring<4, false>, stream_ring<4, true>};
+    const char *zn[] = {"ring 3 periodic", "ring 3 zigzag", "ring 4 periodic", "ring 4 zigzag"};
+    for (int k = 0; k < 4; ++k) hipFuncSetAttribute((const void *)zk[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int steps : {40, 57})
+        for (int rep = 0; rep < 2; ++rep)
+            for (int k = 0; k < 4; ++k) {
+                const size_t region_f4 = (size_t)8 * steps * 128;
+                const int iters = 60;
+                float ms = 0;
+                for (int pass = 0; pass < 2; ++pass) {
+                    hipEventRecord(e0, 0);
+                    hipLaunchKernelGGL(zk[k], dim3(256), dim3(512), 160 * 1024, 0, buf, region_f4, steps, iters, out);
+                    hipEventRecord(e1, 0);
+                    hipEventSynchronize(e1);
+                    hipEventElapsedTime(&ms, e0, e1);
+                }
+                if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { printf("FAILED %s\n", zn[k]); continue; }
+                const double bytes = (double)region_f4 * 16 * 256 * iters;
+                printf("ZIGZAG %4zu KB  %-16s %10.4f ms/pass %10.2f TB/s\n", region_f4 * 16 / 1024, zn[k], ms / iters, bytes / (ms * 1e-3) / 1e12);
+            }
     return 0;
 }
