@@ -353,9 +353,13 @@ typedef struct pd_vit_weights {
 typedef struct pd_vit pd_vit;
 int pd_vit_create(const pd_vit_weights *w, pd_vit **out);
 void pd_vit_destroy(pd_vit *v);
-/* PD_VIT_OPT_EXACT_FP32: 0 (default) = batches of >= 1024 token rows run their GEMMs in split precision (every fp32 operand
- * as bf16 hi + bf16 lo, three bf16 matrix products, fp32 accumulation; features deviate ~1e-5 of max|z| from the fp32
- * network, the contract is 1e-4); 1 = the exact-fp32 matrix instruction everywhere. */
+/* PD_VIT_OPT_EXACT_FP32, the arithmetic of batches of >= 1024 token rows (smaller batches are exact fp32 whatever it says):
+ *   0 (default) = the four Linear layers of every block on fp16 hi + fp16 lo operand planes (22 mantissa bits, power-of-two scales fixed at
+ *       creation from bounds that hold for every input, three fp16 matrix products, fp32 accumulation) -- the denoiser's default mode;
+ *       LayerNorm, QK^T, softmax, PV, GELU (exact erf form) and residuals in fp32: fp32-grade features.  Non-finite weights have no bound:
+ *       such a network runs mode 1;
+ *   1 = the exact-fp32 matrix instruction everywhere;
+ *   2 = rounds 1-5's bf16 hi + lo planes (16 bits, QK^T on them too, polynomial GELU): features ~1e-5 of max|z| off, kept for comparison. */
 #define PD_VIT_OPT_EXACT_FP32 1
 int pd_vit_set_option(pd_vit *v, int option, int value);
 
@@ -370,6 +374,14 @@ int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, int H, int W
                          float weight, int accumulate, float *z_out, void *stream);
 
 /* ---- measurement helpers ------------------------------------------------------------------ */
+
+/* Start / end of the GGS launches of the engine's LAST sampling pass, recorded by the kernel itself (lane-per-item kernel: workgroup 0
+ * stores wall_clock64() when it starts, every workgroup atomicMax'es it when it ends): dst[k][2] (DEVICE int64) <- {start, end} ticks of
+ * the launch of guided step k = 0 .. n-1 (k = cond_start_step - 1 - t; a step-level pd_ggs_guide uses slot 0), copied on `stream`
+ * behind the work already enqueued there; *clock_khz_out = tick rate (hipDeviceAttributeWallClockRate).  This is how bench.py times the
+ * dominant kernel INSIDE its timed region -- launches replayed from a captured graph, several contexts in flight -- instead of a launch
+ * alone on an idle chip.  Slots of launches that ran another GGS kernel read {0, 0}. */
+int pd_ggs_launch_stamps(pd_engine *eng, long long *dst, int n, int *clock_khz_out, void *stream);
 
 /* Times `reps` launches of the dominant kernels with hipEvents on `stream` (the stream the
  * kernels run on) and returns average milliseconds per launch.  what: 0 = one full denoiser

@@ -82,7 +82,7 @@ extern "C" void pd_engine_destroy(pd_engine *eng) {
         (void)hipEventDestroy(r.done);
     }
     pd_denoiser_destroy(eng);
-    void *ptrs[] = {eng->d_seqs, eng->d_xchg, eng->d_err, eng->d_z, eng->d_noise, eng->d_process, eng->d_mean, eng->d_stats};
+    void *ptrs[] = {eng->d_seqs, eng->d_xchg, eng->d_err, eng->d_z, eng->d_noise, eng->d_process, eng->d_mean, eng->d_stats, eng->d_stamps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete eng;
@@ -157,6 +157,7 @@ extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_en
         PD_ALLOC(eng->d_seqs, sizeof(PdSeqDesc) * max_B);
         PD_ALLOC(eng->d_xchg, sizeof(unsigned long long) * 2 * eng->xchg_granules * max_B);
         PD_ALLOC(eng->d_err, 256);
+        PD_ALLOC(eng->d_stamps, sizeof(unsigned long long) * 2 * PD_STAMP_SLOTS);
         PD_ALLOC(eng->d_z, sizeof(float) * max_B * max_N * w->z_dim);
         PD_ALLOC(eng->d_noise, sizeof(float) * (T + 1) * bn9);
         PD_ALLOC(eng->d_process, sizeof(float) * (T + 1) * bn9);
@@ -164,7 +165,8 @@ extern "C" int pd_engine_create(const pd_weights *w, int max_B, int max_N, pd_en
         PD_ALLOC(eng->d_stats, sizeof(float) * (size_t)T * max_B * 5 * 4);
 #undef PD_ALLOC
         if (hipMemset(eng->d_seqs, 0, sizeof(PdSeqDesc) * max_B) != hipSuccess ||
-            hipMemset(eng->d_err, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            hipMemset(eng->d_err, 0, 256) != hipSuccess || hipMemset(eng->d_stamps, 0, sizeof(unsigned long long) * 2 * PD_STAMP_SLOTS) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
             pd_set_error("pd_engine_create: hipMemset failed");
             rc = PD_ERR_HIP;
             break;
@@ -313,7 +315,9 @@ static int issue_loop(pd_engine *eng, int B, int N, int cond_start, const pd_ggs
             rc = pd_denoiser_launch(eng, x, eng->d_z, t, B, N, nullptr, nullptr, nullptr, nullptr, xn, s, true);
             if (rc) return rc;
             float *st = want_stats ? eng->d_stats + (size_t)(cond_start - 1 - t) * B * 5 * 4 : nullptr;
+            eng->stamp_slot = (cond_start - 1 - t) % PD_STAMP_SLOTS;     // this guided step's launch stamps (baked into a captured node like `st`)
             rc = pd_ggs_guide(eng, xn, B, N, t, ggs, st, s);
+            eng->stamp_slot = 0;
         } else {
             const float *nz = (t > 0) ? eng->d_noise + (size_t)(step + 1) * bn9 : nullptr;   // :278
             rc = pd_denoiser_launch(eng, x, eng->d_z, t, B, N, nullptr, nullptr, nullptr, nz, xn, s, true);
@@ -564,6 +568,27 @@ extern "C" int pd_debug_ggs_prof(pd_engine *eng, int enable, long long *out6) {
         PD_HIP_CHECK(hipDeviceSynchronize());
         PD_HIP_CHECK(hipMemcpy(out6, eng->d_err + 2, sizeof(long long) * 16, hipMemcpyDeviceToHost));
     }
+    return PD_OK;
+}
+
+__global__ void pd_copy_stamps_kernel(const unsigned long long *__restrict__ src, long long *__restrict__ dst, int n2) {
+    const int i = threadIdx.x;
+    if (i < n2) dst[i] = (long long)src[i];
+}
+extern "C" int pd_ggs_launch_stamps(pd_engine *eng, long long *dst, int n, int *clock_khz_out, void *stream) {
+    if (!eng || !dst || n <= 0 || n > PD_STAMP_SLOTS) {
+        pd_set_error("pd_ggs_launch_stamps: invalid arguments (n=%d, at most %d slots)", n, PD_STAMP_SLOTS);
+        return PD_ERR_INVALID_ARG;
+    }
+    if (clock_khz_out) {
+        static int khz = 0;          // one query per process: the attribute call is not free and bench.py asks once per pass
+        if (khz == 0) PD_HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, eng->device));
+        *clock_khz_out = khz;
+    }
+    // a one-workgroup kernel into the caller's (preallocated) rows, not hipMemcpyAsync into a fresh tensor: that form of the readout cost bench.py's
+    // pipe 40 % (653 instead of 1 080 sequences/s, profiles/round6_launch_stamps_ab.txt); a launch is ordered on its stream and nothing else
+    hipLaunchKernelGGL(pd_copy_stamps_kernel, dim3(1), dim3(2 * PD_STAMP_SLOTS), 0, (hipStream_t)stream, eng->d_stamps, dst, 2 * n);
+    PD_HIP_CHECK(hipGetLastError());
     return PD_OK;
 }
 

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
             for (int i = 0; i < 16; ++i) {
                 const int row = r0 + (i & 3) + 8 * (i >> 2);
                 float v = F16 ? fmaf(acc[mi][c][i], g.c_scale, bias) : acc[mi][c][i] + bias;
-                if constexpr (EPI == 3) v = vit_gelu_fast(v);
+                if constexpr (EPI == 3) v = F16 ? 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)) : vit_gelu_fast(v);   // fp16 planes: nn.GELU()'s exact form
                 if constexpr (EPI == 4) v = pd_relu(v);
                 if constexpr (EPI == 2) v += res[i];
                 if (row < g.M) {

@@ -2207,6 +2207,7 @@ int pd_ggs_launch(pd_engine *eng, float *x, int B, int N, const PdGgsStage *stag
     P.prof = eng->ggs_prof_on ? (long long *)(eng->d_err + 2) : nullptr;
     P.prof_wave = eng->ggs_prof_on > 0 ? (eng->ggs_prof_on - 1) & 0x107 : 1;
     P.n_seqs = B;
+    P.stamp = eng->d_stamps ? eng->d_stamps + 2 * (size_t)eng->stamp_slot : nullptr;
     P.xchg_local = plan.xchg_local;
     const int B_map = plan.xchg_local ? ((B + 7) & ~7) : B;     // the kernels' block -> (sequence, workgroup) mapping
     if (k > 1) {

@@ -111,6 +111,10 @@ struct PdGgsParams {
     long long *prof;           // optional phase cycle counters (debug), else null
     int prof_wave;             // which wave of workgroup 0 records them
     int n_seqs;                // sequences of the launch (the kernels' `B` argument is this, or this rounded up to 8: xchg_local)
+    unsigned long long *stamp; // [2] {start, end} of this launch in wall_clock64() ticks (constant rate: hipDeviceAttributeWallClockRate), written by the
+                               //   lane-per-item kernel itself: workgroup 0 stores its start, every workgroup atomicMax'es its end (the clock only
+                               //   grows, so a slot re-used by the next replay needs no reset); null: not recorded.  bench.py reads the launches of
+                               //   its timed region from these (pd_ggs_launch_stamps): the in-pipe duration of the dominant kernel
     int xchg_local;            // one-hop kernel, k > 1: the launch places all workgroups of a sequence on ONE XCD (block -> sequence mapping
                                //   padded to a multiple of 8); the kernel verifies it and then keeps its exchange stores in that XCD's L2
 };
@@ -211,6 +215,8 @@ struct pd_engine {
     int den_split = 0;               // PD_OPT_DENOISER_SPLIT: encoder GEMMs of the large-batch path: 0 exact fp32, 1 bf16 planes, 2 fp16 planes (default there)
     int gemm_wide_min_tiles = 200;   // launch_gemm: 32-wide tiles when there are at least this many of them
     float *d_stats_scratch = nullptr;
+    unsigned long long *d_stamps = nullptr;   // [PD_STAMP_SLOTS][2] launch stamps of the GGS launches (PdGgsParams::stamp); slot = guided step index of the
+    int stamp_slot = 0;                       //   sampling loop (issue_loop sets it before every pd_ggs_guide), 0 for the step-level API
     // sampler buffers (fixed addresses so a captured graph can be replayed)
     float *d_z = nullptr, *d_noise = nullptr, *d_process = nullptr, *d_mean = nullptr, *d_stats = nullptr;
     // graph cache
@@ -263,3 +269,4 @@ int pd_mark_use(pd_engine *eng, hipStream_t s);
 int pd_record_stream_event(std::vector<pd_engine::StreamEvent> &list, hipStream_t s);   // (re)record this stream's event of the list
 int pd_wait_uses(pd_engine *eng, hipStream_t s, bool host);   // wait (device side on s, or on the host) for every recorded use
 #define PD_GRAPH_CACHE_MAX 8
+#define PD_STAMP_SLOTS 128

@@ -34,12 +34,17 @@
 
 struct pd_vit {
     int device = 0, depth = 0, grid0 = 0;       // grid0: side of the trained position grid (14)
-    int exact_fp32 = 0;                         // PD_VIT_OPT_EXACT_FP32
+    int exact_fp32 = 0;                         // PD_VIT_OPT_EXACT_FP32: 0 fp16 planes (default at >= 1 024 rows), 1 exact fp32, 2 bf16 planes (rounds 1-5)
+    bool h_ready = false;                       // the fp16-plane weights and their static scales exist (finite weights)
+    float ln_scale = 1.0f;                      // 2^e of the LayerNorm operand (|x^| <= sqrt(384))
     float *patch_wp = nullptr, *patch_b = nullptr, *cls = nullptr, *pos = nullptr;   // pos [1 + grid0^2, 384]
     struct Layer {
         float *qkv_wp, *qkv_b, *proj_wp, *proj_b, *fc1_wp, *fc1_b, *fc2a_wp, *fc2b_wp, *fc2_b;
         float *qkv_wf, *proj_wf, *fc1_wf, *fc2_wf;      // row-major copies (LayerNorm scale folded) for the streamed GEMM
         unsigned *qkv_ws, *proj_ws, *fc1_ws, *fc2_ws;   // split into bf16 hi / lo, in MFMA fragment order (vit_frag_split_kernel)
+        unsigned *qkv_wh, *proj_wh, *fc1_wh, *fc2_wh;   // fp16 hi / lo planes of w * 2^e (round 6: the denoiser's fp16-plane mode, pd_gemm_strip_kernel<.., F16>)
+        float qkv_cs, proj_cs, fc1_cs, fc2_cs;          // accumulator scales 2^-(e_operand + e_weight)
+        float ctx_scale, hid_scale;                     // 2^e of the attention output / the GELU hidden rows (split-word operands of proj / fc2)
     } L[VDEPTH_MAX];
     float *norm_w = nullptr, *norm_b = nullptr, *zero_b = nullptr;
     // workspaces, sized at the first forward / grown on demand
@@ -304,8 +309,10 @@ __device__ __forceinline__ void vit_split8(const float4 &a, const float4 &c, flo
 //   P = softmax(S)  : 8 threads per row, in place
 //   O = P V         : waves = 2 column tiles (32 of the 64 head dims) x 2 halves of the keys; V fragments from global memory
 //                     (32 consecutive dims per half wave), the two halves summed through LDS
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void vit_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int T, int nqb) {
+// SPLIT: 0 = exact-fp32 QK^T, fp32 ctx; 1 = QK^T on bf16 hi + lo planes, ctx as bf16 split words (rounds 1-5); 2 = exact-fp32 QK^T, ctx as fp16 split
+// words of ctx * out_scale (round 6: the default at >= 1 024 rows -- only the four Linear layers run on fp16 planes, as in the denoiser)
+template <int SPLIT>
+__global__ __launch_bounds__(256) void vit_attn_kernel(const float *__restrict__ qkv, float *__restrict__ ctx, int T, int nqb, float out_scale) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nkt = (T + 31) >> 5, LP = nkt * 32 + 4;
     float *S = lds;
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const float *__restrict__
     b /= nqb;
     const int h = b % VH, im = b / VH, q0 = qb * 32;
     const float *base = qkv + (size_t)im * T * (3 * VD) + h * VDH;
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT == 1) {
         // S = (Q / 8) K^T in split precision: 8 consecutive head dims per lane and 16-k step (lanes 0-31 the even groups of 8,
         // lanes 32-63 the odd ones), each fp32 fragment split into bf16 hi + lo in registers, three bf16 products per step
         bf16x8 qh[4], ql[4];
@@ -486,8 +493,10 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const float *__restrict__
             if (qr < T) {
                 const float v = o[i] + red[(nt * 16 + i) * 64 + lane];
                 float *dst = ctx + ((size_t)im * T + qr) * VD + h * VDH + nt * 32 + l31;
-                if constexpr (SPLIT)
+                if constexpr (SPLIT == 1)
                     *(unsigned *)dst = pd_split_word(v);       // feeds vit_gemm_split_kernel
+                else if constexpr (SPLIT == 2)
+                    *(unsigned *)dst = pd_split_word_h(v * out_scale);     // feeds pd_gemm_strip_kernel<.., F16>
                 else
                     *dst = v;
             }
@@ -574,6 +583,85 @@ extern "C" void pd_vit_destroy(pd_vit *v) {
     delete v;
 }
 
+// The fp16-plane mode of the four Linear layers (round 6; the denoiser's pd_denoiser_build_scales, for dim 384): fp16 keeps 11 bits and five
+// exponent bits, so every operand gets a POWER-OF-TWO scale (exact to apply and to undo) fixed here from bounds that hold for every input:
+//   * LayerNorm output without affine: sum of squares <= D, so |x^| <= sqrt(384) = 19.6;                       scale 2^floor(log2(32768 / 19.6)) = 2^10
+//   * a Linear fed by it: |x^ . w + b| <= sqrt(D) ||w||_2 + |b| (Cauchy-Schwarz) -- the V rows the attention averages (a convex combination:
+//     same bound) and the FC1 rows, of which GELU keeps |gelu(v)| <= |v|;                                          scale 2^floor(log2(32768 / bound))
+//   * weights (LayerNorm gamma folded): 2^floor(log2(16384 / max |w|)).
+// Nothing can overflow (fp16 max 65 504); hi + lo keeps 22 bits.  Non-finite weights have no bound: h_ready stays false and the engine
+// runs the exact-fp32 kernels (which propagate inf / NaN like the reference).
+static int vit_floor_log2_ratio(double cap, double v) {
+    if (!(v > 0.0)) return 0;
+    double e = floor(log2(cap / v));
+    e = e < -60.0 ? -60.0 : (e > 60.0 ? 60.0 : e);
+    return (int)e;
+}
+static int vit_build_planes_h(pd_vit *v) {
+    std::vector<float> w, b;
+    bool finite = true;
+    auto fetch = [&](const float *Wf, const float *bias, int Nout, int K) -> int {
+        w.resize((size_t)Nout * K);
+        b.resize(Nout);
+        PD_HIP_CHECK(hipMemcpy(w.data(), Wf, w.size() * sizeof(float), hipMemcpyDeviceToHost));
+        PD_HIP_CHECK(hipMemcpy(b.data(), bias, b.size() * sizeof(float), hipMemcpyDeviceToHost));
+        return PD_OK;
+    };
+    auto max_abs = [&]() { double m = 0; for (float x : w) { finite = finite && isfinite(x); m = fmax(m, fabs((double)x)); } return m; };
+    auto row_bound = [&](int r0, int r1, int K) {            // max over rows of sqrt(D) ||w_r||_2 + |b_r|
+        double bound = 0;
+        for (int r = r0; r < r1; ++r) {
+            double q = 0;
+            for (int k = 0; k < K; ++k) q += (double)w[(size_t)r * K + k] * w[(size_t)r * K + k];
+            bound = fmax(bound, sqrt((double)VD) * sqrt(q) + fabs((double)b[r]));
+            finite = finite && isfinite(q) && isfinite(b[r]);
+        }
+        return bound;
+    };
+    auto planes = [&](unsigned **dst, const float *Wf, int Nout, int K, int ew) -> int {
+        float *p = nullptr;
+        VIT_TRY(vit_alloc(v, &p, (size_t)Nout * K));
+        *dst = (unsigned *)p;
+        const size_t total = (size_t)(Nout / 32) * (K / 16) * 64;
+        hipLaunchKernelGGL(vit_frag_split_kernel, dim3(512), dim3(256), 0, 0, Wf, (const float *)nullptr, K, total, (uint4 *)p, 1, ldexpf(1.0f, ew));   // gamma is in Wf
+        PD_HIP_CHECK(hipGetLastError());
+        return PD_OK;
+    };
+    PD_HIP_CHECK(hipDeviceSynchronize());
+    const int e_ln = vit_floor_log2_ratio(32768.0, sqrt((double)VD));
+    struct E { int qkv, proj, fc1, fc2, ctx, hid; } e[VDEPTH_MAX];
+    for (int l = 0; l < v->depth; ++l) {
+        pd_vit::Layer &L = v->L[l];
+        VIT_TRY(fetch(L.qkv_wf, L.qkv_b, 3 * VD, VD));
+        e[l].ctx = vit_floor_log2_ratio(32768.0, row_bound(2 * VD, 3 * VD, VD));
+        e[l].qkv = vit_floor_log2_ratio(16384.0, max_abs());
+        VIT_TRY(fetch(L.proj_wf, L.proj_b, VD, VD));
+        e[l].proj = vit_floor_log2_ratio(16384.0, max_abs());
+        VIT_TRY(fetch(L.fc1_wf, L.fc1_b, VFF, VD));
+        e[l].hid = vit_floor_log2_ratio(32768.0, row_bound(0, VFF, VD));
+        e[l].fc1 = vit_floor_log2_ratio(16384.0, max_abs());
+        VIT_TRY(fetch(L.fc2_wf, L.fc2_b, VD, VFF));
+        e[l].fc2 = vit_floor_log2_ratio(16384.0, max_abs());
+        if (!finite) return PD_OK;                 // (not an error: the exact-fp32 kernels take such a network)
+    }
+    for (int l = 0; l < v->depth; ++l) {
+        pd_vit::Layer &L = v->L[l];
+        VIT_TRY(planes(&L.qkv_wh, L.qkv_wf, 3 * VD, VD, e[l].qkv));
+        VIT_TRY(planes(&L.proj_wh, L.proj_wf, VD, VD, e[l].proj));
+        VIT_TRY(planes(&L.fc1_wh, L.fc1_wf, VFF, VD, e[l].fc1));
+        VIT_TRY(planes(&L.fc2_wh, L.fc2_wf, VD, VFF, e[l].fc2));
+        L.qkv_cs = ldexpf(1.0f, -(e_ln + e[l].qkv));
+        L.proj_cs = ldexpf(1.0f, -(e[l].ctx + e[l].proj));
+        L.fc1_cs = ldexpf(1.0f, -(e_ln + e[l].fc1));
+        L.fc2_cs = ldexpf(1.0f, -(e[l].hid + e[l].fc2));
+        L.ctx_scale = ldexpf(1.0f, e[l].ctx);
+        L.hid_scale = ldexpf(1.0f, e[l].hid);
+    }
+    v->ln_scale = ldexpf(1.0f, e_ln);
+    v->h_ready = true;
+    return PD_OK;
+}
+
 extern "C" int pd_vit_create(const pd_vit_weights *w, pd_vit **out) {
     if (!w || !out) {
         pd_set_error("pd_vit_create: NULL argument");
@@ -631,8 +719,10 @@ extern "C" int pd_vit_create(const pd_vit_weights *w, pd_vit **out) {
         if ((rc = vit_set_lds(vit_gemm_kernel<VD, 0, 2>, 32 * (VD + 4) * 4))) break;
         if ((rc = vit_set_lds(vit_gemm_kernel<VD, 1, 3>, 32 * (VD + 4) * 4))) break;
         if ((rc = vit_set_lds(vit_gemm_kernel<VKP, 0, 2>, 32 * (VKP + 4) * 4))) break;
-        if ((rc = vit_set_lds(vit_attn_kernel<false>, vit_attn_lds(VT_MAX)))) break;
-        if ((rc = vit_set_lds(vit_attn_kernel<true>, vit_attn_lds(VT_MAX)))) break;
+        if ((rc = vit_set_lds(vit_attn_kernel<0>, vit_attn_lds(VT_MAX)))) break;
+        if ((rc = vit_set_lds(vit_attn_kernel<1>, vit_attn_lds(VT_MAX)))) break;
+        if ((rc = vit_set_lds(vit_attn_kernel<2>, vit_attn_lds(VT_MAX)))) break;
+        if ((rc = vit_build_planes_h(v))) break;
         if (hipDeviceSynchronize() != hipSuccess) rc = PD_ERR_HIP;
     } while (0);
     if (rc) {
@@ -679,7 +769,7 @@ static void vit_gemm(const VitGemmArgs &g, hipStream_t s) {
 #define vit_gemm_split pd_gemm_split
 
 extern "C" int pd_vit_set_option(pd_vit *v, int option, int value) {
-    if (!v || option != PD_VIT_OPT_EXACT_FP32 || (value != 0 && value != 1)) {
+    if (!v || option != PD_VIT_OPT_EXACT_FP32 || value < 0 || value > 2) {
         pd_set_error("pd_vit_set_option: unknown option %d / value %d", option, value);
         return PD_ERR_INVALID_ARG;
     }
@@ -729,11 +819,24 @@ extern "C" int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, i
     const bool streamed = (int)tokens >= PD_STREAM_MIN_ROWS;
     for (int l = 0; l < v->depth; ++l) {
         const pd_vit::Layer &L = v->L[l];
-        if (streamed && !v->exact_fp32) {
+        if (streamed && v->exact_fp32 == 0 && v->h_ready) {
+            // fp16-plane mode (round 6, the default): LayerNorm, softmax, QK^T, PV, residuals in fp32; the four Linear layers multiply fp16 hi + lo
+            // operand pairs (22 bits, static power-of-two scales) with fp32 accumulation; exact erf GELU in FC1's epilogue
+            const int M = (int)tokens;
+            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, 2>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f, v->ln_scale);
+            pd_gemm_strip<0, 2, true, 1, true>((const unsigned *)v->xn, VD, L.qkv_wh, VD, L.qkv_b, v->qkv, M, 3 * VD, s, L.qkv_cs);
+            hipLaunchKernelGGL(vit_attn_kernel<2>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb, L.ctx_scale);
+            pd_gemm_strip<2, 2, true, 1, true>((const unsigned *)v->ctx, VD, L.proj_wh, VD, L.proj_b, v->x, M, VD, s, L.proj_cs);
+            hipLaunchKernelGGL((pd_ln_rows_kernel<VD, 2>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f, v->ln_scale);
+            pd_gemm_strip<3, 2, true, 1, true>((const unsigned *)v->xn, VD, L.fc1_wh, VD, L.fc1_b, v->hid, M, VFF, s, L.fc1_cs, L.hid_scale);
+            pd_gemm_strip<2, 2, true, 1, true>((const unsigned *)v->hid, VFF, L.fc2_wh, VFF, L.fc2_b, v->x, M, VD, s, L.fc2_cs);
+            continue;
+        }
+        if (streamed && v->exact_fp32 == 2) {
             const int M = (int)tokens;
             hipLaunchKernelGGL((pd_ln_rows_kernel<VD, 1>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f, 1.0f);
             vit_gemm_split<0, 2, 2>((const unsigned *)v->xn, VD, L.qkv_ws, VD, L.qkv_b, v->qkv, M, 3 * VD, s);
-            hipLaunchKernelGGL(vit_attn_kernel<true>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
+            hipLaunchKernelGGL(vit_attn_kernel<1>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb, 1.0f);
             vit_gemm_split<2, 2, 1>((const unsigned *)v->ctx, VD, L.proj_ws, VD, L.proj_b, v->x, M, VD, s);
             hipLaunchKernelGGL((pd_ln_rows_kernel<VD, 1>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f, 1.0f);
             vit_gemm_split<3, 2, 2>((const unsigned *)v->xn, VD, L.fc1_ws, VD, L.fc1_b, v->hid, M, VFF, s);
@@ -744,7 +847,7 @@ extern "C" int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, i
             const int M = (int)tokens;
             hipLaunchKernelGGL((pd_ln_rows_kernel<VD, 0>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f, 1.0f);
             pd_gemm_stream<0>(v->xn, VD, L.qkv_wf, VD, L.qkv_b, v->qkv, M, 3 * VD, s);
-            hipLaunchKernelGGL(vit_attn_kernel<false>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
+            hipLaunchKernelGGL(vit_attn_kernel<0>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb, 1.0f);
             pd_gemm_stream<2>(v->ctx, VD, L.proj_wf, VD, L.proj_b, v->x, M, VD, s);
             hipLaunchKernelGGL((pd_ln_rows_kernel<VD, 0>), dim3((M + 3) / 4), dim3(256), 0, s, v->x, v->xn, M, 1e-6f, 1.0f);
             pd_gemm_stream<3>(v->xn, VD, L.fc1_wf, VD, L.fc1_b, v->hid, M, VFF, s);
@@ -753,7 +856,7 @@ extern "C" int pd_vit_forward_scale(pd_vit *v, const float *images, int n_img, i
         }
         g.A = v->x; g.lda = VD; g.Wp = L.qkv_wp; g.bias = L.qkv_b; g.C = v->qkv; g.Nout = 3 * VD;
         vit_gemm<VD, 1, 0>(g, s);
-        hipLaunchKernelGGL(vit_attn_kernel<false>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb);
+        hipLaunchKernelGGL(vit_attn_kernel<0>, dim3(n_img * VH * nqb), dim3(256), attn_lds, s, v->qkv, v->ctx, T, nqb, 1.0f);
         g.A = v->ctx; g.lda = VD; g.Wp = L.proj_wp; g.bias = L.proj_b; g.C = v->x; g.Nout = VD;
         vit_gemm<VD, 0, 2>(g, s);
         g.A = v->x; g.lda = VD; g.Wp = L.fc1_wp; g.bias = L.fc1_b; g.C = v->hid; g.Nout = VFF;

@@ -291,6 +291,18 @@ class PoseEngine:
                                                  self._stream()), "pd_pose_to_camera_ex")
         return R, T, F
 
+    def ggs_launch_stamps(self, n: int, out: Optional[torch.Tensor] = None):
+        """(int64 tensor [n, 2] on the device, ticks per millisecond): {start, end} of the GGS launches of guided steps 0 .. n-1 of the last
+        sampling pass, recorded by the kernel itself (pd_ggs_launch_stamps); copied on the current stream behind the pass.  ``out``: a
+        preallocated contiguous int64 [n, 2] device tensor (no allocation between the passes of a pipe)."""
+        if out is None:
+            out = torch.zeros(int(n), 2, dtype=torch.int64, device=self.device)
+        elif out.dtype != torch.int64 or tuple(out.shape) != (int(n), 2) or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous int64 [n, 2] tensor on the engine's device")
+        khz = C.c_int(0)
+        _lib.check(self.lib.pd_ggs_launch_stamps(self._h, out.data_ptr(), int(n), C.byref(khz), self._stream()), "pd_ggs_launch_stamps")
+        return out, float(khz.value)
+
     def time_kernel(self, what: int, B: int, N: int, cfg=None, reps: int = 10) -> float:
         c = cfg if isinstance(cfg, _lib.pd_ggs_cfg) else make_ggs_cfg(cfg)
         ms = C.c_float(0.0)

@@ -65,9 +65,10 @@ class VitEngine:
         self._h = h
         self._pos_cache: Dict[Tuple[int, int], torch.Tensor] = {}
 
-    def set_exact_fp32(self, on: bool):
-        """True: the exact-fp32 matrix instruction everywhere; False (default): split-precision GEMMs for large batches."""
-        _lib.check(self.lib.pd_vit_set_option(self._h, 1, int(bool(on))), "pd_vit_set_option")
+    def set_exact_fp32(self, on):
+        """Arithmetic of batches of >= 1024 token rows (PD_VIT_OPT_EXACT_FP32): False / 0 (default) fp16 hi + lo planes for the four Linear
+        layers (22 bits, static scales: fp32-grade); True / 1 the exact-fp32 matrix instruction everywhere; 2 the bf16 planes of rounds 1-5."""
+        _lib.check(self.lib.pd_vit_set_option(self._h, 1, int(on)), "pd_vit_set_option")
 
     def close(self):
         if getattr(self, "_h", None):

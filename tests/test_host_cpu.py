@@ -198,12 +198,33 @@ def test_product_never_touches_the_oracle():
                 if pat.search(txt) or "oracle/_ref" in txt or "sys.path" in txt and "oracle" in txt:
                     offenders.append(os.path.join(base, f))
     assert not offenders, offenders
-    bench = open(os.path.join(root, "bench.py")).read()
-    uses = [m.start() for m in pat.finditer(bench)]
-    body = bench[bench.index("def cpu_baseline"):bench.index("def main")]
-    assert uses and all(bench.index("def cpu_baseline") < u < bench.index("def main") for u in uses), \
-        "bench.py may import the oracle only inside cpu_baseline()"
-    assert "oracle" in body
+    # bench.py itself never imports the oracle; bench_legs.py only inside cpu_baseline()
+    assert not pat.search(open(os.path.join(root, "bench.py")).read())
+    legs = open(os.path.join(root, "bench_legs.py")).read()
+    uses = [m.start() for m in pat.finditer(legs)]
+    lo = legs.index("def cpu_baseline")
+    hi = legs.index("\ndef ", lo + 1)
+    assert uses and all(lo < u < hi for u in uses), "bench_legs.py may import the oracle only inside cpu_baseline()"
+
+
+def test_bench_legs_are_callable_pieces():
+    """bench.py = command line + timed region + JSON line; the legs are functions of bench_legs.py: the ones that need
+    no GPU are exercised here -- the cut-rule mirror, the in-pipe launch statistics, the argument defaults."""
+    import bench
+    import bench_legs as L
+    frac, items, waves = L.lane_stream_fraction([300] * 190)
+    assert waves == [75, 75, 75, 75, 38, 38, 38, 38] and items == 504          # pd_lane_pass_cost's choice on the bench shape (csrc/pd_internal.h)
+    assert abs(frac - sum(max(t - L.LANE_RESIDENT_STEPS, 0) for t in waves) * 64 * 32 / (16.0 * 57000)) < 1e-12
+    assert L.lane_stream_fraction([7] * 190)[1] <= 512 and L.lane_stream_fraction([40] * 28)[0] == 0.0
+    # launch stamps -> durations: {0, 0} slots (another kernel ran) and unordered pairs are dropped
+    st = torch.tensor([[1000, 2600], [0, 0], [5000, 4000], [7000, 8650]], dtype=torch.int64)
+    assert L.in_pipe_launches([(st, 100.0)]) == [16.0, 16.5] and L.in_pipe_launches([]) == []
+    a = bench.parse_args([])
+    assert (a.gpus, a.steps, a.warmup, a.scaling, a.pipeline_depth, a.engine_batch) == (1, 24, 4, "strong", 3, 256)
+    for leg in ("cpu_baseline", "measure_config", "per_config", "from_images", "pass_latency", "cold_single_batch", "exact_mode", "fresh_inputs",
+                "headline_slots_equal_alone", "roofline_ggs", "roofline_denoiser", "rank_emulation", "stream_ceiling", "pmc_traffic"):
+        assert callable(getattr(L, leg)), leg
+    assert L.CPU_GGS_THREADS == 16 and L.CPU_DEN_THREADS == 8                   # fixed thread counts of the cpu_baseline (stated in its `sample`)
 
 
 def test_colmap_keypoint_bookkeeping_vs_reference_fixture(golden):

@@ -17,7 +17,7 @@ B, N = 8, 20
 diff = synth.make_diffuser(seed=0).to(dev)
 tables = {k: v for k, v in diff.named_buffers(recurse=False)}
 engines = [PoseEngine(denoiser_state(diff.model), tables, device=dev, max_B=B, max_N=N) for _ in range(depth)]
-inputs = [bench.build_inputs(engines[j], diff, B, dev, seed0=j * B) for j in range(depth)]
+inputs = [bench.make_batch_inputs(engines[j], diff, B, dev, seed0=j * B) for j in range(depth)]
 cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=wgs)
 pipe = SamplingPipeline(engines, slots, dev, trace=False, unguided_streams=nu)
 for j in range(depth):
