@@ -24,6 +24,15 @@
 #include "pd_gemm_stream.h"
 #include "pd_gemm_split.h"
 #include "pd_qkv_attn.h"
+#ifndef PD_STRIP_RT3
+#define PD_STRIP_RT3 1         // round 6: 96-row tiles for the 512-wide strip GEMMs when that takes them from more tiles than CUs to at most one per CU
+#endif
+#ifndef PD_STRIP_RT1
+#define PD_STRIP_RT1 0         // (probe: 32-row tiles instead -- 640 half tiles, more workgroups per CU, twice the weight bytes per MFMA)
+#endif
+#ifndef PD_STRIP_RT3_FF1
+#define PD_STRIP_RT3_FF1 0     // (the 1 024-wide FF1 has 640 tiles at 64 rows, 432 at 96: three tiles of 1 or two of 1.5 on the busiest CU -- the same)
+#endif
 #ifndef PD_STRIP_K64
 #define PD_STRIP_K64 true      // the strip GEMMs of the fp16-plane mode: A chunks of 64 k per barrier (pd_gemm_split.h)
 #endif
@@ -1202,12 +1211,30 @@ int pd_denoiser_launch(pd_engine *eng, const float *x, const float *z, int t, in
                 if (N <= 32 && attn_mma) hipLaunchKernelGGL(pd_attn_mma_kernel<2>, dim3(B * NH), dim3(256), attn_mma_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
                 else hipLaunchKernelGGL(pd_attn_seq_kernel<2>, dim3(B * NH), dim3(256), attn_seq_lds(N), s, d->qkv, d->ctx, N, L.ctx_scale);
             }
-            if (strip & 2) pd_gemm_strip<2, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
+            // 512-wide outputs: 96-row tiles where 64-row tiles would give the busiest CUs two tiles and most CUs one (5 120 rows: 320 tiles on 256 CUs ->
+            // 216 tiles of 1.5 x the work: the launch is as long as its busiest CU).  Same sums in the same order: bitwise the same C.
+            const bool rt3 = PD_STRIP_RT3 && (((M + 63) / 64) * (DM / 128)) > cus && (((M + 95) / 96) * (DM / 128)) <= cus;
+#if PD_STRIP_RT1
+            if ((strip & 2) && rt3) pd_gemm_strip<2, 1, true, 1, PD_STRIP_K64>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
+            else
+#endif
+            if ((strip & 2) && rt3) pd_gemm_strip<2, 3, true, 1, PD_STRIP_K64>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
+            else if (strip & 2) pd_gemm_strip<2, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
             else pd_gemm_split<2, 1, 1, true>((const unsigned *)d->ctx, DM, L.out_wh, DM, L.out_b, d->h, M, DM, s, L.out_cs);
             hipLaunchKernelGGL((pd_ln_rows_kernel<DM, 2>), dim3((M + 3) / 4), dim3(256), 0, s, d->h, d->hn, M, 1e-5f, 512.0f);
-            if (strip & 4) pd_gemm_strip<4, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->hn, DM, L.ff1_wh, DM, L.ff1_b, d->ff, M, DFF, s, L.ff1_cs, L.ff_scale);
+#if PD_STRIP_RT1 == 2
+            if ((strip & 4) && rt3) pd_gemm_strip<4, 1, true, 1, PD_STRIP_K64>((const unsigned *)d->hn, DM, L.ff1_wh, DM, L.ff1_b, d->ff, M, DFF, s, L.ff1_cs, L.ff_scale);
+            else
+#endif
+            if ((strip & 4) && PD_STRIP_RT3_FF1 && rt3) pd_gemm_strip<4, 3, true, 1, PD_STRIP_K64>((const unsigned *)d->hn, DM, L.ff1_wh, DM, L.ff1_b, d->ff, M, DFF, s, L.ff1_cs, L.ff_scale);
+            else if (strip & 4) pd_gemm_strip<4, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->hn, DM, L.ff1_wh, DM, L.ff1_b, d->ff, M, DFF, s, L.ff1_cs, L.ff_scale);
             else pd_gemm_split<4, 1, 2, true>((const unsigned *)d->hn, DM, L.ff1_wh, DM, L.ff1_b, d->ff, M, DFF, s, L.ff1_cs, L.ff_scale);
-            if (strip & 8) pd_gemm_strip<2, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->ff, DFF, L.ff2_wh, DFF, L.ff2_b, d->h, M, DM, s, L.ff2_cs);
+#if PD_STRIP_RT1
+            if ((strip & 8) && rt3) pd_gemm_strip<2, 1, true, 1, PD_STRIP_K64>((const unsigned *)d->ff, DFF, L.ff2_wh, DFF, L.ff2_b, d->h, M, DM, s, L.ff2_cs);
+            else
+#endif
+            if ((strip & 8) && rt3) pd_gemm_strip<2, 3, true, 1, PD_STRIP_K64>((const unsigned *)d->ff, DFF, L.ff2_wh, DFF, L.ff2_b, d->h, M, DM, s, L.ff2_cs);
+            else if (strip & 8) pd_gemm_strip<2, 2, true, 1, PD_STRIP_K64>((const unsigned *)d->ff, DFF, L.ff2_wh, DFF, L.ff2_b, d->h, M, DM, s, L.ff2_cs);
             else pd_gemm_split<2, 1, 1, true>((const unsigned *)d->ff, DFF, L.ff2_wh, DFF, L.ff2_b, d->h, M, DM, s, L.ff2_cs);
             continue;
         }

@@ -248,8 +248,9 @@ __global__ __launch_bounds__(256) void vit_gemm_split_kernel(VitSplitArgs g) {
 // the same accumulation order (bitwise the same C).  K must be a multiple of 64.
 template <int EPI, int RT, bool F16, int CT = 1, int BARE = 0, bool K64 = false>
 __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
-    constexpr int KC = 32, TM = 32 * RT, TN = 128 * CT, GROUP = 2048 / TM, CHA = TM * KC;     // words of A per chunk
-    static_assert((RT == 2 || RT == 4) && (CT == 1 || CT == 2), "pieces of 8 rows, RT per wave and chunk");
+    constexpr int KC = 32, TM = 32 * RT, TN = 128 * CT, GROUP = RT == 3 ? 24 : (RT == 1 ? 32 : 2048 / TM), CHA = TM * KC;     // words of A per chunk; GROUP row tiles (a multiple of
+                                                                                                         //   8: a row block's column tiles share an XCD) per block group
+    static_assert(RT >= 1 && RT <= 4 && (CT == 1 || CT == 2), "pieces of 8 rows, RT per wave and chunk");
     extern __shared__ __attribute__((aligned(1024))) unsigned strip_lds[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -360,7 +361,9 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
             block(a, a0, a1, a2, a3);
             PD_STRIP_WLOAD(a0, a1, a2, a3, 2 * cn);              //   ... + the next chunk's first block [4]
             // the second block's weights must have landed; the DMA and the loads just issued may still be in flight (in-order returns)
-            if constexpr (RT == 2) PD_STRIP_WAIT(8, b0, b1, b2, b3);
+            if constexpr (RT == 2) PD_STRIP_WAIT(8, b0, b1, b2, b3);          // (2 RT DMA pieces + 4 weight loads may stay in flight)
+            else if constexpr (RT == 1) PD_STRIP_WAIT(6, b0, b1, b2, b3);
+            else if constexpr (RT == 3) PD_STRIP_WAIT(10, b0, b1, b2, b3);
             else PD_STRIP_WAIT(12, b0, b1, b2, b3);
             block(a + CHA, b0, b1, b2, b3);
             PD_STRIP_WLOAD(b0, b1, b2, b3, 2 * cn + 1);          //   ... + the next chunk's second block [4]
