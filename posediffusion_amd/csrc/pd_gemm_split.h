@@ -60,7 +60,21 @@ struct VitSplitArgs {
     void *C;                    // EPI 0 / 2: fp32 [M][Nout]; EPI 3 (gelu) / 4 (relu): split words [M][Nout]
     int M, Nout, K, lda;
     float c_scale, out_scale;   // F16 only (see the header): accumulator scale, scale of split-word outputs
+#ifdef PD_STRIP_LEGS
+    long long *legs;            // tools/strip_legs_probe.hip only: [workgroup][8] = {wall start, wall end, cycles: entry, operands landed, K loop done, end, XCC id, CU id}
+#endif
 };
+#ifndef PD_STRIP_PIPE
+#define PD_STRIP_PIPE 1
+#endif
+#ifndef PD_STRIP_WIDE_EPI
+#define PD_STRIP_WIDE_EPI 1
+#endif
+#ifdef PD_STRIP_LEGS
+#define PD_LEG(i, v) do { if (g.legs && threadIdx.x == 0) g.legs[(size_t)blockIdx.x * 8 + (i)] = (long long)(v); } while (0)
+#else
+#define PD_LEG(i, v) do { } while (0)
+#endif
 
 // A rows stream through LDS (un-zipped into hi / lo fragments on the way, shared by the waves of a row block); the weight
 // fragments go straight from global memory / L2 to registers, one chunk ahead (they are already in operand order, and
@@ -252,6 +266,8 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
                                                                                                          //   8: a row block's column tiles share an XCD) per block group
     static_assert(RT >= 1 && RT <= 4 && (CT == 1 || CT == 2), "pieces of 8 rows, RT per wave and chunk");
     extern __shared__ __attribute__((aligned(1024))) unsigned strip_lds[];
+    PD_LEG(0, wall_clock64());
+    PD_LEG(2, __builtin_amdgcn_s_memtime());
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int MT = (g.M + TM - 1) / TM, NT = g.Nout / TN;
@@ -346,6 +362,71 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
                 for (int mi = 0; mi < RT; ++mi) acc[mi][0] = mmaw(ah[mi], wh, acc[mi][0]);
             }
         };
+#if PD_STRIP_PIPE
+        // Round 6: the 16-k steps of the K loop, scheduled by hand.  A wave issues in order and an MFMA holds its issue port for the matrix pipe's 32 cycles unless
+        // something else is there to issue: the compiler's schedule -- a step's 24 un-zips and 6 fragment reads in clumps, its 9 MFMAs back to back -- ran
+        // 36 MFMAs + 234 other instructions per 64-k chunk in ~ 2 100 cycles = their SUM (tools/strip_legs_probe.hip: waits + barrier are 5 % of the loop, yet the
+        // matrix pipe was 41 - 55 % busy; neither later operands, nor hidden LDS latency, nor moved DMA issue changed that).  Here every MFMA is preceded by the
+        // few instructions that fit its shadow: the four un-zips of its own A fragment, or (second product) four un-zips + the NEXT step's two fragment reads of
+        // that row tile, or (third product) one LDS-DMA piece of the next chunk; sched_barrier(0) pins the order.  Raw fragments double-buffered in registers, read
+        // one step ahead and waited for (lgkmcnt(0)) a step later.  The same un-zips and MFMAs per accumulator in the same order as `block`: bitwise the same C.
+        wv4 raw[2][RT][2];
+        const int swz = (l31 >> 1) & 7;
+        auto read_mi = [&](int rb, const unsigned *a, int st, int mi) {
+            const unsigned p_ = (unsigned)(size_t)(a + mi * 32 * KC + 4 * ((4 * st + 2 * hi) ^ swz));
+            const unsigned q_ = (unsigned)(size_t)(a + mi * 32 * KC + 4 * ((4 * st + 2 * hi + 1) ^ swz));
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(raw[rb][mi][0]), "=&v"(raw[rb][mi][1]) : "v"(p_), "v"(q_) : "memory");
+        };
+        auto wait_reads = [&](int rb) {
+#pragma unroll
+            for (int mi = 0; mi < RT; ++mi) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[rb][mi][0]), "+v"(raw[rb][mi][1]) : : "memory");
+        };
+        // piece p (0 .. 2 RT - 1) of chunk dma_cn's rows -> buffer dma_nb (the vector-memory issue ORDER of the loop is unchanged -- all 2 RT pieces before the
+        // first block's weight loads --, so the hand-counted vmcnt waits stand)
+        int dma_cn = 0, dma_nb = 0;
+        auto dma_piece_at = [&](int p) {
+            const unsigned da = __builtin_amdgcn_readfirstlane(lds_a + dma_nb * 2 * CHA * 4);
+            const int h = p / RT, j = p % RT;
+            pd_dma_piece((const float *)(g.A + (2 * dma_cn + h) * KC), oa[j], da + h * CHA * 4 + j * 1024);
+        };
+        auto step = [&](int rb, const wv4 &wh, const wv4 &wl, bool has_next, int nrb, const unsigned *na, int nst, int dma_step) {
+            uint4 ah[RT], al[RT];
+#pragma unroll
+            for (int mi = 0; mi < RT; ++mi) {
+                const wv4 p = raw[rb][mi][0], q = raw[rb][mi][1];
+#ifdef PD_STRIP_NOPERM      // (probe only: what the loop costs WITHOUT the un-zip -- wrong products, right instruction count otherwise)
+                al[mi] = make_uint4(q.x, q.y, q.z, q.w);
+#else
+                al[mi] = make_uint4(__builtin_amdgcn_perm(p.y, p.x, 0x07060302u), __builtin_amdgcn_perm(p.w, p.z, 0x07060302u),
+                                    __builtin_amdgcn_perm(q.y, q.x, 0x07060302u), __builtin_amdgcn_perm(q.w, q.z, 0x07060302u));
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                acc[mi][0] = mmaw(al[mi], wh, acc[mi][0]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int mi = 0; mi < RT; ++mi) {
+                const wv4 p = raw[rb][mi][0], q = raw[rb][mi][1];
+#ifdef PD_STRIP_NOPERM
+                ah[mi] = make_uint4(p.x, p.y, p.z, p.w);
+#else
+                ah[mi] = make_uint4(__builtin_amdgcn_perm(p.y, p.x, 0x05040100u), __builtin_amdgcn_perm(p.w, p.z, 0x05040100u),
+                                    __builtin_amdgcn_perm(q.y, q.x, 0x05040100u), __builtin_amdgcn_perm(q.w, q.z, 0x05040100u));
+#endif
+                if (has_next) read_mi(nrb, na, nst, mi);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[mi][0] = mmaw(ah[mi], wl, acc[mi][0]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int mi = 0; mi < RT; ++mi) {
+                if (dma_step >= 0) dma_piece_at(dma_step * RT + mi);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[mi][0] = mmaw(ah[mi], wh, acc[mi][0]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+#endif
         wv4 a0, a1, a2, a3, b0, b1, b2, b3;               // weight fragments of the chunk's first / second 32-k block
         const int nk64 = g.K / 64;
         stage64(0, 0);
@@ -354,23 +435,76 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
         PD_STRIP_WAIT(0, a0, a1, a2, a3);
         PD_STRIP_WAIT(0, b0, b1, b2, b3);
         __syncthreads();
+        PD_LEG(3, __builtin_amdgcn_s_memtime());
+#ifdef PD_STRIP_LEGS
+        long long leg_t0 = 0, leg_wb = 0, leg_wa = 0, leg_bar = 0, leg_s0 = 0, leg_s1 = 0, leg_s2 = 0, leg_s3 = 0;
+#define PD_LEG_T0() leg_t0 = __builtin_amdgcn_s_memtime()
+#define PD_LEG_ACC(v) v += __builtin_amdgcn_s_memtime() - leg_t0
+#else
+#define PD_LEG_T0() do { } while (0)
+#define PD_LEG_ACC(v) do { } while (0)
+#endif
+        // (round 6, measured and dropped: the A rows TWO chunks ahead through three LDS buffers -- the K loop's cycles did not move, 17.0 k -> 18.0 k per
+        //  workgroup of the out-projection: what keeps the matrix pipe at 41 - 55 % is one wave per SIMD issuing its LDS reads, un-zips and waits between its
+        //  own MFMAs, not late operands; profiles/round6_strip_legs.txt)
         for (int c = 0; c < nk64; ++c) {
             const int cn = min(c + 1, nk64 - 1);                 // the chunk after the last is the last again (never used)
             const unsigned *a = strip_lds + (c & 1) * 2 * CHA + l31 * KC;
+#if PD_STRIP_PIPE
+            dma_cn = cn;                                         // in flight, oldest first: the second block's weights [4, from the previous turn], this DMA [2 RT]
+            dma_nb = (c + 1) & 1;                                //   (its pieces are issued inside the first block's MFMA groups, below)
+#pragma unroll
+            for (int mi = 0; mi < RT; ++mi) read_mi(0, a, 0, mi);                // (the one exposed read per chunk: its rows were published by the barrier just passed)
+            wait_reads(0);
+            PD_LEG_T0();
+            step(0, a0, a1, true, 1, a, 1, 0);
+            PD_LEG_ACC(leg_s0);
+            wait_reads(1);
+            PD_LEG_T0();
+            step(1, a2, a3, true, 0, a + CHA, 0, 1);
+            PD_LEG_ACC(leg_s1);
+#else
             stage64(cn, (c + 1) & 1);                            // in flight, oldest first: the second block's weights [4, from the previous turn], this DMA [2 RT]
             block(a, a0, a1, a2, a3);
+#endif
             PD_STRIP_WLOAD(a0, a1, a2, a3, 2 * cn);              //   ... + the next chunk's first block [4]
             // the second block's weights must have landed; the DMA and the loads just issued may still be in flight (in-order returns)
+            PD_LEG_T0();
             if constexpr (RT == 2) PD_STRIP_WAIT(8, b0, b1, b2, b3);          // (2 RT DMA pieces + 4 weight loads may stay in flight)
             else if constexpr (RT == 1) PD_STRIP_WAIT(6, b0, b1, b2, b3);
             else if constexpr (RT == 3) PD_STRIP_WAIT(10, b0, b1, b2, b3);
             else PD_STRIP_WAIT(12, b0, b1, b2, b3);
+            PD_LEG_ACC(leg_wb);
+#if PD_STRIP_PIPE
+            wait_reads(0);
+            PD_LEG_T0();
+            step(0, b0, b1, true, 1, a + CHA, 1, -1);
+            PD_LEG_ACC(leg_s2);
+            wait_reads(1);
+            PD_LEG_T0();
+            step(1, b2, b3, false, 0, a, 0, -1);
+            PD_LEG_ACC(leg_s3);
+#else
             block(a + CHA, b0, b1, b2, b3);
+#endif
             PD_STRIP_WLOAD(b0, b1, b2, b3, 2 * cn + 1);          //   ... + the next chunk's second block [4]
+            PD_LEG_T0();
             PD_STRIP_WAIT(4, a0, a1, a2, a3);                    // the next chunk's rows and first block have landed; the second block may still fly
+            PD_LEG_ACC(leg_wa);
+            PD_LEG_T0();
             __syncthreads();
+            PD_LEG_ACC(leg_bar);
         }
         PD_STRIP_WAIT(0, b0, b1, b2, b3);
+        PD_LEG(4, __builtin_amdgcn_s_memtime());
+#ifdef PD_STRIP_LEGS
+        PD_LEG(6, (leg_wb << 32) | (leg_wa & 0xffffffffll));
+        PD_LEG(7, leg_bar);
+#ifdef PD_STRIP_STEP_CLOCKS
+        PD_LEG(0, (leg_s0 << 32) | (leg_s1 & 0xffffffffll));       // (overwrites the wall-clock stamps: the step-timing build of the probe does not print the timeline)
+        PD_LEG(1, (leg_s2 << 32) | (leg_s3 & 0xffffffffll));
+#endif
+#endif
 #undef PD_STRIP_WLOAD
 #undef PD_STRIP_WAIT
     } else {
@@ -448,6 +582,52 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
         }
     }
     }
+#if PD_STRIP_WIDE_EPI
+    if constexpr (BARE == 0 && K64) {              // (the 64-k form's staging LDS holds the four waves' patches: 18 KB <= 32 KB at RT = 2)
+        // Epilogue with 16-byte accesses (round 6; tools/strip_legs_probe.hip: the 4-byte form -- 16 loads + 16 stores per row tile and wave, each covering two
+        // 128-byte row segments -- was 27 - 33 % of a workgroup's time, store-issue bound).  Every wave turns its 32 x 32 accumulator tile through a private 32 x 36
+        // float patch of the (now idle) staging LDS: written column-per-lane as the MFMA leaves it, read back as four consecutive columns of one row per lane, so
+        // that residual loads and stores are dwordx4 (four per row tile instead of sixteen).  Per element the arithmetic is the old epilogue's: the same bits.
+        __syncthreads();                               // every wave's last (unused) re-stage has landed: the staging buffers are free
+        float *patch = (float *)strip_lds + wave * (32 * 36);
+        const int pr = lane >> 3, pc = (lane & 7) * 4;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int colb = n0 + (CT * wave + c) * 32 + pc;
+            const float4 bias4 = *(const float4 *)(g.bias + colb);
+#pragma unroll
+            for (int mi = 0; mi < RT; ++mi) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) patch[((i & 3) + 8 * (i >> 2) + 4 * hi) * 36 + l31] = acc[mi][c][i];
+                float4 res4[4];
+                if constexpr (EPI == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        res4[q] = *(const float4 *)((const float *)g.C + (size_t)min(m0 + mi * 32 + 8 * q + pr, g.M - 1) * g.Nout + colb);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = m0 + mi * 32 + 8 * q + pr;
+                    const float4 a4 = *(const float4 *)(patch + (8 * q + pr) * 36 + pc);
+                    float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                    const float b4[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+                    const float r4[4] = {EPI == 2 ? res4[q].x : 0.0f, EPI == 2 ? res4[q].y : 0.0f, EPI == 2 ? res4[q].z : 0.0f, EPI == 2 ? res4[q].w : 0.0f};
+                    unsigned o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = F16 ? fmaf(v[e], g.c_scale, b4[e]) : v[e] + b4[e];
+                        if constexpr (EPI == 3) t = F16 ? 0.5f * t * (1.0f + erff(t * 0.70710678118654752f)) : vit_gelu_fast(t);   // fp16 planes: nn.GELU()'s exact form
+                        if constexpr (EPI == 4) t = pd_relu(t);
+                        if constexpr (EPI == 2) t += r4[e];
+                        if constexpr (EPI == 3 || EPI == 4) o[e] = pd_split_word_as<F16 ? 2 : 1>(t, g.out_scale);
+                        else o[e] = __float_as_uint(t);
+                    }
+                    if (row < g.M) *(uint4 *)((unsigned *)g.C + (size_t)row * g.Nout + colb) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    } else
+#endif
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int col = n0 + (CT * wave + c) * 32 + l31;
@@ -476,14 +656,24 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
             }
         }
     }
+#ifdef PD_STRIP_LEGS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have left
+    PD_LEG(5, __builtin_amdgcn_s_memtime());
+#ifndef PD_STRIP_STEP_CLOCKS
+    PD_LEG(1, wall_clock64());
+#endif
+#endif
 }
+// dynamic LDS of a launch: two 32-k buffers, or (64-k form) two buffers of two 32-k blocks
+template <int RT, bool K64>
+static constexpr size_t pd_gemm_strip_lds() { return (size_t)(K64 ? 4 : 2) * 32 * RT * 32 * sizeof(unsigned); }
 template <int EPI, int RT, bool F16, int CT = 1, bool K64 = false>
 static inline void pd_gemm_strip(const unsigned *A, int lda, const unsigned *W, int K, const float *bias, void *C, int M, int Nout, hipStream_t s,
                                  float c_scale = 1.0f, float out_scale = 1.0f) {
     VitSplitArgs g{A, W, bias, C, M, Nout, K, lda, c_scale, out_scale};
     constexpr int TM = 32 * RT;
     hipLaunchKernelGGL((pd_gemm_strip_kernel<EPI, RT, F16, CT, 0, K64>), dim3(((M + TM - 1) / TM) * (Nout / (128 * CT))), dim3(256),
-                       (size_t)(K64 ? 4 : 2) * TM * 32 * sizeof(unsigned), s, g);
+                       (pd_gemm_strip_lds<RT, K64>()), s, g);
 }
 
 static constexpr size_t pd_split_lds(int WM) { return (size_t)2 * 64 * WM * PD_STREAM_LR * sizeof(float); }

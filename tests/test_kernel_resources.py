@@ -66,9 +66,12 @@ def test_denoiser_kernels_keep_their_register_budget(tmp_path):
         if m and cur is not None:
             cur[m.group(1).split("[")[0].strip()] = int(m.group(2))
     strip = {k: v for k, v in kernels.items() if "pd_gemm_strip_kernel" in k}
-    assert len(strip) == 3, sorted(kernels)                     # EPI 0 / 2 / 4 at two row tiles, fp16 planes
+    # EPI 0 / 2 / 4 at 64-row tiles (4 waves per SIMD: several workgroups share a CU there) + (round 6) EPI 2 / 4 at 96-row tiles (one workgroup per
+    # CU by construction: 48 accumulator registers more, 3 waves per SIMD suffice); fp16 planes; nothing spilled
+    assert len(strip) == 5, sorted(kernels)
     for name, r in strip.items():
-        assert r["Occupancy"] >= 4 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
+        rt3 = "ELi3ELb1E" in name
+        assert r["Occupancy"] >= (3 if rt3 else 4) and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
     dma = {k: v for k, v in kernels.items() if "pd_gemm_dma_kernel" in k}
     assert len(dma) == 5, sorted(kernels)                       # EPI 0, 0 + LN, 1 + LN, 2, and (round 5) 4: _first's step piece + the hoisted z piece
     for name, r in dma.items():

@@ -1,0 +1,6 @@
+#!/bin/bash
+# round 6, call 11: the strip kernels' epilogue with 16-byte accesses (accumulator tile turned through LDS) against the 4-byte form (narrowepi): legs, step alone + bitwise check, tests
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
+tools/strip_legs_probe > gpurun_out/r6_strip_legs_wide.txt 2>&1; head -12 gpurun_out/r6_strip_legs_wide.txt | cut -c1-400
+timeout 900 python tools/den_large_ab.py gpurun_ab/libpd_narrowepi.so posediffusion_amd/lib/libpd_engine.so 2>&1 | grep -v "Warning\|TransformerEncoder\|amdgpu.ids\|FUSED_ATTN" > gpurun_out/r6_den_wide_epi.txt; cat gpurun_out/r6_den_wide_epi.txt
+timeout 900 python -m pytest tests -m gpu -q -k "bench_launch_shapes or fused_qkv or fp16_plane or first_layer or vit or adversarial or denoiser" 2>&1 | tail -4
