@@ -401,6 +401,10 @@ int pd_debug_ggs_prof(pd_engine *eng, int enable, long long *out6);   /* enable 
  * out8 = {workgroups per sequence, item slots per workgroup, LDS bytes, two-hop kernel, waves per workgroup, LDS-DMA staging pieces,
  * lane-per-item kernel, its LDS-resident steps}.  Lets a test pin which kernel the engine picks by itself. */
 int pd_debug_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, int *out8);
+/* The lane-per-item tables of match slot `seq` as the device holds them (host- or device-built): out[0..3] = {lane items, waves, base item length in
+ * matches, steps of the longest wave}, out[4 + w] = steps of wave w (two matches per lane and step).  Synchronises the device.  tests/ compare it with
+ * bench_legs.lane_stream_fraction, the Python mirror of the cut rule that bench.py reports streamed bytes from. */
+int pd_debug_lane_tables(pd_engine *eng, int seq, int *out, int n_out);
 /* Does v_mfma_f32_32x32x16_f16 keep fp16-SUBNORMAL operands (the `lo` halves of small elements in the fp16-plane denoiser mode are
  * subnormal)?  One 32x32x16 product per case, every element of A = a, of B = b: out4 = {C[0][0] for (a, b) = (2^-20, 2^10): 2^-6 if kept;
  * (2^10, 2^-20): 2^-6; (2^-20, 2^-4): 2^-20 (a subnormal times a normal, result far below fp16's range: fp32 accumulation);

@@ -106,6 +106,7 @@ SIGNATURES = {
     "pd_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _vp, _vp, _vp, _i, _vp]),
     "pd_sample_phase": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(pd_ggs_cfg), _i, _vp, _vp, _vp, _i, _vp]),
     "pd_pose_to_camera": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "pd_debug_lane_tables": (_i, [_vp, _i, C.POINTER(C.c_int), _i]),
     "pd_ggs_launch_stamps": (_i, [_vp, _vp, _i, C.POINTER(C.c_int), _vp]),
     "pd_ggs_stage_iters": (_i, [C.POINTER(pd_ggs_cfg), C.POINTER(C.c_int)]),
     "pd_pose_to_camera_ex": (_i, [_vp, _vp, _i, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _vp]),

@@ -592,6 +592,29 @@ extern "C" int pd_ggs_launch_stamps(pd_engine *eng, long long *dst, int n, int *
     return PD_OK;
 }
 
+extern "C" int pd_debug_lane_tables(pd_engine *eng, int seq, int *out, int n_out) {
+    if (!eng || !out || seq < 0 || seq >= eng->max_B || n_out < 4) {
+        pd_set_error("pd_debug_lane_tables: invalid arguments (seq=%d n_out=%d)", seq, n_out);
+        return PD_ERR_INVALID_ARG;
+    }
+    // the DEVICE descriptor (for slots filled by pd_ggs_set_matches_csr_async the host shadow holds capacities, not counts); synchronous
+    PD_HIP_CHECK(hipDeviceSynchronize());
+    PdSeqDesc D;
+    PD_HIP_CHECK(hipMemcpy(&D, eng->d_seqs + seq, sizeof(D), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n_out; ++i) out[i] = 0;
+    out[0] = D.n_litems;
+    out[1] = D.n_lwaves;
+    out[2] = D.l_item_len;
+    out[3] = D.l_max_steps;
+    if (D.n_lwaves > 0 && D.lwave) {
+        int2 lw[PD_LANE_WAVES];
+        const int nw = D.n_lwaves < PD_LANE_WAVES ? D.n_lwaves : PD_LANE_WAVES;
+        PD_HIP_CHECK(hipMemcpy(lw, D.lwave, sizeof(int2) * nw, hipMemcpyDeviceToHost));
+        for (int w = 0; w < nw && 4 + w < n_out; ++w) out[4 + w] = lw[w].y;
+    }
+    return PD_OK;
+}
+
 extern "C" int pd_debug_ggs_plan(pd_engine *eng, int B, int N, const pd_ggs_cfg *cfg, int *out8) {
     if (!eng || !cfg || !out8) return PD_ERR_INVALID_ARG;
     PdGgsPlan plan;

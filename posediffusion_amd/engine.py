@@ -291,6 +291,12 @@ class PoseEngine:
                                                  self._stream()), "pd_pose_to_camera_ex")
         return R, T, F
 
+    def lane_tables(self, seq: int = 0):
+        """(lane items, waves, base item length, [steps per wave]) of match slot ``seq`` as the device holds them (pd_debug_lane_tables)."""
+        buf = (C.c_int * 20)()
+        _lib.check(self.lib.pd_debug_lane_tables(self._h, int(seq), buf, 20), "pd_debug_lane_tables")
+        return int(buf[0]), int(buf[1]), int(buf[2]), [int(buf[4 + w]) for w in range(int(buf[1]))]
+
     def ggs_launch_stamps(self, n: int, out: Optional[torch.Tensor] = None):
         """(int64 tensor [n, 2] on the device, ticks per millisecond): {start, end} of the GGS launches of guided steps 0 .. n-1 of the last
         sampling pass, recorded by the kernel itself (pd_ggs_launch_stamps); copied on the current stream behind the pass.  ``out``: a
