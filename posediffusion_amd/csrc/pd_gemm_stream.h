@@ -275,6 +275,9 @@ __global__ __launch_bounds__(256) void pd_gemm_stream_kernel(PdStreamArgs g) {
 // fragment reads (32 rows x one k-chunk per half wave) conflict free.  LayerNorm (ALN) moves from the staging stores to the fragment
 // reads: (a - mean) * rstd with the statistics of the lane's own row, the same two roundings.  Same MFMA chain as the register-staged
 // kernel: bitwise the same C.
+#ifndef PD_DMA_WIDE_EPI
+#define PD_DMA_WIDE_EPI 1
+#endif
 // one 1 KiB piece: 64 lanes x 16 B from `base` + the lane's byte offset to the wave-uniform LDS byte address `dst`
 __device__ __forceinline__ void pd_dma_piece(const float *base, unsigned off, unsigned dst) {
     unsigned keep;
@@ -385,6 +388,46 @@ __global__ __launch_bounds__(256) void pd_gemm_dma_kernel(PdStreamArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk has landed in the other buffer
         __syncthreads();
     }
+#if PD_DMA_WIDE_EPI
+    {
+        // Epilogue with 16-byte accesses (round 6, as in pd_gemm_strip_kernel): every wave turns its 32 x 32 accumulator tiles through a private 32 x 36 float patch of
+        // the idle staging LDS so that a lane holds four consecutive columns of a row: residual loads and stores are dwordx4.  The same arithmetic per element.
+        __syncthreads();                               // the last (unused) re-stage has landed in every wave: the staging buffers are free
+        float *patch = lds + wave * (32 * 36);
+        const int pr = lane >> 3, pc = (lane & 7) * 4;
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) {
+                const int colb = n0 + (wn * WN + ni) * 32 + pc, rb = m0 + (wm * WM + mi) * 32;
+                const float4 bias4 = *(const float4 *)(g.bias + colb);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) patch[((i & 3) + 8 * (i >> 2) + 4 * hi) * 36 + l31] = acc[mi][ni][i];
+                float4 res4[4];
+                if constexpr (EPI == 2 || EPI == 4) {
+                    const float *rsrc = EPI == 2 ? g.C : g.R;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) res4[q] = *(const float4 *)(rsrc + (size_t)min(rb + 8 * q + pr, g.M - 1) * g.Nout + colb);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = rb + 8 * q + pr;
+                    const float4 a4 = *(const float4 *)(patch + (8 * q + pr) * 36 + pc);
+                    float v[4] = {a4.x + bias4.x, a4.y + bias4.y, a4.z + bias4.z, a4.w + bias4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (EPI == 1) v[e] = pd_relu(v[e]);
+                        if constexpr (EPI == 3) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+                    }
+                    if constexpr (EPI == 2 || EPI == 4) {
+                        v[0] += res4[q].x; v[1] += res4[q].y; v[2] += res4[q].z; v[3] += res4[q].w;
+                    }
+                    if (row < g.M) *(float4 *)(g.C + (size_t)row * g.Nout + colb) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        return;
+    }
+#endif
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
