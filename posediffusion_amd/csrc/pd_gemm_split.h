@@ -67,6 +67,9 @@ struct VitSplitArgs {
 #ifndef PD_STRIP_PIPE
 #define PD_STRIP_PIPE 1
 #endif
+#ifndef PD_STRIP_RES_AHEAD
+#define PD_STRIP_RES_AHEAD 1   // the residual tile of an EPI 2 product requested during the last K chunk (needs the wide epilogue and the 64-k form)
+#endif
 #ifndef PD_STRIP_WIDE_EPI
 #define PD_STRIP_WIDE_EPI 1
 #endif
@@ -308,6 +311,8 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
         else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     };
     f32x16 acc[RT][CT];
+    typedef unsigned res_v4 __attribute__((ext_vector_type(4)));
+    res_v4 resid[(EPI == 2 && K64) ? RT : 1][4];      // (PD_STRIP_RES_AHEAD, below)
     if constexpr (K64) {
         static_assert(CT == 1 && BARE == 0, "the 64-k form exists for one column tile per wave");
         typedef unsigned wv4 __attribute__((ext_vector_type(4)));          // a weight fragment as a native vector (an inline-asm register operand)
@@ -330,6 +335,7 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
                      : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(wp_) : "memory");                                            \
     } while (0)
 #define PD_STRIP_WAIT(n, w0, w1, w2, w3) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : : "memory")
+#define PD_STRIP_WAITN(n, w0, w1, w2, w3) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "n"(n) : "memory")
         auto stage64 = [&](int c, int buf) {            // both 32-k blocks of chunk c: 2 RT pieces per wave
             const unsigned da = __builtin_amdgcn_readfirstlane(lds_a + buf * 2 * CHA * 4);
 #pragma unroll
@@ -429,6 +435,20 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
 #endif
         wv4 a0, a1, a2, a3, b0, b1, b2, b3;               // weight fragments of the chunk's first / second 32-k block
         const int nk64 = g.K / 64;
+        // Round 6: the residual tile (EPI 2: C += ...) requested at the end of the chunk BEFORE the last, in the wide epilogue's own 16-byte pattern, instead of one
+        // row tile at a time inside the epilogue (in-place C: the compiler cannot lift a row tile's loads over the previous tile's stores, so every row tile exposed
+        // a whole global-load latency: ~ 1.9 k cycles each).  Hand-issued, counted by the loop's waits (`chunk`, below), 4 RT registers of 16 bytes.  The same values
+        // into the same adds: bitwise the same C.
+        auto resid_load = [&]() {
+            const int pr_ = lane >> 3, colb_ = n0 + wave * 32 + (lane & 7) * 4;
+#pragma unroll
+            for (int mi = 0; mi < RT; ++mi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float *rp_ = (const float *)g.C + (size_t)min(m0 + mi * 32 + 8 * q + pr_, g.M - 1) * g.Nout + colb_;
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(resid[mi][q]) : "v"(rp_) : "memory");
+                }
+        };
         stage64(0, 0);
         PD_STRIP_WLOAD(a0, a1, a2, a3, 0);
         PD_STRIP_WLOAD(b0, b1, b2, b3, 1);
@@ -447,8 +467,14 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
         // (round 6, measured and dropped: the A rows TWO chunks ahead through three LDS buffers -- the K loop's cycles did not move, 17.0 k -> 18.0 k per
         //  workgroup of the out-projection: what keeps the matrix pipe at 41 - 55 % is one wave per SIMD issuing its LDS reads, un-zips and waits between its
         //  own MFMAs, not late operands; profiles/round6_strip_legs.txt)
-        for (int c = 0; c < nk64; ++c) {
-            const int cn = min(c + 1, nk64 - 1);                 // the chunk after the last is the last again (never used)
+        // One 64-k chunk.  MODE 0: a chunk with a successor -- the successor's rows and weights are requested while this one is multiplied.  MODE 1: the one before the
+        // last -- as 0, and (EPI 2) the residual tile is requested behind everything else, so that a whole chunk of matrix work hides it: returns are in order, the
+        // end-of-chunk wait lets it fly (+ RESN) and so does the last chunk's first wait; the last chunk's end collects it.  MODE 2: the last chunk requests nothing
+        // (round 6; until then it re-staged itself "for nothing": one chunk in nk64 of useless L2 traffic) and leaves the closing barrier to the epilogue.
+        constexpr int RESN = (PD_STRIP_RES_AHEAD && EPI == 2) ? 4 * RT : 0;
+        auto chunk = [&](int c, auto mode_) {
+            constexpr int MODE = decltype(mode_)::value;
+            const int cn = c + 1;
             const unsigned *a = strip_lds + (c & 1) * 2 * CHA + l31 * KC;
 #if PD_STRIP_PIPE
             dma_cn = cn;                                         // in flight, oldest first: the second block's weights [4, from the previous turn], this DMA [2 RT]
@@ -457,23 +483,20 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
             for (int mi = 0; mi < RT; ++mi) read_mi(0, a, 0, mi);                // (the one exposed read per chunk: its rows were published by the barrier just passed)
             wait_reads(0);
             PD_LEG_T0();
-            step(0, a0, a1, true, 1, a, 1, 0);
+            step(0, a0, a1, true, 1, a, 1, MODE == 2 ? -1 : 0);
             PD_LEG_ACC(leg_s0);
             wait_reads(1);
             PD_LEG_T0();
-            step(1, a2, a3, true, 0, a + CHA, 0, 1);
+            step(1, a2, a3, true, 0, a + CHA, 0, MODE == 2 ? -1 : 1);
             PD_LEG_ACC(leg_s1);
 #else
-            stage64(cn, (c + 1) & 1);                            // in flight, oldest first: the second block's weights [4, from the previous turn], this DMA [2 RT]
+            if constexpr (MODE != 2) stage64(cn, (c + 1) & 1);   // in flight, oldest first: the second block's weights [4, from the previous turn], this DMA [2 RT]
             block(a, a0, a1, a2, a3);
 #endif
-            PD_STRIP_WLOAD(a0, a1, a2, a3, 2 * cn);              //   ... + the next chunk's first block [4]
+            if constexpr (MODE != 2) PD_STRIP_WLOAD(a0, a1, a2, a3, 2 * cn);     //   ... + the next chunk's first block [4]
             // the second block's weights must have landed; the DMA and the loads just issued may still be in flight (in-order returns)
             PD_LEG_T0();
-            if constexpr (RT == 2) PD_STRIP_WAIT(8, b0, b1, b2, b3);          // (2 RT DMA pieces + 4 weight loads may stay in flight)
-            else if constexpr (RT == 1) PD_STRIP_WAIT(6, b0, b1, b2, b3);
-            else if constexpr (RT == 3) PD_STRIP_WAIT(10, b0, b1, b2, b3);
-            else PD_STRIP_WAIT(12, b0, b1, b2, b3);
+            PD_STRIP_WAITN((MODE == 2 ? RESN : 2 * RT + 4), b0, b1, b2, b3);     // (2 RT DMA pieces + 4 weight loads may stay in flight; last chunk: the residual tile)
             PD_LEG_ACC(leg_wb);
 #if PD_STRIP_PIPE
             wait_reads(0);
@@ -487,15 +510,33 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
 #else
             block(a + CHA, b0, b1, b2, b3);
 #endif
-            PD_STRIP_WLOAD(b0, b1, b2, b3, 2 * cn + 1);          //   ... + the next chunk's second block [4]
-            PD_LEG_T0();
-            PD_STRIP_WAIT(4, a0, a1, a2, a3);                    // the next chunk's rows and first block have landed; the second block may still fly
-            PD_LEG_ACC(leg_wa);
-            PD_LEG_T0();
-            __syncthreads();
-            PD_LEG_ACC(leg_bar);
+            if constexpr (MODE != 2) {
+                PD_STRIP_WLOAD(b0, b1, b2, b3, 2 * cn + 1);      //   ... + the next chunk's second block [4]
+                if constexpr (MODE == 1 && RESN > 0) resid_load();
+                PD_LEG_T0();
+                PD_STRIP_WAITN((MODE == 1 ? 4 + RESN : 4), a0, a1, a2, a3);      // the next chunk's rows and first block have landed; the second block (and the residual tile) may still fly
+                PD_LEG_ACC(leg_wa);
+                PD_LEG_T0();
+                __syncthreads();
+                PD_LEG_ACC(leg_bar);
+            }
+        };
+        if constexpr (RESN > 0) {
+            if (nk64 < 2) {                                      // (a single chunk: nothing to hide behind)
+                resid_load();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
+        for (int c = 0; c < nk64 - 2; ++c) chunk(c, std::integral_constant<int, 0>());
+        if (nk64 >= 2) chunk(nk64 - 2, std::integral_constant<int, 1>());
+        chunk(nk64 - 1, std::integral_constant<int, 2>());
         PD_STRIP_WAIT(0, b0, b1, b2, b3);
+#if PD_STRIP_RES_AHEAD
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int mi = 0; mi < RT; ++mi) asm volatile("" : "+v"(resid[mi][0]), "+v"(resid[mi][1]), "+v"(resid[mi][2]), "+v"(resid[mi][3]));     // (landed: vmcnt(0) above)
+        }
+#endif
         PD_LEG(4, __builtin_amdgcn_s_memtime());
 #ifdef PD_STRIP_LEGS
         PD_LEG(6, (leg_wb << 32) | (leg_wa & 0xffffffffll));
@@ -507,6 +548,7 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
 #endif
 #undef PD_STRIP_WLOAD
 #undef PD_STRIP_WAIT
+#undef PD_STRIP_WAITN
     } else {
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -588,7 +630,7 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
         // 128-byte row segments -- was 27 - 33 % of a workgroup's time, store-issue bound).  Every wave turns its 32 x 32 accumulator tile through a private 32 x 36
         // float patch of the (now idle) staging LDS: written column-per-lane as the MFMA leaves it, read back as four consecutive columns of one row per lane, so
         // that residual loads and stores are dwordx4 (four per row tile instead of sixteen).  Per element the arithmetic is the old epilogue's: the same bits.
-        __syncthreads();                               // every wave's last (unused) re-stage has landed: the staging buffers are free
+        __syncthreads();                               // every wave is past its last fragment read (the last chunk ends without a barrier): the staging buffers are free
         float *patch = (float *)strip_lds + wave * (32 * 36);
         const int pr = lane >> 3, pc = (lane & 7) * 4;
 #pragma unroll
@@ -602,8 +644,13 @@ __global__ __launch_bounds__(256) void pd_gemm_strip_kernel(VitSplitArgs g) {
                 float4 res4[4];
                 if constexpr (EPI == 2) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < 4; ++q) {
+#if PD_STRIP_RES_AHEAD
+                        res4[q] = __builtin_bit_cast(float4, resid[mi][q]);
+#else
                         res4[q] = *(const float4 *)((const float *)g.C + (size_t)min(m0 + mi * 32 + 8 * q + pr, g.M - 1) * g.Nout + colb);
+#endif
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {

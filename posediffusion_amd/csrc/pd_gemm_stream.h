@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void pd_gemm_dma_kernel(PdStreamArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
-        stage(min(kc + 1, nk - 1), (kc + 1) & 1);       // (the chunk after the last is the last again: the loop body stays straight-line)
+        if (kc + 1 < nk) stage(kc + 1, (kc + 1) & 1);   // (round 6: the last chunk requests nothing; it used to re-stage itself to keep the loop body straight-line)
         const float *a = As + (kc & 1) * CHA + arow * KC, *b = Ws + (kc & 1) * CHW + brow * KC;
 #pragma unroll
         for (int kk = 0; kk < KC / 8; ++kk) {
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void pd_gemm_dma_kernel(PdStreamArgs g) {
     {
         // Epilogue with 16-byte accesses (round 6, as in pd_gemm_strip_kernel): every wave turns its 32 x 32 accumulator tiles through a private 32 x 36 float patch of
         // the idle staging LDS so that a lane holds four consecutive columns of a row: residual loads and stores are dwordx4.  The same arithmetic per element.
-        __syncthreads();                               // the last (unused) re-stage has landed in every wave: the staging buffers are free
+        __syncthreads();                               // (kept: cheap, and the staging buffers are free for certain)
         float *patch = lds + wave * (32 * 36);
         const int pr = lane >> 3, pc = (lane & 7) * 4;
 #pragma unroll

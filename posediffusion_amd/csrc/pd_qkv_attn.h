@@ -160,13 +160,19 @@ __global__ __launch_bounds__(PD_QA_THREADS) void pd_qkv_attn_kernel(PdQkvAttnArg
             const int cn = min(c + 1, nk64 - 1);                 // the chunk after the last is the last again (never used)
             const unsigned *a = qa_lds + (c & 1) * 2 * CHA + l31 * KC;
             if constexpr (BARE == 0) {
-                stage64(cn, (c + 1) & 1);                        // in flight, oldest first: the second block's weights [4, from the previous turn], this DMA [2]
-                block(a, a0, a1, a2, a3);
-                PD_QA_WLOAD(a0, a1, a2, a3, 2 * cn);             //   ... + the next chunk's first block [4]
-                PD_QA_WAIT(6, b0, b1, b2, b3);                   // the second block's weights have landed; the DMA [2] and the loads just issued [4] may fly
-                block(a + CHA, b0, b1, b2, b3);
-                PD_QA_WLOAD(b0, b1, b2, b3, 2 * cn + 1);         //   ... + the next chunk's second block [4]
-                PD_QA_WAIT(4, a0, a1, a2, a3);                   // the next chunk's rows and first block have landed; the second block may still fly
+                if (c + 1 < nk64) {
+                    stage64(cn, (c + 1) & 1);                    // in flight, oldest first: the second block's weights [4, from the previous turn], this DMA [2]
+                    block(a, a0, a1, a2, a3);
+                    PD_QA_WLOAD(a0, a1, a2, a3, 2 * cn);         //   ... + the next chunk's first block [4]
+                    PD_QA_WAIT(6, b0, b1, b2, b3);               // the second block's weights have landed; the DMA [2] and the loads just issued [4] may fly
+                    block(a + CHA, b0, b1, b2, b3);
+                    PD_QA_WLOAD(b0, b1, b2, b3, 2 * cn + 1);     //   ... + the next chunk's second block [4]
+                    PD_QA_WAIT(4, a0, a1, a2, a3);               // the next chunk's rows and first block have landed; the second block may still fly
+                } else {                                         // the last chunk requests nothing (round 6; it used to re-stage itself: 1 / 8 of the loop's L2 traffic
+                    block(a, a0, a1, a2, a3);                    //   and a whole load latency at the loop's end, for operands never used)
+                    PD_QA_WAIT(0, b0, b1, b2, b3);
+                    block(a + CHA, b0, b1, b2, b3);
+                }
             } else {                                             // development variants (see BARE): every wait drains
                 if constexpr (BARE != 2 && BARE != 3) stage64(cn, (c + 1) & 1);
                 if constexpr (BARE != 4) block(a, a0, a1, a2, a3);

@@ -69,9 +69,11 @@ def test_denoiser_kernels_keep_their_register_budget(tmp_path):
     # EPI 0 / 2 / 4 at 64-row tiles (4 waves per SIMD: several workgroups share a CU there) + (round 6) EPI 2 / 4 at 96-row tiles (one workgroup per
     # CU by construction: 48 accumulator registers more, 3 waves per SIMD suffice); fp16 planes; nothing spilled
     assert len(strip) == 5, sorted(kernels)
+    # (round 6) the EPI 2 variants also hold the residual tile, requested a K chunk before the epilogue needs it: 4 RT more 16-byte registers, one wave
+    # per SIMD less -- their launches are one workgroup per CU at the bench's shapes (96-row tiles: 216 workgroups; 64-row tiles at 2 060 rows: 132)
     for name, r in strip.items():
-        rt3 = "ELi3ELb1E" in name
-        assert r["Occupancy"] >= (3 if rt3 else 4) and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
+        rt3, epi2 = "ELi3ELb1E" in name, "kernelILi2E" in name
+        assert r["Occupancy"] >= (3 if rt3 else 4) - (1 if epi2 else 0) and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
     dma = {k: v for k, v in kernels.items() if "pd_gemm_dma_kernel" in k}
     assert len(dma) == 5, sorted(kernels)                       # EPI 0, 0 + LN, 1 + LN, 2, and (round 5) 4: _first's step piece + the hoisted z piece
     for name, r in dma.items():
@@ -80,4 +82,4 @@ def test_denoiser_kernels_keep_their_register_budget(tmp_path):
     fused = {k: v for k, v in kernels.items() if "pd_qkv_attn_kernel" in k}
     assert len(fused) == 1, sorted(kernels)                     # (the BARE > 0 variants exist in -DPD_DEV_KNOBS builds only)
     for name, r in fused.items():
-        assert r["VGPRs"] + r.get("AGPRs", 0) <= 168 and r["Occupancy"] == 3 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 168 and r["Occupancy"] >= 3 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
