@@ -966,7 +966,6 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
         for (int q = tid; q < N * rstride * 4; q += NT) ((float4 *)L.pinc)[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     const int my_pair_xz = (my_pair.x & 0xffff) | (my_pair.z << 16), my_pair_y = my_pair.y, my_pair_w = my_pair.w;
-    if (wave == PD_GGS_WAVES - 1 && fast34) jac_all(L, lane, N);   // (L.xst was published before the barrier above; first read two barriers from here)
     unsigned epoch = 0;
     int trace_row = 0;
     // the in-kernel cycle counters cost 24 VGPRs for the whole launch: compiled out of the 12-wave variants, which run at the
@@ -994,8 +993,6 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
             // ---- P1: F for the pairs of this workgroup's items -------------------------------
             const Cam cam = {L.cam[0], L.cam[1], L.cam[2], L.cam[3]};
             if (tid == 0) *q_ctr = NW;                    // first slot the match pass hands out dynamically
-            // an idle wave: the quaternion Jacobian of the parameters the previous iteration left (read two barriers from here)
-            if (wave == PD_GGS_WAVES - 1 && S.update_R && fast34) jac_all(L, lane, N);
             for (int s = tid; s < n_slots && !(PD_GGS_ABLATE & 1); s += NT) {
                 const int4 e = L.itab[s];
                 if (e.y > 0) {
@@ -1204,6 +1201,10 @@ __global__ __launch_bounds__(NW * 64, NW > PD_GGS_WAVES ? 3 : PD_GGS_MIN_WAVES_P
                             for (int c = 0; c < 9; ++c) G[c] += L.item[(mp.y + u) * PD_ITEM_VALS + c];
 #include "pd_ggs_pairbwd.inc"
                     }
+                    // the quaternion Jacobian of this iteration's parameters, on a wave the pair backward leaves idle (<= 276 pairs: waves 0 .. 4), read by P3b behind the
+                    // barrier below.  (Round 6: until here it ran at the top of the iteration, where a one-item-per-wave sequence -- B = 1, k = 24 -- has nothing to hide it
+                    // behind: every wave waited at P1's barrier for this one.)
+                    if (ck == 0 && wave == PD_GGS_WAVES - 1 && S.update_R && fast34) jac_all(L, lane, N);
                 }
                 if (prof) { pq = __builtin_readcyclecounter(); if (lane == 0) L.prof[6] += pq - pc; }
                 __syncthreads();
