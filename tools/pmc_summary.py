@@ -54,10 +54,19 @@ def main():
                 # default mode there (fp16-plane encoder GEMMs): LayerNorm rows x 16, QKV x 8, out-projection + FF2 x 16, FF1 x 8, attention x 8
                 "pd_ln_rows_kernel<512, 2>": 16, "pd_gemm_strip_kernel<0, 2, true": 8, "pd_gemm_strip_kernel<2, 2, true": 16,
                 "pd_gemm_strip_kernel<4, 2, true": 8, "pd_attn_seq_kernel<2>": 8, "pd_attn_mma_kernel<2>": 8,
+                # round 5 / 6 (MISSING from this table until the end of round 6 -- the step figure of rounds 5 and 6 up to then left out the fused attention kernel
+                # and the 96-row strip GEMMs, i.e. most of the step): in_proj + attention in one kernel x 8 (then no <0, 2, true> / pd_attn_* launches), out-projection +
+                # FF2 on 96-row tiles x 16 where the launch takes them (then no <2, 2, true> launches), _first's step piece on the LDS-DMA kernel (EPI 4)
+                "pd_qkv_attn_kernel": 8, "pd_gemm_strip_kernel<2, 3, true": 16, "pd_gemm_strip_kernel<4, 3, true": 8, "pd_gemm_dma_kernel<4, false": 1,
                 # exact mode (PD_OPT_DENOISER_SPLIT = 0): statistics x 16, QKV / FF1 with LayerNorm at the fragment reads x 8 each, out-projection + FF2 x 16
                 "pd_ln_stats_kernel": 16, "pd_gemm_dma_kernel<0, true": 8, "pd_gemm_dma_kernel<1, true": 8, "pd_gemm_dma_kernel<2, false": 16,
                 "pd_attn_seq_kernel<0>": 8}
     den = 0.0
+    names = [k.replace("void ", "") for k in kernels]
+    for a, b in (("pd_gemm_strip_kernel<2, 2, true", "pd_gemm_strip_kernel<2, 3, true"), ("pd_gemm_strip_kernel<4, 2, true", "pd_gemm_strip_kernel<4, 3, true"),
+                 ("pd_gemm_strip_kernel<0, 2, true", "pd_qkv_attn_kernel")):
+        if any(n.startswith(a) for n in names) and any(n.startswith(b) for n in names):
+            sys.exit(f"pmc_summary: both {a} and {b} ran in the profiled process -- alternatives for the same launches of a step; profile one batch size")
     for k, v in kernels.items():
         for pre, n in per_step.items():
             if k.replace("void ", "").startswith(pre):
