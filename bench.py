@@ -212,7 +212,8 @@ def timed_region(bc, dry):
     # every guided step must have run its full 700 iterations (no data-dependent early exit skipped work)
     iters = torch.cat([p.stats[:, :, :, 1].sum(dim=(0, 2)).cpu() for p in pend])
     return {"dt": dt, "pend": pend, "iters": iters, "finite": bool(torch.isfinite(gathered).all().item()),
-            "in_pipe_ms": L.in_pipe_launches([p.stamps for p in pend if getattr(p, "stamps", None) is not None])}
+            "in_pipe_ms": L.in_pipe_launches([p.stamps for p in pend if getattr(p, "stamps", None) is not None]),
+            "in_pipe_busy": L.in_pipe_busy([p.stamps for p in pend if getattr(p, "stamps", None) is not None])}
 
 
 def main():
@@ -258,7 +259,7 @@ def main():
     fast = L.exact_mode(bc, full_pose, n_passes) if (not args.no_fast_mode and EB * N_FRAMES >= PD_STREAM_MIN_ROWS) else None
     fresh = L.fresh_inputs(bc, full_pose, n_passes) if bc.want_fresh else None
     slots_equal = L.headline_slots_equal_alone(bc, full_pose) if rank == 0 else None
-    roofline, ggs_alone_ms = L.roofline_ggs(bc, full_pose, tr["in_pipe_ms"])
+    roofline, ggs_alone_ms = L.roofline_ggs(bc, full_pose, tr["in_pipe_ms"], tr["in_pipe_busy"])
     roofline_den, den_ms = L.roofline_denoiser(bc)
     ranks = L.rank_emulation(bc) if (rank == 0 and world == 1 and not args.no_rank_emulation and bc.strong and EB >= 160) else None
     per_config = L.per_config(bc) if (not args.no_per_config and rank == 0) else None      # (closes the extra contexts: keep it after the legs that use them)

@@ -553,7 +553,34 @@ def in_pipe_launches(stamp_sets):
     return ms
 
 
-def roofline_ggs(bc: Bench, full_pose, in_pipe_ms):
+def in_pipe_busy(stamp_sets):
+    """The same stamps as in_pipe_launches -> (wall ms the chip spent inside AT LEAST ONE of those launches / number of launches, launches whose interval
+    overlaps another's by more than a tenth of itself).  Two contexts' launches that reach the dispatcher together share the CUs workgroup by workgroup: each then
+    lasts about two launch times by its own stamps while the chip did two launches' work -- the mean duration counts that wall time twice, this figure once."""
+    iv = []
+    for st, khz in stamp_sets:
+        for s0, s1 in st.cpu().numpy().astype(np.int64):
+            if s0 > 0 and s1 > s0 and khz > 0:
+                iv.append((s0 / khz, s1 / khz))
+    if not iv:
+        return None, 0
+    iv.sort()
+    busy, cur0, cur1 = 0.0, iv[0][0], iv[0][1]
+    for a, b in iv[1:]:
+        if a > cur1:
+            busy += cur1 - cur0
+            cur0, cur1 = a, b
+        else:
+            cur1 = max(cur1, b)
+    busy += cur1 - cur0
+    over = 0
+    for i, (a, b) in enumerate(iv):
+        o = max((min(b, d) - max(a, c) for j, (c, d) in enumerate(iv) if j != i), default=0.0)
+        over += int(o > 0.1 * (b - a))
+    return busy / len(iv), over
+
+
+def roofline_ggs(bc: Bench, full_pose, in_pipe_ms, busy=(None, 0)):
     """Roofline of the dominant kernel.  `frac` = the launches of the TIMED REGION (in-kernel wall-clock stamps of every one of them, several
     contexts in flight, replayed from captured graphs); the launch alone on an idle chip (hipEvents, pd_time_kernel) is a side figure."""
     eng, EB, depth, cfg, pipe = bc.eng, bc.EB, bc.depth, bc.cfg, bc.pipe
@@ -608,7 +635,11 @@ def roofline_ggs(bc: Bench, full_pose, in_pipe_ms):
         "algorithmic_flops_per_launch": ggs_flops, "algorithmic_flop_per_match_iteration": FLOP_PER_MATCH_ITER,
         "launch_ms": ggs_ms,
         "in_pipe": None if not have_pipe else {"launches": len(in_pipe_ms), "mean_ms": pipe_ms, "min_ms": float(np.min(in_pipe_ms)),
-                                               "max_ms": float(np.max(in_pipe_ms)), "p50_ms": float(np.median(in_pipe_ms))},
+                                               "max_ms": float(np.max(in_pipe_ms)), "p50_ms": float(np.median(in_pipe_ms)),
+                                               "busy_ms_per_launch": busy[0], "overlapping_launches": busy[1],
+                                               "busy_note": "wall time inside at least one of these launches / launches (union of the stamped intervals): launches of two "
+                                                            "contexts that reach the dispatcher together share the CUs and each lasts ~ 2 launch times by its own stamps; "
+                                                            "`frac` keeps the plain mean (what rocprofv3's average duration shows)"},
         "alone": {"launch_ms": alone_ms, "launch_ms_each": ggs_each, "achieved": ggs_flops / (alone_ms * 1e-3) / 1e12,
                   "frac": ggs_flops / (alone_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                   "note": "six single launches after the timed region with nothing else on the chip (hipEvents on the launch's stream, pd_time_kernel): a cooler, "

@@ -17,6 +17,9 @@
 #pragma once
 #include "pd_gemm_split.h"
 
+#ifndef PD_QA_XCD_MAP
+#define PD_QA_XCD_MAP 1
+#endif
 #define PD_QA_WAVES 12
 #define PD_QA_THREADS (PD_QA_WAVES * 64)
 #define PD_QA_ROWS 96                       // three 32-row tiles
@@ -54,9 +57,28 @@ __global__ __launch_bounds__(PD_QA_THREADS) void pd_qkv_attn_kernel(PdQkvAttnArg
     extern __shared__ __attribute__((aligned(1024))) unsigned qa_lds[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // block -> (group of sequences, head): the four heads of a group are neighbours (XCD b % 8 hosts head b % 4: a head's 786 KB of weights
-    // stay in two XCDs' L2s)
-    const int head = blockIdx.x & 3, grp = blockIdx.x >> 2;
+    // block -> (group of sequences, head).  XCD b % 8 runs block b.  PD_QA_XCD_MAP 0 (rounds 5 - 6): the four heads of a group are neighbours -- XCD x hosts head x % 4
+    // (786 KB of weights) and touches the rows of HALF of all groups: every group's rows cross the fabric four times (55 MB per launch at 5 120 rows against 21 if
+    // every operand crossed once; profiles/round6_pmc_summary.json).  1: in chunks of 16 blocks = 4 groups, XCDs 0 - 3 host heads {0, 1}, XCDs 4 - 7 heads {2, 3}, XCD x
+    // the groups = x mod 4: two heads' weights (1.6 MB) and a quarter of the groups' rows per L2, every row crosses twice.  Same workgroups, same arithmetic.
+    int head = blockIdx.x & 3, grp = blockIdx.x >> 2;
+#if PD_QA_XCD_MAP == 1
+    {
+        const int ngrp = gridDim.x >> 2, c = blockIdx.x >> 4, r = blockIdx.x & 15;
+        if (4 * c + 4 <= ngrp) {
+            head = 2 * ((r & 7) >> 2) + (r >> 3);
+            grp = 4 * c + (r & 3);
+        }
+    }
+#elif PD_QA_XCD_MAP == 2      // (measured alternative: all four heads of a group on ONE XCD -- every row crosses once, 3.1 MB of weights per L2)
+    {
+        const int ngrp = gridDim.x >> 2, c = blockIdx.x >> 5, r = blockIdx.x & 31;
+        if (8 * c + 8 <= ngrp) {
+            head = r >> 3;
+            grp = 8 * c + (r & 7);
+        }
+    }
+#endif
     const int N = g.N, G = g.G, M = g.B * N;
     const int seq0 = grp * G, nseq = min(G, g.B - seq0), m0 = seq0 * N, rows = nseq * N;     // this workgroup's token rows [m0, m0 + rows)
     // ---- 1. the in_proj product ------------------------------------------------------------------------------------------------------

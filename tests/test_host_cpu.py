@@ -219,6 +219,11 @@ def test_bench_legs_are_callable_pieces():
     # launch stamps -> durations: {0, 0} slots (another kernel ran) and unordered pairs are dropped
     st = torch.tensor([[1000, 2600], [0, 0], [5000, 4000], [7000, 8650]], dtype=torch.int64)
     assert L.in_pipe_launches([(st, 100.0)]) == [16.0, 16.5] and L.in_pipe_launches([]) == []
+    # ... and the wall time inside at least one launch: two launches that share the chip (overlapping stamps) count their common time once
+    assert L.in_pipe_busy([(st, 100.0)]) == (16.25, 0) and L.in_pipe_busy([]) == (None, 0)
+    st2 = torch.tensor([[1000, 4000], [1100, 4200], [5000, 6600]], dtype=torch.int64)
+    busy, over = L.in_pipe_busy([(st2[:1], 100.0), (st2[1:], 100.0)])
+    assert abs(busy - (32.0 + 16.0) / 3) < 1e-9 and over == 2
     a = bench.parse_args([])
     assert (a.gpus, a.steps, a.warmup, a.scaling, a.pipeline_depth, a.engine_batch) == (1, 24, 4, "strong", 3, 256)
     for leg in ("cpu_baseline", "measure_config", "per_config", "from_images", "pass_latency", "cold_single_batch", "exact_mode", "fresh_inputs",
