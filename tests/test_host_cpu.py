@@ -362,3 +362,20 @@ def test_trace_tools_separate_the_ggs_launch_shapes(tmp_path):
     assert any("pd_ggs_lane_kernel" in ln and "  64 workgroups:     3 launches, average   13.000 ms" in ln for ln in lines), st
     assert any("pd_ggs_kernel" in ln and " 256 workgroups:     3 launches, average    8.000 ms" in ln for ln in lines), st
     assert st.splitlines()[1].startswith("_Z18pd_ggs_lane_kernel")                                   # the table itself: by total time
+
+
+def test_fused_attention_block_mapping_covers_every_group_and_head_once():
+    """pd_qkv_attn_kernel's block -> (sequence group, head) mapping (csrc/pd_qkv_attn.h, PD_QA_XCD_MAP = 1, restated here): in chunks of 16 blocks the XCDs
+    0 - 3 (= block % 8) host heads {0, 1}, XCDs 4 - 7 heads {2, 3}, XCD x the groups = x mod 4; the groups past the last whole chunk keep the neighbour
+    mapping.  Every (group, head) must be some block's, exactly once, for any number of groups; inside whole chunks a block's XCD decides its head pair."""
+    for ngrp in list(range(1, 40)) + [64, 65, 103]:
+        seen = set()
+        for b in range(4 * ngrp):
+            head, grp = b & 3, b >> 2
+            c, r = b >> 4, b & 15
+            if 4 * c + 4 <= ngrp:
+                head, grp = 2 * ((r & 7) >> 2) + (r >> 3), 4 * c + (r & 3)
+                assert head >> 1 == (b % 8) >> 2 and grp % 4 == (b % 8) % 4
+            assert 0 <= head < 4 and 0 <= grp < ngrp
+            seen.add((grp, head))
+        assert len(seen) == 4 * ngrp, ngrp
