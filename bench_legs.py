@@ -522,16 +522,25 @@ def headline_slots_equal_alone(bc: Bench, full_pose):
     """The headline kernel pinned at the headline launch: a guided step of the full engine batch -- the launch shape of
     the timed region: EB workgroups, the lane-per-item kernel -- against the same sequences run ALONE (one workgroup on an idle chip) on a
     second, single-slot engine: bit for bit, all 700 iterations.  (tests/test_gpu_parity_r5.py does this against the oracle too.)"""
-    from posediffusion_amd.engine import PoseEngine
+    from posediffusion_amd import _lib
+    from posediffusion_amd.engine import PoseEngine, make_ggs_cfg
     from posediffusion_amd.host import denoiser_state
     solo = PoseEngine(denoiser_state(bc.diff.model), bc.tables, device=bc.dev, max_B=1, max_N=N_FRAMES)
     big, big_st = bc.eng.ggs_guide(full_pose, 0, bc.cfg)
     bc.eng.check_async()
+    # the single sequence must run on the kernel family the big launch ran on: with one context (--pipeline-depth 1) the configuration leaves the launch shape
+    # to the engine (wgs_per_seq = 0), which picks the lane-per-item kernel for EB sequences and 24 workgroups of the wave-per-item kernel for one
+    solo_cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=bc.cfg.wgs_per_seq, reserved=bc.cfg.reserved)
+    plan8 = (C.c_int * 8)()
+    if bc.cfg.wgs_per_seq == 0 and hasattr(bc.eng.lib, "pd_debug_ggs_plan") and bc.eng.lib.pd_debug_ggs_plan(bc.eng._h, bc.EB, N_FRAMES, C.byref(bc.cfg), plan8) == 0:
+        solo_cfg.wgs_per_seq = int(plan8[0])
+        if plan8[6]:
+            solo_cfg.reserved |= _lib.PD_GGS_CFG_LANE_ITEMS
     ok = True
     for b in bc.check_slots:
         md = bc.inputs[0][2][b]
         solo.set_matches(0, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
-        one, one_st = solo.ggs_guide(full_pose[b:b + 1], 0, bc.cfg)
+        one, one_st = solo.ggs_guide(full_pose[b:b + 1], 0, solo_cfg)
         solo.check_async()
         ok = ok and bool(torch.equal(one[0], big[b])) and bool(torch.equal(one_st[0], big_st[b])) \
             and float(one_st[0, :, 1].sum().item()) == 7.0 * bc.cfg.iter_num

@@ -125,3 +125,44 @@ def test_ggs_launch_stamps_and_stage_table(engine, golden):
     it = (C.c_int * 5)()
     _lib.check(engine.lib.pd_ggs_stage_iters(C.byref(make_ggs_cfg(iter_num=7)), it), "pd_ggs_stage_iters")
     assert list(it) == [14, 7, 7, 7, 14]
+
+
+def test_lane_kernel_launch_of_more_workgroups_than_cus(seeded_diffuser, engine):
+    """A guided step of 640 sequences in ONE launch of pd_ggs_lane_kernel (one workgroup per sequence: 2.5 x the chip's 256 CUs, the dispatcher back-fills a CU
+    as its workgroup finishes -- what `bench.py --engine-batch 512 / 768` launches; geometry_guided_sampling.py:67-172).  The slots cycle through five distinct
+    sequences: EVERY slot must be bitwise the sequence run alone (one workgroup on an idle chip, an engine of its own), all 700 iterations stepped, and the
+    launch repeated bitwise itself."""
+    from posediffusion_amd.engine import PoseEngine
+    from posediffusion_amd.host import denoiser_state
+    B, N, K = 640, 20, 5
+    dev = torch.device(DEV)
+    diff = seeded_diffuser.to(dev)
+    cfg = make_ggs_cfg(synth.GGS_CFG, wgs_per_seq=1, reserved=LANE)
+    mds, x0s, alone = [], [], []
+    for s in range(K):
+        enc = synth.make_cameras(N, seed=8100 + s)
+        mds.append(synth.make_matches(enc, 224, 224, per_pair=300, seed=8100 + s))
+        x0s.append(synth.perturb_pose(enc, seed=40 + s))
+        engine.set_matches(0, mds[s]["kp1"], mds[s]["kp2"], mds[s]["i12"], mds[s]["img_shape"])
+        o, st = engine.ggs_guide(x0s[s].to(dev), 0, cfg)
+        engine.check_async()
+        assert float(st[0, :, 1].sum()) == 700.0
+        alone.append((o[0].clone(), st[0].clone()))
+    big = PoseEngine(denoiser_state(diff.model), {k: v for k, v in diff.named_buffers(recurse=False)}, device=dev, max_B=B, max_N=N)
+    try:
+        for b in range(B):
+            md = mds[b % K]
+            big.set_matches(b, md["kp1"], md["kp2"], md["i12"], md["img_shape"])
+        x0 = torch.cat([x0s[b % K] for b in range(B)]).to(dev)
+        plan = (C.c_int * 8)()
+        _lib.check(big.lib.pd_debug_ggs_plan(big._h, B, N, C.byref(cfg), plan), "pd_debug_ggs_plan")
+        assert plan[0] == 1 and plan[6] == 1, list(plan)
+        o1, st1 = big.ggs_guide(x0, 0, cfg)
+        big.check_async()
+        o2, st2 = big.ggs_guide(x0, 0, cfg)
+        big.check_async()
+        assert torch.equal(o1, o2) and torch.equal(st1, st2)
+        bad = [b for b in range(B) if not (torch.equal(o1[b], alone[b % K][0]) and torch.equal(st1[b], alone[b % K][1]))]
+        assert not bad, (len(bad), bad[:16])
+    finally:
+        big.close()
